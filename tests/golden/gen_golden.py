@@ -1,0 +1,455 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE's own modules.
+
+Run in the authoring container only (needs /root/reference):
+
+    python tests/golden/gen_golden.py [name ...]
+
+Each fixture is a small .npz holding the reference outputs (+ a json ``meta`` with the
+configuration and the state_dict manifest).  Weights and inputs are rebuilt on both sides from
+seeds (tests/golden/_synth.py), so the fixtures stay small.  The reference is imported through
+tests/golden/ref_shim.py; the only substituted arithmetic is MSDeformAttnFunction ->
+ms_deform_attn_core_pytorch, the reference's own CPU formulation
+(ops/functions/ms_deform_attn_func.py:43-63).
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _synth  # noqa: E402
+import ref_shim  # noqa: E402
+
+ref = ref_shim.ref
+torch.set_grad_enabled(False)
+
+
+def NS(**kw):
+    return types.SimpleNamespace(**kw)
+
+
+def save(name, meta, **arrays):
+    """tensors with more than _synth.MAX_ELEMS elements are stored as a strided subsample of the flattened
+    tensor (meta["subsampled"][key] = [step, full_shape]); tests compare with _synth.subsample()."""
+    out = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()}
+    meta = dict(meta)
+    meta["subsampled"] = {}
+    for k in list(out):
+        if out[k].size > _synth.MAX_ELEMS:
+            step = _synth.sub_step(out[k].size)
+            meta["subsampled"][k] = [step, list(out[k].shape)]
+            out[k] = out[k].reshape(-1)[::step].copy()
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote %-28s %8.1f KB  %s" % (name + ".npz", os.path.getsize(path) / 1024, sorted(arrays)))
+
+
+def man_json(man):
+    return {k: list(v) for k, v in man.items()}
+
+
+# ------------------------------------------------------------------------------ configs
+TINY = dict(
+    backbone="vit", vit_embed_dim=160, vit_depth=3, vit_heads=2, vit_window=14, vit_window_blocks=[0, 1],
+    vit_img_size=1024, vit_patch=16, vit_pretrain_img_size=224, vit_mlp_ratio=4.0,
+    hidden_dim=256, nheads=8, dim_feedforward=256, enc_layers=2, dec_layers=2, num_feature_levels=4,
+    enc_n_points=4, dec_n_points=4, num_queries=40, num_bg_queries=10, num_vl_layers=1, vl_hidden_dim=2048,
+    lang_dim=768, mask_stride=4, ctrl_layers=3,
+    md_num_queries=30, md_dec_layers=3, md_enc_layers=2, md_dim_feedforward=256, md_enc_dim_feedforward=256,
+    md_mask_dim=256, md_conv_dim=256,
+    bert_layers=2, bert_hidden=768, bert_heads=12, bert_intermediate=3072, bert_vocab=30522, bert_max_pos=512,
+    pixel_mean=[123.675, 116.280, 103.530], pixel_std=[58.395, 57.120, 57.375],
+)
+
+
+def hipie_cfg(c):
+    """The yacs keys the imported reference modules read, as a SimpleNamespace tree
+    (values: configs/eval/image_joint_r50_pan_maskdino_ade_test.yaml + hipie/config.py defaults)."""
+    fuse = NS(CLAMP_MIN_FOR_UNDERFLOW=True, CLAMP_MAX_FOR_OVERFLOW=True, CLAMP_BERTATTN_MIN_FOR_UNDERFLOW=True,
+              CLAMP_BERTATTN_MAX_FOR_OVERFLOW=True, STABLE_SOFTMAX_2D=False, CLAMP_DOT_PRODUCT=True)
+    model = NS(
+        USE_EARLY_FUSION=True, USE_ADDITIONAL_BERT=False, VL_FUSION_USE_CHECKPOINT=False,
+        DECOUPLE_TGT=True, STILL_TGT_FOR_BOTH=True, USE_IOU_BRANCH=True, STILL_CLS_FOR_ENCODER=True,
+        DEVICE="cpu",
+        LANGUAGE_BACKBONE=NS(MODEL_TYPE="bert-base-uncased", MAX_QUERY_LEN=256, N_LAYERS=1, LANG_DIM=c["lang_dim"],
+                             USE_CHECKPOINT=False),
+        DYHEAD=NS(PRIOR_PROB=0.01, LOG_SCALE=0.0, FUSE_CONFIG=fuse),
+        DDETRS=NS(HIDDEN_DIM=c["hidden_dim"], NUM_VL_LAYERS=c["num_vl_layers"], VL_HIDDEN_DIM=c["vl_hidden_dim"],
+                  ENC_LAYERS=c["enc_layers"], TWO_STAGE_NUM_BG_PROPOSALS=c["num_bg_queries"],
+                  TWO_STAGE_NUM_PROPOSALS=c["num_queries"], CTRL_LAYERS=c["ctrl_layers"]),
+        PARALLEL_DET=False,
+    )
+    return NS(MODEL=model)
+
+
+# ------------------------------------------------------------------------------ MSDA
+def gen_msda():
+    fn = ref("models.deformable_detr.ops.functions.ms_deform_attn_func")
+    core = fn.ms_deform_attn_core_pytorch
+    arrays, meta = {}, {"cases": []}
+    # (1) the reference's own test recipe, ops/test.py:21-36,52-66 (CPU instead of .cuda())
+    N, M, D, Lq, L, P = 1, 2, 2, 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long)
+    S = int(shapes.prod(1).sum())
+    torch.manual_seed(3)
+    for tag, dt in (("ref_double", torch.float64), ("ref_float", torch.float32)):
+        value = torch.rand(N, S, M, D) * 0.01
+        loc = torch.rand(N, Lq, M, L, P, 2)
+        attn = torch.rand(N, Lq, M, L, P) + 1e-5
+        attn /= attn.sum(-1, keepdim=True).sum(-2, keepdim=True)
+        out = core(value.to(dt), shapes, loc.to(dt), attn.to(dt))
+        arrays.update({tag + "_value": value, tag + "_loc": loc, tag + "_attn": attn, tag + "_out": out,
+                       tag + "_shapes": shapes})
+        meta["cases"].append(tag)
+    # (2) hot-path geometry M=8, D=32, L=4, P=4, locations incl. out-of-range
+    for tag, B, Lq, shp, seed in (("hot_enc", 2, 340, [(16, 16), (8, 8), (4, 4), (2, 2)], 11),
+                                  ("hot_dec", 1, 37, [(16, 16), (8, 8), (4, 4), (2, 2)], 12),
+                                  ("hot_rect", 2, 50, [(12, 20), (6, 10), (3, 5), (2, 3)], 13)):
+        shapes = torch.as_tensor(shp, dtype=torch.long)
+        S = int(shapes.prod(1).sum())
+        g = torch.Generator().manual_seed(seed)
+        value = torch.randn(B, S, 8, 32, generator=g)
+        loc = torch.rand(B, Lq, 8, 4, 4, 2, generator=g) * 1.2 - 0.1
+        attn = torch.softmax(torch.randn(B, Lq, 8, 16, generator=g), -1).view(B, Lq, 8, 4, 4)
+        out = core(value, shapes, loc, attn)
+        arrays.update({tag + "_out": out, tag + "_shapes": shapes})
+        meta["cases"].append(tag)
+        meta[tag] = dict(B=B, Lq=Lq, seed=seed)
+    save("msda", meta, **arrays)
+
+
+# ------------------------------------------------------------------------------ ViT attention / backbone
+def gen_vit_attn():
+    vit = ref("backbone.vit")
+    arrays, meta = {}, {"cases": {}}
+    cases = {
+        # name: (dim, heads, input_size for rel-pos table, (B,H,W) of x)
+        "window14": (160, 2, (14, 14), (3, 14, 14)),
+        "global16": (160, 2, (64, 64), (2, 16, 16)),     # table 127 -> interpolated to 31
+        "global64": (80, 1, (64, 64), (1, 64, 64)),      # the real 64x64 geometry, 1 head
+        "global_rect": (160, 2, (64, 64), (1, 12, 20)),  # non-square token grid
+    }
+    for name, (dim, heads, insz, (B, H, W)) in cases.items():
+        m = vit.Attention(dim, num_heads=heads, qkv_bias=True, use_rel_pos=True, rel_pos_zero_init=True,
+                          input_size=insz).eval()
+        man = _synth.load_synth(m, seed=21)
+        x = _synth.synth_tensor("x_" + name, (B, H, W, dim), seed=22) * 8.0
+        arrays[name + "_out"] = m(x)
+        meta["cases"][name] = dict(dim=dim, heads=heads, input_size=list(insz), x_shape=[B, H, W, dim],
+                                   manifest=man_json(man))
+    save("vit_attn", meta, **arrays)
+
+
+def build_ref_vit(c):
+    vit = ref("backbone.vit")
+    from functools import partial
+    m = vit.ViT(img_size=c["vit_img_size"], patch_size=c["vit_patch"], in_chans=3, embed_dim=c["vit_embed_dim"],
+                depth=c["vit_depth"], num_heads=c["vit_heads"], drop_path_rate=0.0, window_size=c["vit_window"],
+                mlp_ratio=c["vit_mlp_ratio"], qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                window_block_indexes=c["vit_window_blocks"], residual_block_indexes=[], use_rel_pos=True,
+                out_feature="last_feat", use_act_checkpoint=False,
+                pretrain_img_size=c["vit_pretrain_img_size"]).eval()
+    return m
+
+
+def gen_vit_backbone():
+    c = TINY
+    m = build_ref_vit(c)
+    man = _synth.load_synth(m, seed=31)
+    x = _synth.synth_tensor("vit_in", (2, 3, 256, 224 + 32), seed=32)
+    out = m(x)
+    save("vit_backbone", dict(cfg=c, manifest=man_json(man), x_shape=list(x.shape)),
+         res3=out["res3"], res4=out["res4"], res5=out["res5"])
+
+
+# ------------------------------------------------------------------------------ VL fusion
+def gen_bi_attn():
+    fh = ref("models.deformable_detr.fuse_helper")
+    cfg = hipie_cfg(TINY)
+    arrays, meta = {}, {"cases": {}}
+    for name, (B, Nv, L, npad, scale) in {"L20": (2, 340, 20, 3, 1.0), "L600_pad": (1, 340, 600, 300, 1.0),
+                                          "clamp": (1, 64, 20, 5, 3000.0)}.items():
+        m = fh.BiAttentionBlockForCheckpoint(v_dim=256, l_dim=768, embed_dim=2048, num_heads=8, dropout=0.1,
+                                             drop_path=0.0, init_values=1.0 / 6, cfg=cfg).eval()
+        man = _synth.load_synth(m, seed=41)
+        v = _synth.synth_tensor("v_" + name, (B, Nv, 256), seed=42) * 16 * scale
+        l = _synth.synth_tensor("l_" + name, (B, L, 768), seed=43) * 27 * scale
+        mask = torch.ones(B, L, dtype=torch.long)
+        mask[:, L - npad:] = 0
+        if B > 1:
+            mask[1, L - 2 * npad:] = 0
+        ov, ol = m(v, l, attention_mask_l=mask)
+        arrays.update({name + "_v": ov, name + "_l": ol, name + "_mask": mask})
+        meta["cases"][name] = dict(B=B, Nv=Nv, L=L, scale=scale, manifest=man_json(man))
+    save("bi_attn", meta, **arrays)
+
+
+# ------------------------------------------------------------------------------ BERT wrapper
+def build_ref_bert(c):
+    bm = ref("models.deformable_detr.bert_model")
+    from transformers import BertConfig, BertModel
+    conf = BertConfig(vocab_size=c["bert_vocab"], hidden_size=c["bert_hidden"], num_hidden_layers=c["bert_layers"],
+                      num_attention_heads=c["bert_heads"], intermediate_size=c["bert_intermediate"],
+                      max_position_embeddings=c["bert_max_pos"], hidden_dropout_prob=0.0,
+                      attention_probs_dropout_prob=0.0)
+    enc = bm.BertEncoder.__new__(bm.BertEncoder)
+    nn.Module.__init__(enc)
+    enc.model = BertModel(conf, add_pooling_layer=False)
+    enc.language_dim, enc.num_layers, enc.parallel_det = 768, 1, False
+    return enc.eval()
+
+
+def gen_bert():
+    c = TINY
+    enc = build_ref_bert(c)
+    man = _synth.load_synth(enc, seed=51)
+    arrays = {}
+    ids, mask, _ = _synth.synth_token_ids(2, 9, 64, seed=52)
+    arrays["short_hidden"] = enc({"input_ids": ids, "attention_mask": mask}, sep=1012)["hidden"]
+    arrays["short_ids"], arrays["short_mask"] = ids, mask
+    ids, mask, _ = _synth.synth_token_ids(2, 400, 1400, seed=53, pad_to=1536)
+    out = enc({"input_ids": ids.clone(), "attention_mask": mask}, sep=1012)
+    arrays["long_hidden"] = out["hidden"]
+    arrays["long_ids"], arrays["long_mask"] = ids, mask
+    save("bert", dict(cfg=c, manifest=man_json(man)), **arrays)
+
+
+# ------------------------------------------------------------------------------ dynamic mask head (CondInst)
+def gen_dynamic_mask():
+    dn = ref("models.ddetrs_dn")
+    fake = NS(no_rel_pos=False, dynamic_mask_channels=8, weight_nums=[80, 64, 8], bias_nums=[8, 8, 1],
+              mask_out_stride=4, use_raft=False)
+    fake.mask_heads_forward = types.MethodType(dn.DDETRSegmUniDN.mask_heads_forward, fake)
+    arrays, meta = {}, {"cases": {}}
+    for name, (B, Q, H, W) in {"sq": (2, 37, 32, 32), "rect": (1, 21, 20, 28)}.items():
+        feats = _synth.synth_tensor("dm_feats_" + name, (B, 8, H, W), seed=61) * 20
+        refs = torch.rand(1, B * Q, 2, generator=torch.Generator().manual_seed(62)) * torch.tensor([W * 8.0, H * 8.0])
+        params = _synth.synth_tensor("dm_params_" + name, (1, B * Q, 169), seed=63) * 6
+        out = dn.DDETRSegmUniDN.dynamic_mask_with_coords(fake, feats, refs, params, num_insts=[Q] * B,
+                                                         mask_feat_stride=8, rel_coord=True, up_masks=None)
+        arrays.update({name + "_out": out, name + "_refs": refs})
+        meta["cases"][name] = dict(B=B, Q=Q, H=H, W=W)
+    # aligned_bilinear on its own
+    x = _synth.synth_tensor("ab_x", (3, 1, 9, 13), seed=64) * 10
+    arrays["aligned_bilinear_out"] = dn.aligned_bilinear(x, 2)
+    save("dynamic_mask", meta, **arrays)
+
+
+# ------------------------------------------------------------------------------ full model (a22 parity surface)
+class _ImageList:
+    """the two things coco_inference needs from detectron2.structures.ImageList
+    (hipie/models/ddetrs_dn.py:804-807): .image_sizes and iteration over unpadded images."""
+
+    def __init__(self, tensors, image_sizes):
+        self.tensor, self.image_sizes = tensors, image_sizes
+
+    def __iter__(self):
+        for t, (h, w) in zip(self.tensor, self.image_sizes):
+            yield t[:, :h, :w]
+
+    def __len__(self):
+        return len(self.image_sizes)
+
+
+def build_ref_maskdino(c, in_shape):
+    enc_m = ref("models.maskdino.pixel_decoder.maskdino_encoder")
+    dec_m = ref("models.maskdino.transformer_decoder.maskdino_decoder")
+    head_m = ref("models.maskdino.meta_arch.maskdino_head")
+    # values: configs/mask_dino/maskdino_R50_bs16_50ep_3s_dowsample1_2048.yaml
+    pix = enc_m.MaskDINOEncoder(
+        input_shape=in_shape, transformer_dropout=0.0, transformer_nheads=8,
+        transformer_dim_feedforward=c["md_enc_dim_feedforward"], transformer_enc_layers=c["md_enc_layers"],
+        conv_dim=c["md_conv_dim"], mask_dim=c["md_mask_dim"], norm="GN",
+        transformer_in_features=["res3", "res4", "res5"], common_stride=4, num_feature_levels=3,
+        total_num_feature_levels=4, feature_order="low2high")
+    dec = dec_m.MaskDINODecoder(
+        in_channels=c["md_conv_dim"], mask_classification=True, num_classes=c["hidden_dim"], hidden_dim=256,
+        num_queries=c["md_num_queries"], nheads=8, dim_feedforward=c["md_dim_feedforward"],
+        dec_layers=c["md_dec_layers"], mask_dim=c["md_mask_dim"], enforce_input_project=False, two_stage=True,
+        dn="seg", noise_scale=0.4, dn_num=100, initialize_box_type="no", initial_pred=True, learn_tgt=False,
+        total_num_feature_levels=4, dropout=0.0, semantic_ce_loss=False, dynamic_label_enc=True,
+        dynamic_label_enc_dropout=0.1)
+    head = head_m.MaskDINOHead(input_shape=in_shape, num_classes=c["hidden_dim"], pixel_decoder=pix,
+                               loss_weight=1.0, ignore_value=255, transformer_predictor=dec)
+    return head
+
+
+def build_ref_model(c):
+    """Assemble HIPIE_IMG.detr (DDETRSegmUniDN) from the reference's own classes, following
+    hipie_img.py:77-176 and ddetrs_dn.py:90-215, without detectron2's config/registry layer."""
+    cfg = hipie_cfg(c)
+    vit = build_ref_vit(c)
+    mb_m = ref("backbone.masked_backbone")
+    bb_m = ref("models.deformable_detr.backbone")
+    pe_m = ref("models.deformable_detr.position_encoding")
+    tr_m = ref("models.deformable_detr.deformable_transformer_dino")
+    dd_m = ref("models.deformable_detr.deformable_detr")
+    dn_m = ref("models.ddetrs_dn")
+    E = c["vit_embed_dim"]
+    in_shape = {"res3": ref_shim.ShapeSpec(channels=E // 2, stride=8), "res4": ref_shim.ShapeSpec(channels=E, stride=16),
+                "res5": ref_shim.ShapeSpec(channels=E, stride=32)}
+
+    class _D2ViT(vit.__class__):  # D2ViT.forward/output_shape/size_divisibility (vit.py:440-466)
+        size_divisibility = 32
+
+        def output_shape(self):
+            return in_shape
+    vit.__class__ = _D2ViT
+    masked = mb_m.MaskedBackbone.__new__(mb_m.MaskedBackbone)
+    nn.Module.__init__(masked)
+    masked.backbone = vit
+    masked.feature_strides = [8, 16, 32]
+    masked.num_channels = [E // 2, E, E]
+    backbone = bb_m.Joiner(masked, pe_m.PositionEmbeddingSine(c["hidden_dim"] // 2, normalize=True))
+    backbone.num_channels = masked.num_channels
+    backbone.strides = masked.feature_strides
+    transformer = tr_m.DeformableTransformerVLDINO(
+        d_model=c["hidden_dim"], nhead=c["nheads"], num_encoder_layers=c["enc_layers"],
+        num_decoder_layers=c["dec_layers"], dim_feedforward=c["dim_feedforward"], dropout=0.0, activation="relu",
+        return_intermediate_dec=True, num_feature_levels=4, dec_n_points=4, enc_n_points=4, two_stage=True,
+        two_stage_num_proposals=c["num_queries"], use_checkpoint=False, look_forward_twice=True,
+        mixed_selection=True, cfg=cfg)
+    detr = dd_m.DeformableDETRDINO(backbone, transformer, num_queries=c["num_queries"], num_feature_levels=4,
+                                   aux_loss=True, with_box_refine=True, two_stage=True, mixed_selection=True, cfg=cfg)
+    model = dn_m.DDETRSegmUniDN.__new__(dn_m.DDETRSegmUniDN)
+    nn.Module.__init__(model)
+    model.detr = detr
+    model.rel_coord, model.ota, model.decouple_tgt, model.cls_pool_type = True, True, True, "average"
+    model.use_iou_branch, model.new_mask_head, model.use_raft = True, False, False
+    model.in_channels, model.dynamic_mask_channels, model.controller_layers = 8, 8, 3
+    model.mask_out_stride, model.up_rate = 4, 2
+    model.weight_nums, model.bias_nums, model.num_gen_params = [80, 64, 8], [8, 8, 1], 169
+    model.controller = dn_m.MLP(256, 256, 169, 3)
+    model.mask_head = dn_m.MaskHeadSmallConv(256, None, 256, use_raft=False, up_rate=2)
+    model.resizer = tr_m.FeatureResizer(input_feat_size=768, output_feat_size=256, dropout=0.0)
+    model.no_rel_pos, model.decouple_decoder = False, True
+    model.mask_dino_fixed_linear_head, model.mask_dino_share_encoder, model.mask_dino_share_cls_head = False, False, False
+    model.mask_dino = build_ref_maskdino(c, in_shape)
+    model.feature_keys = ["res3", "res4", "res5"]
+    model.mask_dino_cls_embed = dn_m._get_clones(detr.class_embed[0], c["md_dec_layers"] + 2)
+    return model.eval()
+
+
+def gen_e2e():
+    c = TINY
+    model = build_ref_model(c)
+    bert = build_ref_bert(c)
+    man = _synth.load_synth(model, seed=71)
+    man_b = _synth.load_synth(bert, seed=72)
+    full_man = {"detr." + k: v for k, v in man.items()}
+    full_man.update({"text_encoder.body." + k: v for k, v in man_b.items()})
+    sizes = [(200, 256), (256, 224)]
+    imgs = _synth.synth_images(sizes, seed=73)
+    mean = torch.tensor(c["pixel_mean"]).view(3, 1, 1)
+    std = torch.tensor(c["pixel_std"]).view(3, 1, 1)
+    # HIPIE_IMG.preprocess_image (hipie_img.py:880-898): normalise, ImageList.from_tensors (pad to max HxW)
+    norm = [(x - mean) / std for x in imgs]
+    Hm, Wm = max(s[0] for s in sizes), max(s[1] for s in sizes)
+    batched = torch.zeros(len(imgs), 3, Hm, Wm)
+    for i, x in enumerate(norm):
+        batched[i, :, :x.shape[1], :x.shape[2]] = x
+    images = _ImageList(batched, sizes)
+    arrays, meta = {}, dict(cfg=c, manifest=man_json(full_man), sizes=sizes)
+    topk_log = []
+    real_topk = torch.topk
+
+    def spy_topk(*a, **k):
+        r = real_topk(*a, **k)
+        topk_log.append(r[1].clone())
+        return r
+    for task, ncls in (("detection", 9), ("grounding", 1)):
+        ids, mask, pmap = _synth.synth_token_ids(2, ncls, 64, seed=74)
+        lang = bert({"input_ids": ids, "attention_mask": mask}, sep=1012)
+        arrays[task + "_lang_hidden"] = lang["hidden"].clone()
+        topk_log.clear()
+        torch.topk = spy_topk
+        try:
+            out, _ = model.coco_inference(images, None, None, train=False,
+                                          language_dict_features={"hidden": lang["hidden"].clone(), "masks": lang["masks"]},
+                                          task=task, bg_queries_lang=None)
+        finally:
+            torch.topk = real_topk
+        for k, v in out.items():
+            if torch.is_tensor(v):
+                arrays[task + "_" + k] = v
+        arrays[task + "_topk_fg"] = topk_log[0]
+        arrays[task + "_topk_md"] = topk_log[1]
+        meta[task] = dict(n_classes=ncls, L=int(ids.shape[1]), pmap={str(k): v for k, v in pmap.items()})
+    save("e2e_tiny", meta, **arrays)
+
+
+# ------------------------------------------------------------------------------ sub-module goldens from the e2e model
+def gen_stages():
+    """Intermediate tensors of the same tiny model (detection task), for stage-by-stage checks:
+    backbone+pos, input_proj, encoder memory, two-stage selection, decoder hs, MaskDINO pixel decoder."""
+    c = TINY
+    model = build_ref_model(c)
+    bert = build_ref_bert(c)
+    _synth.load_synth(model, seed=71)
+    _synth.load_synth(bert, seed=72)
+    sizes = [(200, 256), (256, 224)]
+    imgs = _synth.synth_images(sizes, seed=73)
+    mean = torch.tensor(c["pixel_mean"]).view(3, 1, 1)
+    std = torch.tensor(c["pixel_std"]).view(3, 1, 1)
+    batched = torch.zeros(2, 3, 256, 256)
+    for i, x in enumerate(imgs):
+        batched[i, :, :x.shape[1], :x.shape[2]] = (x - mean) / std
+    misc = ref("util.misc")
+    samples = misc.nested_tensor_from_tensor_list(list(_ImageList(batched, sizes)), size_divisibility=32)
+    feats, pos = model.detr.backbone(samples)
+    arrays = {}
+    for i, (f, p) in enumerate(zip(feats, pos)):
+        arrays["feat%d" % i], arrays["pos%d" % i], arrays["mask%d" % i] = f.tensors, p, f.mask
+    ids, mask, _ = _synth.synth_token_ids(2, 9, 64, seed=74)
+    lang = bert({"input_ids": ids, "attention_mask": mask}, sep=1012)
+    caps = {}
+    tr = model.detr.transformer
+
+    def hook(name):
+        def f(mod, inp, out):
+            caps[name] = out
+        return f
+    hs = [tr.encoder.register_forward_hook(hook("encoder")),
+          tr.encoder.vl_layers[0].register_forward_hook(hook("vl0")),
+          tr.decoder.register_forward_hook(hook("decoder")),
+          model.mask_head.register_forward_hook(hook("mask_head")),
+          model.mask_dino.pixel_decoder.transformer.register_forward_hook(hook("md_enc"))]
+    md_pix = {}
+    orig_ff = model.mask_dino.pixel_decoder.forward_features
+
+    def ff(features, masks):
+        r = orig_ff(features, masks)
+        md_pix["mask_features"], md_pix["ms"] = r[0], r[2]
+        return r
+    model.mask_dino.pixel_decoder.forward_features = ff
+    out, _ = model.coco_inference(_ImageList(batched, sizes), None, None, train=False,
+                                  language_dict_features={"hidden": lang["hidden"].clone(), "masks": lang["masks"]},
+                                  task="detection", bg_queries_lang=None)
+    for h in hs:
+        h.remove()
+    arrays["vl0_visual"] = caps["vl0"]["visual"]
+    arrays["vl0_lang"] = caps["vl0"]["lang"]["hidden"]
+    arrays["memory"] = caps["encoder"]["visual"]
+    arrays["dec_hs"], arrays["dec_refs"] = caps["decoder"][0], caps["decoder"][1]
+    arrays["mask_head_out"] = caps["mask_head"]
+    arrays["md_enc_memory"] = caps["md_enc"][0]
+    arrays["md_mask_features"] = md_pix["mask_features"]
+    for i, t in enumerate(md_pix["ms"]):
+        arrays["md_ms%d" % i] = t
+    save("stages_tiny", dict(cfg=c, sizes=sizes), **arrays)
+
+
+ALL = dict(msda=gen_msda, vit_attn=gen_vit_attn, vit_backbone=gen_vit_backbone, bi_attn=gen_bi_attn, bert=gen_bert,
+           dynamic_mask=gen_dynamic_mask, e2e=gen_e2e, stages=gen_stages)
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(ALL)
+    for n in names:
+        ALL[n]()
