@@ -11,6 +11,7 @@ the reference outputs.
 The rules avoid the degenerate initialisations of the reference (zero rel_pos tables, zero
 sampling_offsets weights, zero last bbox layer -- SURVEY 8d) so every kernel does real work.
 """
+import re
 import zlib
 
 import numpy as np
@@ -23,7 +24,24 @@ def _gen(seed, name):
     return g
 
 
+_ALIASES = (
+    # the reference registers some modules under several names (shared objects): the box/class heads are
+    # also attached to the decoder (deformable_detr.py:272,282), MaskDINO shares one _bbox_embed across
+    # layers and the decoder (maskdino_decoder.py:158-163) and decoder.norm is decoder_norm (:147-149).
+    (re.compile(r"\.transformer\.decoder\.(bbox_embed|class_embed)\."), r".\1."),
+    (re.compile(r"predictor\.(decoder\.)?bbox_embed\.\d+\."), "predictor._bbox_embed."),
+    (re.compile(r"predictor\.decoder\.norm\."), "predictor.decoder_norm."),
+)
+
+
+def canonical_key(name):
+    for pat, rep in _ALIASES:
+        name = pat.sub(rep, name)
+    return name
+
+
 def synth_tensor(name, shape, seed=0, dtype=torch.float32):
+    name = canonical_key(name)
     shape = tuple(int(s) for s in shape)
     g = _gen(seed, name)
     leaf = name.split(".")[-1]
@@ -131,3 +149,18 @@ def sub_step(numel):
 
 def subsample(t, step):
     return t.reshape(-1)[::step]
+
+
+def synth_full_state_dict(manifest, seed_detr=71, seed_text=72):
+    """State dict of the whole HIPIE_IMG model ("detr.*" + "text_encoder.body.*" keys) with the
+    same values gen_golden.py loaded into the reference's DDETRSegmUniDN / BertEncoder (which it built
+    separately, so the seeds and key prefixes differ)."""
+    out = {}
+    for k, shp in manifest.items():
+        if k.startswith("detr."):
+            out[k] = synth_tensor(k[len("detr."):], shp, seed_detr)
+        elif k.startswith("text_encoder.body."):
+            out[k] = synth_tensor(k[len("text_encoder.body."):], shp, seed_text)
+        else:
+            raise KeyError(k)
+    return out

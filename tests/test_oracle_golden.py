@@ -1,0 +1,160 @@
+"""CPU: the oracle (oracle/) against the golden fixtures produced by the reference's own modules.
+This is what pins the oracle (there are no reference tests for this path beyond ops/test.py)."""
+import pytest
+import torch
+
+import _synth
+from oracle import model as om
+from oracle import ops as oo
+from util import Golden, rel_err
+
+torch.set_grad_enabled(False)
+TOL = 2e-5   # fp32 CPU vs fp32 CPU, different summation order only
+
+
+def test_msda_reference_recipe():
+    g = Golden("msda")
+    for tag, dt, tol in (("ref_double", torch.float64, 1e-12), ("ref_float", torch.float32, 1e-6)):
+        out = oo.ms_deform_attn_core(g[tag + "_value"].to(dt), g[tag + "_shapes"], g[tag + "_loc"].to(dt), g[tag + "_attn"].to(dt))
+        assert rel_err(out, g[tag + "_out"]) < tol
+
+
+def msda_case(g, tag):
+    m = g.meta[tag]
+    shapes = g[tag + "_shapes"]
+    S = int(shapes.prod(1).sum())
+    gen = torch.Generator().manual_seed(m["seed"])
+    value = torch.randn(m["B"], S, 8, 32, generator=gen)
+    loc = torch.rand(m["B"], m["Lq"], 8, 4, 4, 2, generator=gen) * 1.2 - 0.1
+    attn = torch.softmax(torch.randn(m["B"], m["Lq"], 8, 16, generator=gen), -1).view(m["B"], m["Lq"], 8, 4, 4)
+    return value, shapes, loc, attn
+
+
+@pytest.mark.parametrize("tag", ["hot_enc", "hot_dec", "hot_rect"])
+def test_msda_hot_geometry(tag):
+    g = Golden("msda")
+    value, shapes, loc, attn = msda_case(g, tag)
+    out = oo.ms_deform_attn_core(value, shapes, loc, attn)
+    assert rel_err(g.like(tag + "_out", out), g[tag + "_out"]) < TOL
+
+
+def vit_attn_case(g, name):
+    c = g.meta["cases"][name]
+    sd = _synth.synth_state_dict({k: tuple(v) for k, v in c["manifest"].items()}, seed=21)
+    x = _synth.synth_tensor("x_" + name, c["x_shape"], seed=22) * 8.0
+    return c, sd, x
+
+
+@pytest.mark.parametrize("name", ["window14", "global16", "global64", "global_rect"])
+def test_vit_attention(name):
+    g = Golden("vit_attn")
+    c, sd, x = vit_attn_case(g, name)
+    out = oo.vit_attention(x, sd, "", c["heads"])
+    assert rel_err(g.like(name + "_out", out), g[name + "_out"]) < TOL
+
+
+def test_vit_backbone():
+    g = Golden("vit_backbone")
+    cfg = g.meta["cfg"]
+    sd = _synth.synth_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}, seed=31)
+    x = _synth.synth_tensor("vit_in", g.meta["x_shape"], seed=32)
+    out = om.vit_backbone(x, sd, "", cfg)
+    for k in ("res3", "res4", "res5"):
+        assert rel_err(g.like(k, out[k]), g[k]) < TOL
+
+
+def bi_case(g, name):
+    c = g.meta["cases"][name]
+    sd = _synth.synth_state_dict({k: tuple(v) for k, v in c["manifest"].items()}, seed=41)
+    v = _synth.synth_tensor("v_" + name, (c["B"], c["Nv"], 256), seed=42) * 16 * c["scale"]
+    l = _synth.synth_tensor("l_" + name, (c["B"], c["L"], 768), seed=43) * 27 * c["scale"]
+    return c, sd, v, l, g[name + "_mask"]
+
+
+@pytest.mark.parametrize("name", ["L20", "L600_pad", "clamp"])
+def test_bi_attention(name):
+    g = Golden("bi_attn")
+    c, sd, v, l, mask = bi_case(g, name)
+    ov, ol = oo.bi_attention_block(v, l, mask, sd, "")
+    assert rel_err(g.like(name + "_v", ov), g[name + "_v"]) < TOL
+    assert rel_err(g.like(name + "_l", ol), g[name + "_l"]) < TOL
+
+
+def test_bert_short_and_chunked():
+    g = Golden("bert")
+    cfg = g.meta["cfg"]
+    sd = _synth.synth_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}, seed=51)
+    for tag in ("short", "long"):
+        out = om.bert_encoder(g[tag + "_ids"], g[tag + "_mask"], sd, "model.", cfg)["hidden"]
+        assert rel_err(g.like(tag + "_hidden", out), g[tag + "_hidden"]) < 5e-5
+
+
+def dyn_case(g, name):
+    c = g.meta["cases"][name]
+    feats = _synth.synth_tensor("dm_feats_" + name, (c["B"], 8, c["H"], c["W"]), seed=61) * 20
+    params = _synth.synth_tensor("dm_params_" + name, (1, c["B"] * c["Q"], 169), seed=63) * 6
+    return c, feats, g[name + "_refs"], params
+
+
+@pytest.mark.parametrize("name", ["sq", "rect"])
+def test_dynamic_mask(name):
+    g = Golden("dynamic_mask")
+    c, feats, refs, params = dyn_case(g, name)
+    out = oo.dynamic_mask(feats, refs, params, [c["Q"]] * c["B"], stride=8, up=2)
+    assert rel_err(g.like(name + "_out", out), g[name + "_out"]) < TOL
+
+
+def test_aligned_bilinear():
+    g = Golden("dynamic_mask")
+    x = _synth.synth_tensor("ab_x", (3, 1, 9, 13), seed=64) * 10
+    assert rel_err(oo.aligned_bilinear(x, 2), g["aligned_bilinear_out"]) < 1e-6
+
+
+def e2e_inputs(g, task):
+    cfg = g.meta["cfg"]
+    sd = _synth.synth_full_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()})
+    imgs = _synth.synth_images([tuple(s) for s in g.meta["sizes"]], seed=73)
+    ids, mask, pmap = _synth.synth_token_ids(2, g.meta[task]["n_classes"], 64, seed=74)
+    return cfg, sd, imgs, ids, mask
+
+
+E2E_KEYS = ["pred_logits", "pred_boxes", "pred_boxious", "pred_masks", "reference_points", "pred_masks_maskdino",
+            "pred_logits_maskdino", "pred_boxes_maskdino"]
+
+
+@pytest.mark.parametrize("task", ["detection", "grounding"])
+def test_e2e_tiny(task):
+    """the full a22 dictionary of DDETRSegmUniDN.coco_inference, free-running top-k (same fp32 CPU arithmetic,
+    so the selections agree) and with pinned indices."""
+    g = Golden("e2e_tiny")
+    cfg, sd, imgs, ids, mask = e2e_inputs(g, task)
+    lang = om.bert_encoder(ids, mask, sd, "text_encoder.body.model.", cfg)
+    assert rel_err(g.like(task + "_lang_hidden", lang["hidden"]), g[task + "_lang_hidden"]) < 5e-5
+    out = om.coco_inference(imgs, lang, sd, cfg, task=task, topk_fg=g[task + "_topk_fg"], topk_md=g[task + "_topk_md"])
+    for k in E2E_KEYS:
+        assert rel_err(g.like(task + "_" + k, out[k]), g[task + "_" + k]) < 2e-4, k
+    free = om.coco_inference(imgs, lang, sd, cfg, task=task)
+    assert torch.equal(free["topk_fg"], g[task + "_topk_fg"])
+    assert torch.equal(free["topk_md"], g[task + "_topk_md"])
+
+
+def test_stages_tiny():
+    g = Golden("stages_tiny")
+    e = Golden("e2e_tiny")
+    cfg, sd, imgs, ids, mask = e2e_inputs(e, "detection")
+    lang = om.bert_encoder(ids, mask, sd, "text_encoder.body.model.", cfg)
+    out = om.coco_inference(imgs, lang, sd, cfg, task="detection", want_stages=True)
+    st = out["_stages"]
+    for i, n in enumerate(["res3", "res4", "res5"]):
+        assert rel_err(g.like("feat%d" % i, st["feats"][n]), g["feat%d" % i]) < TOL
+        assert rel_err(g.like("pos%d" % i, st["poses"][i]), g["pos%d" % i]) < TOL
+        assert torch.equal(g.like("mask%d" % i, st["fmasks"][i]), g["mask%d" % i])
+    assert rel_err(g.like("memory", st["memory"]), g["memory"]) < 1e-4
+    assert rel_err(g.like("vl0_lang", st["lang_hidden"]), g["vl0_lang"]) < 1e-4
+    assert rel_err(g.like("dec_hs", st["hs"]), g["dec_hs"]) < 1e-4
+    assert rel_err(g.like("dec_refs", st["inter"]), g["dec_refs"]) < 1e-4
+    assert rel_err(g.like("mask_head_out", st["mask_head"]), g["mask_head_out"]) < 1e-4
+    assert rel_err(g.like("md_enc_memory", st["md_enc_memory"]), g["md_enc_memory"]) < 1e-4
+    assert rel_err(g.like("md_mask_features", st["md_mask_features"]), g["md_mask_features"]) < 1e-4
+    for i in range(4):
+        assert rel_err(g.like("md_ms%d" % i, st["md_ms"][i]), g["md_ms%d" % i]) < 1e-4
