@@ -1,0 +1,66 @@
+"""ctypes binding of libhipie_mi355.so (the C ABI of include/hipie_mi355.h).
+
+The library is built in-tree (``make -C hipie_amd/csrc`` or ``__graft_entry__.build()``).  There is NO fallback: if the
+shared object is missing or does not export a symbol, importing the op layer raises -- the product never silently runs a
+PyTorch/CPU substitute for a hand-written kernel.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhipie_mi355.so")
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_l = ctypes.c_int64
+c_f = ctypes.c_float
+
+# name -> argtypes, in the order of include/hipie_mi355.h
+SIGNATURES = {
+    "hipie_version": [],
+    "hipie_last_error": [],
+    "hipie_msda_forward": [c_p, c_p, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p],
+    "hipie_msda_fused_forward": [c_p, c_p, c_p, c_p, c_p, c_p, c_p] + [c_i] * 9 + [c_p],
+    "hipie_flash_attn": [c_p, c_p, c_p, c_p] + [c_i] * 5 + [c_l] * 12 + [c_p, c_p, c_i, c_i, c_p, c_f, c_f, c_i, c_p],
+    "hipie_vit_attn": [c_p, c_p, c_p, c_p] + [c_i] * 5 + [c_f, c_i, c_p],
+    "hipie_bi_xattn": [c_p, c_p, c_p, c_p, c_p, c_p, c_p] + [c_i] * 5 + [c_f, c_i, c_p],
+    "hipie_mask_einsum": [c_p, c_p, c_p] + [c_i] * 6 + [c_p],
+    "hipie_dynamic_mask": [c_p, c_p, c_p, c_p] + [c_i] * 7 + [c_p],
+    "hipie_selftest": [c_i, c_p, c_p, c_p, c_p],
+}
+
+_lib = None
+
+
+class HipieLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library once and set the prototypes; raises HipieLibraryError when it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipieLibraryError(
+            "libhipie_mi355.so not found at %s -- build it with `make -C hipie_amd/csrc` (hipcc, gfx950). "
+            "There is no PyTorch fallback for the hand-written kernels." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # missing libamdhip64 etc.
+        raise HipieLibraryError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise HipieLibraryError("%s does not export %s (stale build?)" % (LIB_PATH, name))
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_char_p if name == "hipie_last_error" else ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().hipie_last_error()
+        raise RuntimeError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ""))

@@ -1,0 +1,51 @@
+// common.h -- shared device/host helpers for libhipie_mi355 (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/hipie_mi355.h"
+
+namespace hipie {
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+typedef short i16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// ---- error plumbing (host) -------------------------------------------------------------------------
+extern thread_local char g_err[512];
+int set_err(int code, const char* fmt, ...);
+int check_launch(const char* what);
+
+#define HIPIE_REQUIRE(cond, ...)                              \
+  do {                                                        \
+    if (!(cond)) return ::hipie::set_err(HIPIE_EINVAL, __VA_ARGS__); \
+  } while (0)
+
+// ---- 16-bit <-> f32 ---------------------------------------------------------------------------------
+template <typename T> struct elem;
+template <> struct elem<float> {
+  static __device__ __forceinline__ float to_f32(float x) { return x; }
+  static __device__ __forceinline__ float from_f32(float x) { return x; }
+};
+template <> struct elem<bf16_t> {
+  static __device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+  static __device__ __forceinline__ bf16_t from_f32(float x) { return (bf16_t)x; }
+};
+template <> struct elem<f16_t> {
+  static __device__ __forceinline__ float to_f32(f16_t x) { return (float)x; }
+  static __device__ __forceinline__ f16_t from_f32(float x) { return (f16_t)x; }
+};
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace hipie

@@ -1,0 +1,265 @@
+// msda.hip -- multi-scale deformable attention sampling (forward) for gfx950.
+//
+// What it computes: SURVEY.md row a10 / include/hipie_mi355.h hipie_msda_forward.  For every (batch b, query q,
+// head m) the weighted sum over L levels x P points of a bilinear sample of value[b, level pixels, m, 0:D].
+//
+// Data layout in HBM: value is (B, S, M, D) with D fastest, i.e. the M*D = 256 channels of one pixel are one
+// contiguous 1 KiB (f32) / 512 B (16-bit) line and one head's slice is 128 / 64 contiguous bytes.
+//
+// Mapping (D == 32 fast path): 8 lanes own one (b,q,m); each lane owns 4 consecutive channels, so a corner fetch of one
+// head is ONE 128-byte coalesced segment (8 lanes x 16 B) and a wave covers 8 heads = the full 1 KiB pixel line when
+// M == 8.  All L*P*4 = 64 corner fetches of a lane are independent -> the compiler keeps them in flight together
+// (latency hiding by ILP; the kernel is gather/L2-bound, never MFMA work).  Control flow is branch-free: out-of-range
+// samples / corners are clamped to a legal address and zeroed by select, exactly reproducing the zero padding of
+// ms_deform_attn_im2col_bilinear (ms_deform_im2col_cuda.cuh:33-84).
+//
+// The FUSED variant additionally computes the sampling locations and the softmax over the L*P logits in registers
+// (ops/modules/ms_deform_attn.py:99-114) so the (B,Lq,M,L,P,2) location tensor never exists in HBM.
+//
+// Roofline: HBM/L2 bound.  Algorithmic bytes per call (f32): S*M*D*4 (value) + Lq*M*L*P*(2+1)*4 (loc, weights) +
+// Lq*M*D*4 (out) per image = 78 MB at Nv = 21760.
+#include "common.h"
+
+namespace hipie {
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+  typedef float4 raw;
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    float4 r = *reinterpret_cast<const float4*>(p);
+    v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <> struct Vec4<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[4]) {
+    bf16x4 r = *reinterpret_cast<const bf16x4*>(p);
+    for (int i = 0; i < 4; ++i) v[i] = (float)r[i];
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
+    bf16x4 r;
+    for (int i = 0; i < 4; ++i) r[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x4*>(p) = r;
+  }
+};
+template <> struct Vec4<f16_t> {
+  static __device__ __forceinline__ void load(const f16_t* p, float (&v)[4]) {
+    f16x4 r = *reinterpret_cast<const f16x4*>(p);
+    for (int i = 0; i < 4; ++i) v[i] = (float)r[i];
+  }
+  static __device__ __forceinline__ void store(f16_t* p, const float (&v)[4]) {
+    f16x4 r;
+    for (int i = 0; i < 4; ++i) r[i] = (f16_t)v[i];
+    *reinterpret_cast<f16x4*>(p) = r;
+  }
+};
+
+constexpr int kMaxLP = 32;  // L*P supported by the fused softmax (reference geometry: 4*4 = 16)
+
+// D == 32: 8 lanes per (b,q,m), 4 channels per lane.
+template <typename T, bool FUSED>
+__global__ __launch_bounds__(256) void msda_d32_kernel(const T* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                       const int64_t* __restrict__ lstart,
+                                                       const float* __restrict__ loc_or_off,
+                                                       const float* __restrict__ w_or_logit,
+                                                       const float* __restrict__ ref, T* __restrict__ out, int S, int M,
+                                                       int L, int Lq, int P, int ref_dim, long total_groups) {
+  const long g = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+  if (g >= total_groups) return;
+  const int sub = threadIdx.x & 7;
+  const int m = (int)(g % M);
+  const long bq = g / M;
+  const int b = (int)(bq / Lq);
+  const int LP = L * P;
+  const float* lp = loc_or_off + g * (long)(LP * 2);
+  const float* wp = w_or_logit + g * (long)LP;
+
+  float wmax = 0.f, winv = 1.f;
+  if (FUSED) {
+    wmax = -INFINITY;
+    for (int i = 0; i < LP; ++i) wmax = fmaxf(wmax, wp[i]);
+    float s = 0.f;
+    for (int i = 0; i < LP; ++i) s += expf(wp[i] - wmax);
+    winv = 1.f / s;
+  }
+
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const long row = (long)M * 32;                       // elements per pixel
+  const T* vb = value + (long)b * S * row + m * 32 + sub * 4;
+  for (int l = 0; l < L; ++l) {
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    const T* vl = vb + (long)lstart[l] * row;
+    float rx = 0.f, ry = 0.f, rw = 0.f, rh = 0.f;
+    if (FUSED) {
+      const float* r = ref + (bq * L + l) * ref_dim;
+      rx = r[0]; ry = r[1];
+      if (ref_dim == 4) { rw = r[2]; rh = r[3]; }
+    }
+#pragma unroll 4
+    for (int p = 0; p < P; ++p) {
+      const int i = l * P + p;
+      float x = lp[2 * i], y = lp[2 * i + 1], w;
+      if (FUSED) {
+        if (ref_dim == 2) {                            // ref + off / (W_l, H_l)
+          x = rx + x / (float)W;
+          y = ry + y / (float)H;
+        } else {                                       // ref_xy + off / P * ref_wh * 0.5
+          x = rx + x / (float)P * rw * 0.5f;
+          y = ry + y / (float)P * rh * 0.5f;
+        }
+        w = expf(wp[i] - wmax) * winv;
+      } else {
+        w = wp[i];
+      }
+      const float h_im = y * (float)H - 0.5f;
+      const float w_im = x * (float)W - 0.5f;
+      const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
+      const float hf = floorf(h_im), wf = floorf(w_im);
+      const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+      const int h0 = inside ? (int)hf : 0, w0 = inside ? (int)wf : 0;
+      const int h1 = h0 + 1, w1 = w0 + 1;
+      const bool okh0 = inside && h0 >= 0, okh1 = inside && h1 <= H - 1;
+      const bool okw0 = w0 >= 0, okw1 = w1 <= W - 1;
+      const int ch0 = max(h0, 0), ch1 = min(h1, H - 1), cw0 = max(w0, 0), cw1 = min(w1, W - 1);
+      float v1[4], v2[4], v3[4], v4[4];
+      Vec4<T>::load(vl + ((long)ch0 * W + cw0) * row, v1);
+      Vec4<T>::load(vl + ((long)ch0 * W + cw1) * row, v2);
+      Vec4<T>::load(vl + ((long)ch1 * W + cw0) * row, v3);
+      Vec4<T>::load(vl + ((long)ch1 * W + cw1) * row, v4);
+      const float w1c = (okh0 && okw0) ? hh * hw : 0.f, w2c = (okh0 && okw1) ? hh * lw : 0.f;
+      const float w3c = (okh1 && okw0) ? lh * hw : 0.f, w4c = (okh1 && okw1) ? lh * lw : 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float a1 = (okh0 && okw0) ? v1[c] : 0.f, a2 = (okh0 && okw1) ? v2[c] : 0.f;
+        const float a3 = (okh1 && okw0) ? v3[c] : 0.f, a4 = (okh1 && okw1) ? v4[c] : 0.f;
+        const float val = w1c * a1 + w2c * a2 + w3c * a3 + w4c * a4;
+        acc[c] += val * w;
+      }
+    }
+  }
+  Vec4<T>::store(out + g * 32 + sub * 4, acc);
+}
+
+// any D: one thread per output element (b,q,m,c), the reference's own decomposition.
+template <typename T, bool FUSED>
+__global__ __launch_bounds__(256) void msda_generic_kernel(const T* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                           const int64_t* __restrict__ lstart,
+                                                           const float* __restrict__ loc_or_off,
+                                                           const float* __restrict__ w_or_logit,
+                                                           const float* __restrict__ ref, T* __restrict__ out, int S,
+                                                           int M, int D, int L, int Lq, int P, int ref_dim, long n) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int c = (int)(idx % D);
+  const long g = idx / D;
+  const int m = (int)(g % M);
+  const long bq = g / M;
+  const int b = (int)(bq / Lq);
+  const int LP = L * P;
+  const float* lp = loc_or_off + g * (long)(LP * 2);
+  const float* wp = w_or_logit + g * (long)LP;
+  float wmax = 0.f, winv = 1.f;
+  if (FUSED) {
+    wmax = -INFINITY;
+    for (int i = 0; i < LP; ++i) wmax = fmaxf(wmax, wp[i]);
+    float s = 0.f;
+    for (int i = 0; i < LP; ++i) s += expf(wp[i] - wmax);
+    winv = 1.f / s;
+  }
+  const long row = (long)M * D;
+  const T* vb = value + (long)b * S * row + m * D + c;
+  float col = 0.f;
+  for (int l = 0; l < L; ++l) {
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    const T* vl = vb + (long)lstart[l] * row;
+    for (int p = 0; p < P; ++p) {
+      const int i = l * P + p;
+      float x = lp[2 * i], y = lp[2 * i + 1], w;
+      if (FUSED) {
+        const float* r = ref + (bq * L + l) * ref_dim;
+        if (ref_dim == 2) {
+          x = r[0] + x / (float)W;
+          y = r[1] + y / (float)H;
+        } else {
+          x = r[0] + x / (float)P * r[2] * 0.5f;
+          y = r[1] + y / (float)P * r[3] * 0.5f;
+        }
+        w = expf(wp[i] - wmax) * winv;
+      } else {
+        w = wp[i];
+      }
+      const float h_im = y * (float)H - 0.5f, w_im = x * (float)W - 0.5f;
+      if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
+        const int h0 = (int)floorf(h_im), w0 = (int)floorf(w_im), h1 = h0 + 1, w1 = w0 + 1;
+        const float lh = h_im - h0, lw = w_im - w0, hh = 1.f - lh, hw = 1.f - lw;
+        float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+        if (h0 >= 0 && w0 >= 0) v1 = elem<T>::to_f32(vl[((long)h0 * W + w0) * row]);
+        if (h0 >= 0 && w1 <= W - 1) v2 = elem<T>::to_f32(vl[((long)h0 * W + w1) * row]);
+        if (h1 <= H - 1 && w0 >= 0) v3 = elem<T>::to_f32(vl[((long)h1 * W + w0) * row]);
+        if (h1 <= H - 1 && w1 <= W - 1) v4 = elem<T>::to_f32(vl[((long)h1 * W + w1) * row]);
+        col += (hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4) * w;
+      }
+    }
+  }
+  out[idx] = elem<T>::from_f32(col);
+}
+
+template <typename T, bool FUSED>
+static int launch_msda(const void* value, const int64_t* shapes, const int64_t* lstart, const float* a, const float* w,
+                       const float* ref, void* out, int B, int S, int M, int D, int L, int Lq, int P, int ref_dim,
+                       hipStream_t st) {
+  const long groups = (long)B * Lq * M;
+  if (groups == 0) return HIPIE_OK;
+  if (D == 32) {
+    const long blocks = (groups + 31) / 32;
+    hipLaunchKernelGGL((msda_d32_kernel<T, FUSED>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)value, shapes,
+                       lstart, a, w, ref, (T*)out, S, M, L, Lq, P, ref_dim, groups);
+  } else {
+    const long n = groups * D;
+    const long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL((msda_generic_kernel<T, FUSED>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)value,
+                       shapes, lstart, a, w, ref, (T*)out, S, M, D, L, Lq, P, ref_dim, n);
+  }
+  return check_launch("msda");
+}
+
+template <bool FUSED>
+static int dispatch_msda(const void* value, const int64_t* shapes, const int64_t* lstart, const float* a, const float* w,
+                         const float* ref, void* out, int B, int S, int M, int D, int L, int Lq, int P, int ref_dim,
+                         int dtype, void* stream) {
+  HIPIE_REQUIRE(value && shapes && lstart && a && w && out, "msda: null pointer");
+  HIPIE_REQUIRE(B >= 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq >= 0 && P > 0, "msda: bad shape B=%d S=%d M=%d D=%d L=%d Lq=%d P=%d", B, S, M, D, L, Lq, P);
+  HIPIE_REQUIRE((long)B * S * M * D < (1L << 40), "msda: tensor too large");
+  if (FUSED) {
+    HIPIE_REQUIRE(ref != nullptr && (ref_dim == 2 || ref_dim == 4), "msda_fused: ref_dim must be 2 or 4 (got %d)", ref_dim);
+    HIPIE_REQUIRE(L * P <= kMaxLP, "msda_fused: L*P=%d > %d", L * P, kMaxLP);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  switch (dtype) {
+    case HIPIE_F32: return launch_msda<float, FUSED>(value, shapes, lstart, a, w, ref, out, B, S, M, D, L, Lq, P, ref_dim, st);
+    case HIPIE_F16:
+      HIPIE_REQUIRE(D % 4 == 0 || D != 32, "msda: D");
+      return launch_msda<f16_t, FUSED>(value, shapes, lstart, a, w, ref, out, B, S, M, D, L, Lq, P, ref_dim, st);
+    case HIPIE_BF16: return launch_msda<bf16_t, FUSED>(value, shapes, lstart, a, w, ref, out, B, S, M, D, L, Lq, P, ref_dim, st);
+    default: return set_err(HIPIE_EINVAL, "msda: unsupported dtype %d", dtype);
+  }
+}
+
+}  // namespace hipie
+
+extern "C" int hipie_msda_forward(const void* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                                  const float* sampling_loc, const float* attn_weight, void* out, int B, int S, int M,
+                                  int D, int L, int Lq, int P, int value_dtype, void* stream) {
+  return hipie::dispatch_msda<false>(value, spatial_shapes, level_start, sampling_loc, attn_weight, nullptr, out, B, S,
+                                     M, D, L, Lq, P, 2, value_dtype, stream);
+}
+
+extern "C" int hipie_msda_fused_forward(const void* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                                        const float* ref, const float* offsets, const float* logits, void* out, int B,
+                                        int S, int M, int D, int L, int Lq, int P, int ref_dim, int value_dtype,
+                                        void* stream) {
+  return hipie::dispatch_msda<true>(value, spatial_shapes, level_start, offsets, logits, ref, out, B, S, M, D, L, Lq, P,
+                                    ref_dim, value_dtype, stream);
+}

@@ -1,0 +1,151 @@
+"""Operator layer: torch.Tensor in, torch.Tensor out, raw device pointers + current HIP stream across the C ABI.
+
+Mirrors the reference's operator boundary: ``ms_deform_attn_forward`` has the signature and error
+behaviour of the pybind module ``MultiScaleDeformableAttention`` (contiguity / device checks raise RuntimeError, CPU
+tensors raise "Not implemented on the CPU", ops/src/ms_deform_attn.h:28-39).  All functions are inference-only.
+"""
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name, dtype=None):
+    if not t.is_cuda:
+        raise RuntimeError("Not implemented on the CPU (%s must be a CUDA/HIP tensor)" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s tensor has to be contiguous" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t.data_ptr()
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
+    """MSDA.ms_deform_attn_forward (ops/src/vision.cpp:13-16): value (B,S,M,D), shapes (L,2) i64, level_start (L,) i64,
+    sampling_loc (B,Lq,M,L,P,2), attn_weight (B,Lq,M,L,P) -> (B,Lq,M*D).  value may be f32/f16/bf16; loc/attn are f32."""
+    lib = _lib.load()
+    B, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_loc.shape
+    if value.dtype not in _DT:
+        raise RuntimeError("ms_deform_attn_forward: unsupported dtype %s" % value.dtype)
+    out = torch.empty(B, Lq, M * D, dtype=value.dtype, device=value.device)
+    rc = lib.hipie_msda_forward(_chk(value, "value"), _chk(spatial_shapes, "spatial_shapes", torch.int64),
+                                _chk(level_start_index, "level_start_index", torch.int64),
+                                _chk(sampling_loc, "sampling_loc", torch.float32),
+                                _chk(attn_weight, "attn_weight", torch.float32), out.data_ptr(),
+                                B, S, M, D, L, Lq, P, _DT[value.dtype], _stream())
+    _lib.check(rc, "hipie_msda_forward")
+    return out
+
+
+def msda_fused(value, spatial_shapes, level_start_index, ref, offsets, logits):
+    """value (B,S,M,D); ref (B,Lq,L,2|4) f32; offsets (B,Lq,M,L,P,2) f32; logits (B,Lq,M,L*P) f32 -> (B,Lq,M*D)."""
+    lib = _lib.load()
+    B, S, M, D = value.shape
+    _, Lq, _, L, P, _ = offsets.shape
+    out = torch.empty(B, Lq, M * D, dtype=value.dtype, device=value.device)
+    rc = lib.hipie_msda_fused_forward(_chk(value, "value"), _chk(spatial_shapes, "spatial_shapes", torch.int64),
+                                      _chk(level_start_index, "level_start_index", torch.int64),
+                                      _chk(ref, "ref", torch.float32), _chk(offsets, "offsets", torch.float32),
+                                      _chk(logits, "logits", torch.float32), out.data_ptr(),
+                                      B, S, M, D, L, Lq, P, ref.shape[-1], _DT[value.dtype], _stream())
+    _lib.check(rc, "hipie_msda_fused_forward")
+    return out
+
+
+def flash_attn(q, k, v, scale, bias_h=None, bias_w=None, key_mask=None, clamp=0.0):
+    """q (B,Nq,H,hd), k,v (B,Nk,H,hd) 16-bit (may be strided views with hd contiguous) -> (B,Nq,H*hd).
+    bias_h (B*H,Nq,kh) / bias_w (B*H,Nq,kw) f32 decomposed rel-pos bias; key_mask (B,Nk) uint8/bool."""
+    lib = _lib.load()
+    B, Nq, H, hd = q.shape
+    Nk = k.shape[1]
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        if not t.is_cuda:
+            raise RuntimeError("Not implemented on the CPU (%s)" % n)
+        if t.stride(-1) != 1 or t.dtype != q.dtype or t.dtype not in (torch.float16, torch.bfloat16):
+            raise RuntimeError("flash_attn: %s must be fp16/bf16 with contiguous head_dim" % n)
+    out = torch.empty(B, Nq, H * hd, dtype=q.dtype, device=q.device)
+    kh = kw = 0
+    bhp = bwp = mp = None
+    if bias_h is not None:
+        kh, kw = bias_h.shape[-1], bias_w.shape[-1]
+        bhp, bwp = _chk(bias_h, "bias_h", torch.float32), _chk(bias_w, "bias_w", torch.float32)
+    if key_mask is not None:
+        key_mask = key_mask.to(torch.uint8).contiguous()
+        mp = _chk(key_mask, "key_mask")
+    rc = lib.hipie_flash_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, Nq, Nk, hd,
+                              q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+                              v.stride(0), v.stride(1), v.stride(2), Nq * H * hd, H * hd, hd,
+                              bhp, bwp, kh, kw, mp, float(scale), float(clamp), _DT[q.dtype], _stream())
+    _lib.check(rc, "hipie_flash_attn")
+    return out
+
+
+def vit_attn(qkv, rel_h, rel_w, grid_hw, heads, scale):
+    """qkv (B, gh*gw, 3*heads*hd) 16-bit packed as (3, heads, hd); rel_h (B*heads, N, gh), rel_w (B*heads, N, gw) f32
+    -> (B, N, heads*hd)."""
+    lib = _lib.load()
+    gh, gw = grid_hw
+    B, N, C3 = qkv.shape
+    hd = C3 // (3 * heads)
+    out = torch.empty(B, N, heads * hd, dtype=qkv.dtype, device=qkv.device)
+    rc = lib.hipie_vit_attn(_chk(qkv, "qkv"), _chk(rel_h, "rel_h", torch.float32), _chk(rel_w, "rel_w", torch.float32),
+                            out.data_ptr(), B, gh, gw, heads, hd, float(scale), _DT[qkv.dtype], _stream())
+    _lib.check(rc, "hipie_vit_attn")
+    return out
+
+
+def bi_xattn(q, k, vv, vl, text_mask, clamp=50000.0):
+    """q, vv (B,Nv,H,hd); k, vl (B,L,H,hd) 16-bit contiguous; text_mask (B,L) -> out_v (B,Nv,H*hd), out_l (B,L,H*hd)."""
+    lib = _lib.load()
+    B, Nv, H, hd = q.shape
+    L = k.shape[1]
+    text_mask = text_mask.to(torch.uint8).contiguous()
+    out_v = torch.empty(B, Nv, H * hd, dtype=q.dtype, device=q.device)
+    out_l = torch.empty(B, L, H * hd, dtype=q.dtype, device=q.device)
+    rc = lib.hipie_bi_xattn(_chk(q, "q"), _chk(k, "k"), _chk(vv, "vv"), _chk(vl, "vl"), _chk(text_mask, "text_mask"),
+                            out_v.data_ptr(), out_l.data_ptr(), B, H, Nv, L, hd, float(clamp), _DT[q.dtype], _stream())
+    _lib.check(rc, "hipie_bi_xattn")
+    return out_v, out_l
+
+
+def mask_einsum(mask_embed, mask_features, precision=1, out_dtype=torch.float32):
+    """einsum("bqc,bchw->bqhw"): mask_embed (B,Q,C) f32, mask_features (B,C,H,W) f32 -> (B,Q,H,W) out_dtype.
+    precision 0 = exact fp32 MFMA, 1 = bf16x3 split (default; ~2^-16), 2 = plain bf16."""
+    lib = _lib.load()
+    B, Q, C = mask_embed.shape
+    _, _, Hh, Ww = mask_features.shape
+    out = torch.empty(B, Q, Hh, Ww, dtype=out_dtype, device=mask_embed.device)
+    rc = lib.hipie_mask_einsum(_chk(mask_embed, "mask_embed", torch.float32),
+                               _chk(mask_features, "mask_features", torch.float32), out.data_ptr(),
+                               B, Q, C, Hh * Ww, int(precision), _DT[out_dtype], _stream())
+    _lib.check(rc, "hipie_mask_einsum")
+    return out
+
+
+def dynamic_mask(mask_feats, ref_points, params, num_queries, stride=8, up=2, out_dtype=torch.float32):
+    """mask_feats (B,8,H,W) f32; ref_points (B*Q,2) f32 pixels; params (B*Q,169) f32 -> (B*Q, up*H, up*W)."""
+    lib = _lib.load()
+    B, C, H, W = mask_feats.shape
+    if C != 8 or params.shape[-1] != 169:
+        raise RuntimeError("dynamic_mask: expects 8 feature channels and 169 parameters per instance")
+    n = B * num_queries
+    out = torch.empty(n, up * H, up * W, dtype=out_dtype, device=mask_feats.device)
+    rc = lib.hipie_dynamic_mask(_chk(mask_feats, "mask_feats", torch.float32), _chk(ref_points, "ref_points", torch.float32),
+                                _chk(params, "params", torch.float32), out.data_ptr(), B, num_queries, H, W,
+                                int(stride), int(up), _DT[out_dtype], _stream())
+    _lib.check(rc, "hipie_dynamic_mask")
+    return out
+
+
+def selftest(which, a, b=None):
+    lib = _lib.load()
+    out = torch.empty(32 * 32 if which == 0 else 256, dtype=torch.float32, device=a.device)
+    rc = lib.hipie_selftest(which, a.data_ptr(), None if b is None else b.data_ptr(), out.data_ptr(), _stream())
+    _lib.check(rc, "hipie_selftest")
+    return out

@@ -1,0 +1,143 @@
+/*
+ * hipie_mi355.h -- C ABI of libhipie_mi355.so: the hand-written HIP (gfx950 / CDNA4) kernels of HIPIE's
+ * single-image inference hot path.
+ *
+ * Conventions:
+ *   - plain C, no exceptions, no torch types; every pointer is a DEVICE pointer unless it says "host";
+ *   - the caller owns all buffers (inputs are borrowed, outputs are pre-allocated), nothing is allocated here;
+ *   - every entry point takes the hipStream_t to launch on (as void*) and returns 0 on success or a negative
+ *     HIPIE_E* code; hipie_last_error() gives the text for the calling thread;
+ *   - stateless and thread-safe; launches are asynchronous (no sync inside), so they can be captured in hipGraphs;
+ *   - tensors are dense row-major with the last index fastest unless explicit strides are given.
+ *
+ * Each function names the reference interface it replaces (paths relative to projects/HIPIE/hipie/).
+ */
+#ifndef HIPIE_MI355_H
+#define HIPIE_MI355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPIE_ABI_VERSION 1
+
+/* element types of activations */
+#define HIPIE_F32 0
+#define HIPIE_F16 1
+#define HIPIE_BF16 2
+
+/* error codes */
+#define HIPIE_OK 0
+#define HIPIE_EINVAL (-22)   /* bad shape / dtype / null pointer / unsupported geometry */
+#define HIPIE_ELAUNCH (-5)   /* hipLaunchKernel failed (hipie_last_error() has hipGetErrorString) */
+
+int hipie_version(void);
+/* text of the last error raised on the calling thread ("" when none). */
+const char* hipie_last_error(void);
+
+/*
+ * Multi-scale deformable attention sampling, forward.
+ * Replaces: MultiScaleDeformableAttention.ms_deform_attn_forward (pybind, models/deformable_detr/ops/src/vision.cpp:13-16)
+ *           = ms_deform_attn_cuda_forward (ops/src/cuda/ms_deform_attn_cuda.cu:20-80)
+ *           -> ms_deformable_im2col_gpu_kernel (ops/src/cuda/ms_deform_im2col_cuda.cuh:237-299),
+ *           and the identical copy under models/maskdino/pixel_decoder/ops/.
+ *   value          (B, S, M, D)        dtype `value_dtype` (f32 as the reference; f16/bf16 halve the gather traffic)
+ *   spatial_shapes (L, 2) int64 (H, W) device
+ *   level_start    (L,)   int64        device
+ *   sampling_loc   (B, Lq, M, L, P, 2) f32, (x, y) normalised to [0,1] (values outside sample zero padding)
+ *   attn_weight    (B, Lq, M, L, P)    f32
+ *   out            (B, Lq, M*D)        dtype `value_dtype`; fully overwritten (the reference at::zeros + writes all)
+ * im2col_step of the reference is a batching detail of its host loop and has no equivalent here.
+ */
+int hipie_msda_forward(const void* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                       const float* sampling_loc, const float* attn_weight, void* out,
+                       int B, int S, int M, int D, int L, int Lq, int P, int value_dtype, void* stream);
+
+/*
+ * Fused form used by the product path: sampling locations and the 16-way softmax are computed in the kernel from
+ * the raw projections, so neither (B,Lq,M,L,P,2) locations nor normalised weights ever reach HBM.
+ * Replaces: MSDeformAttn.forward lines 99-114 (ops/modules/ms_deform_attn.py) + the op above.
+ *   offsets (B, Lq, M, L, P, 2) f32 = sampling_offsets(query);  logits (B, Lq, M, L*P) f32 = attention_weights(query)
+ *   ref     (B, Lq, L, ref_dim) f32, ref_dim 2: loc = ref + off/(W_l,H_l); ref_dim 4: loc = ref_xy + off/P*ref_wh*0.5
+ */
+int hipie_msda_fused_forward(const void* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                             const float* ref, const float* offsets, const float* logits, void* out,
+                             int B, int S, int M, int D, int L, int Lq, int P, int ref_dim, int value_dtype,
+                             void* stream);
+
+/*
+ * Fused (flash-style) attention core shared by the ViT blocks and the VL fusion:
+ *     out[b,i,h,:] = softmax_j( clamp(scale * q[b,i,h,:].k[b,j,h,:], +-clamp) + bias_h[bh,i,j / kw] + bias_w[bh,i,j % kw]
+ *                               + (key_mask[b,j] ? 0 : -inf) ) . v[b,j,h,:]
+ * with fp32 scores / softmax / accumulation, 16-bit MFMA operands, nothing of size Nq x Nk in HBM.
+ * q,k,v,out are addressed with explicit element strides (batch, token, head); head_dim contiguous.
+ *   dtype      HIPIE_F16 or HIPIE_BF16 (q, k, v, out)
+ *   head_dim   80 (ViT-H), 64 (ViT-B/L), 256 (VL fusion), 32
+ *   bias_h     (B*H, Nq, kh) f32 or NULL;  bias_w (B*H, Nq, kw) f32 or NULL  (both or none; needs Nk == kh*kw)
+ *   key_mask   (B, Nk) uint8 (1 = keep) or NULL
+ *   clamp      <= 0 disables the clamp
+ * Replaces: Attention.forward's (q*scale)@k^T -> add_decomposed_rel_pos -> softmax -> @v (backbone/vit.py:72-80,
+ *           backbone/utils.py:96-125) and the two softmax(QK^T)V products of BiMultiHeadAttention.forward
+ *           (models/deformable_detr/fuse_helper.py:69-121).
+ */
+int hipie_flash_attn(const void* q, const void* k, const void* v, void* out,
+                     int B, int H, int Nq, int Nk, int head_dim,
+                     int64_t q_sb, int64_t q_st, int64_t q_sh, int64_t k_sb, int64_t k_st, int64_t k_sh,
+                     int64_t v_sb, int64_t v_st, int64_t v_sh, int64_t o_sb, int64_t o_st, int64_t o_sh,
+                     const float* bias_h, const float* bias_w, int kh, int kw,
+                     const uint8_t* key_mask, float scale, float clamp, int dtype, void* stream);
+
+/*
+ * ViT attention with decomposed relative position bias on a packed qkv tensor.
+ * Replaces: Attention.forward between the qkv and proj Linears (backbone/vit.py:69-80) for both the 14x14 windowed
+ * blocks (x already window-partitioned, B = batch*windows, gh=gw=14) and the global blocks (gh x gw token grid).
+ *   qkv    (B, gh*gw, 3, heads, hd) 16-bit;  rel_h (B*heads, gh*gw, gh) f32 = q.Rh[hq,hk];  rel_w (.., gw) = q.Rw[wq,wk]
+ *   out    (B, gh*gw, heads*hd) 16-bit
+ */
+int hipie_vit_attn(const void* qkv, const float* rel_h, const float* rel_w, void* out,
+                   int B, int gh, int gw, int heads, int hd, float scale, int dtype, void* stream);
+
+/*
+ * Bi-directional text<->vision cross attention core of the VL early-fusion block.
+ * Replaces: BiMultiHeadAttention.forward lines 69-121 (models/deformable_detr/fuse_helper.py), i.e. everything between
+ * the four input projections and the two output projections; clamp +-50000, text key mask, no mask on the image side.
+ *   q (B,Nv,H,hd) = v_proj(v)*scale, k (B,L,H,hd) = l_proj(l), vv (B,Nv,H,hd), vl (B,L,H,hd): 16-bit
+ *   text_mask (B,L) uint8;  out_v (B,Nv,H*hd), out_l (B,L,H*hd) 16-bit
+ */
+int hipie_bi_xattn(const void* q, const void* k, const void* vv, const void* vl, const uint8_t* text_mask,
+                   void* out_v, void* out_l, int B, int H, int Nv, int L, int hd, float clamp, int dtype, void* stream);
+
+/*
+ * Mask-logit contraction  out[b,q,p] = sum_c embed[b,q,c] * feats[b,c,p].
+ * Replaces: torch.einsum("bqc,bchw->bqhw") in MaskDINODecoder.forward_prediction_heads
+ *           (models/maskdino/transformer_decoder/maskdino_decoder.py:520-529).
+ *   embed (B,Q,C) f32, feats (B,C,HW) f32, out (B,Q,HW) `out_dtype` (f32 | f16 | bf16).
+ *   precision 0: exact fp32 (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain); 1: bf16x3 split (3 bf16 MFMAs per
+ *   product, ~2^-16 relative); 2: single bf16 MFMA.   C % 32 == 0.
+ */
+int hipie_mask_einsum(const float* embed, const float* feats, void* out, int B, int Q, int C, int HW,
+                      int precision, int out_dtype, void* stream);
+
+/*
+ * Fused CondInst dynamic mask head: relative-coordinate generation + per-instance 10->8->8->1 MLP (ReLU, ReLU, none)
+ * + aligned_bilinear x`up`, without materialising the (1, N*10, H, W) input or running a grouped conv.
+ * Replaces: DDETRSegmUniDN.dynamic_mask_with_coords (models/ddetrs_dn.py:1411-1502) incl. compute_locations (:1857),
+ *           parse_dynamic_params (:1806), mask_heads_forward (:1390) and aligned_bilinear (:1832).
+ *   feats (B,8,H,W) f32;  refs (B*Q,2) f32 pixels (x,y);  params (B*Q,169) f32 = [w0 8x10 | w1 8x8 | w2 1x8 | b0 8 | b1 8 | b2 1]
+ *   out (B*Q, up*H, up*W) `out_dtype`;  instance n uses feats[n / Q];  up in {1,2};  stride = mask feature stride (8)
+ */
+int hipie_dynamic_mask(const float* feats, const float* refs, const float* params, void* out,
+                       int B, int Q, int H, int W, int stride, int up, int out_dtype, void* stream);
+
+/* device-side self-test helpers used by tests/ to pin the MFMA / LDS-transpose lane layouts this library assumes.
+ *   which 0: D = A(32x16) . B(16x32) with v_mfma_f32_32x32x16_bf16, operands loaded with the layouts documented in
+ *            csrc/mfma.h; out (32,32) f32.   which 1: ds_read_b64_tr_b16 of a (64,16) bf16 tile; out (64,4) f32 per lane.
+ *   a, b: bf16 (as uint16) inputs. */
+int hipie_selftest(int which, const uint16_t* a, const uint16_t* b, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPIE_MI355_H */

@@ -1,0 +1,211 @@
+"""GPU: every hand-written HIP kernel, called through the C ABI, against the oracle on the same seeded inputs and
+against the reference-generated golden fixtures.  Tolerances are written next to each check:
+  fp32 kernels (MSDA f32, dynamic mask, einsum precision 0/1): <= 2e-5 relative to the output scale;
+  16-bit MFMA kernels: vs the oracle fed the SAME 16-bit-rounded inputs 1e-3 (fp16) / 8e-3 (bf16) -- the residual is the
+  rounding of P and of the output to 16 bit; vs the fp32 golden 2e-3 (fp16) / 2e-2 (bf16)."""
+import pytest
+import torch
+
+import _synth
+from oracle import ops as oo
+from util import Golden, rel_err
+from test_oracle_golden import msda_case, vit_attn_case, bi_case, dyn_case
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+DEV = "cuda"
+
+
+def test_selftest_mfma_layout():
+    from hipie_amd import ops
+    g = torch.Generator().manual_seed(1)
+    A = torch.randn(32, 16, generator=g).bfloat16()
+    B = torch.randn(16, 32, generator=g).bfloat16()
+    D = ops.selftest(0, A.to(DEV).view(torch.int16), B.to(DEV).view(torch.int16)).cpu().view(32, 32)
+    ref = A.float() @ B.float()      # asymmetric operands: a transposed C/D map cannot pass
+    assert rel_err(D, ref) < 1e-5
+
+
+def test_selftest_tr_read():
+    from hipie_amd import ops
+    tile = torch.arange(256, dtype=torch.float32).view(8, 32)
+    out = ops.selftest(1, tile.bfloat16().to(DEV).view(torch.int16)).cpu().view(64, 4)
+    for lane in range(64):
+        l16, g1, hi = lane & 15, (lane >> 4) & 1, lane >> 5
+        for j in range(4):
+            assert out[lane, j] == tile[4 * hi + j, 16 * g1 + l16], (lane, j)
+
+
+def _lsi(shapes):
+    return torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+
+
+def test_msda_reference_recipe_float():
+    """the reference's own check (ops/test.py:52-66): fp32 op vs pytorch core, rtol 1e-2 atol 1e-3 there; here 1e-6."""
+    from hipie_amd import ops
+    g = Golden("msda")
+    shapes = g["ref_float_shapes"]
+    out = ops.ms_deform_attn_forward(g["ref_float_value"].to(DEV), shapes.to(DEV), _lsi(shapes).to(DEV),
+                                     g["ref_float_loc"].to(DEV), g["ref_float_attn"].to(DEV), 2).cpu()
+    assert torch.allclose(out, g["ref_float_out"], rtol=1e-2, atol=1e-3)
+    assert rel_err(out, g["ref_float_out"]) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["hot_enc", "hot_dec", "hot_rect"])
+def test_msda_hot_geometry(tag):
+    from hipie_amd import ops
+    g = Golden("msda")
+    value, shapes, loc, attn = msda_case(g, tag)
+    out = ops.ms_deform_attn_forward(value.to(DEV), shapes.to(DEV), _lsi(shapes).to(DEV), loc.to(DEV), attn.to(DEV)).cpu()
+    assert rel_err(g.like(tag + "_out", out), g[tag + "_out"]) < 2e-5          # vs reference golden
+    assert rel_err(out, oo.ms_deform_attn_core(value, shapes, loc, attn)) < 2e-5   # vs oracle, full tensor
+    for dt, tol in ((torch.float16, 1e-3), (torch.bfloat16, 8e-3)):
+        o16 = ops.ms_deform_attn_forward(value.to(DEV).to(dt), shapes.to(DEV), _lsi(shapes).to(DEV), loc.to(DEV), attn.to(DEV))
+        ref16 = oo.ms_deform_attn_core(value.to(dt).float(), shapes, loc, attn)
+        assert rel_err(o16.float().cpu(), ref16) < tol
+
+
+@pytest.mark.parametrize("ref_dim", [2, 4])
+def test_msda_fused(ref_dim):
+    """fused sampling-location + softmax variant == MSDeformAttn.forward lines 99-114 followed by the op."""
+    from hipie_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    B, Lq, M, D, L, P = 2, 77, 8, 32, 4, 4
+    shapes = torch.tensor([(12, 20), (6, 10), (3, 5), (2, 3)])
+    S = int(shapes.prod(1).sum())
+    value = torch.randn(B, S, M, D, generator=gen)
+    off = torch.randn(B, Lq, M, L, P, 2, generator=gen) * 2
+    logit = torch.randn(B, Lq, M, L * P, generator=gen)
+    ref = torch.rand(B, Lq, L, ref_dim, generator=gen)
+    aw = torch.softmax(logit, -1).view(B, Lq, M, L, P)
+    if ref_dim == 2:
+        norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).float()
+        loc = ref[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    else:
+        loc = ref[:, :, None, :, None, :2] + off / P * ref[:, :, None, :, None, 2:] * 0.5
+    want = oo.ms_deform_attn_core(value, shapes, loc, aw)
+    got = ops.msda_fused(value.to(DEV), shapes.to(DEV), _lsi(shapes).to(DEV), ref.to(DEV), off.to(DEV), logit.to(DEV)).cpu()
+    assert rel_err(got, want) < 2e-5
+
+
+def test_msda_generic_head_dim():
+    from hipie_amd import ops
+    gen = torch.Generator().manual_seed(6)
+    shapes = torch.tensor([(6, 4), (3, 2)])
+    S = int(shapes.prod(1).sum())
+    for D in (2, 30, 71):
+        value = torch.rand(1, S, 2, D, generator=gen)
+        loc = torch.rand(1, 5, 2, 2, 2, 2, generator=gen)
+        attn = torch.rand(1, 5, 2, 2, 2, generator=gen)
+        got = ops.ms_deform_attn_forward(value.to(DEV), shapes.to(DEV), _lsi(shapes).to(DEV), loc.to(DEV), attn.to(DEV)).cpu()
+        assert rel_err(got, oo.ms_deform_attn_core(value, shapes, loc, attn)) < 2e-6
+
+
+@pytest.mark.parametrize("prec,tol", [(0, 2e-6), (1, 3e-5), (2, 1e-2)])
+@pytest.mark.parametrize("shape", [(2, 300, 256, 64, 64), (1, 37, 64, 24, 40), (1, 330, 32, 8, 8)])
+def test_mask_einsum(prec, tol, shape):
+    from hipie_amd import ops
+    B, Q, C, H, W = shape
+    gen = torch.Generator().manual_seed(7)
+    e = torch.randn(B, Q, C, generator=gen)
+    f = torch.randn(B, C, H, W, generator=gen)
+    want = oo.mask_einsum(e, f)
+    got = ops.mask_einsum(e.to(DEV), f.to(DEV), precision=prec).cpu()
+    assert rel_err(got, want) < tol
+    if prec == 1:
+        got16 = ops.mask_einsum(e.to(DEV), f.to(DEV), precision=1, out_dtype=torch.bfloat16).float().cpu()
+        assert rel_err(got16, want) < 8e-3
+
+
+@pytest.mark.parametrize("name", ["sq", "rect"])
+def test_dynamic_mask(name):
+    from hipie_amd import ops
+    g = Golden("dynamic_mask")
+    c, feats, refs, params = dyn_case(g, name)
+    got = ops.dynamic_mask(feats.to(DEV), refs[0].contiguous().to(DEV), params[0].contiguous().to(DEV), c["Q"], stride=8, up=2).cpu()
+    got = got.view(1, c["B"] * c["Q"], 2 * c["H"], 2 * c["W"])
+    assert rel_err(g.like(name + "_out", got), g[name + "_out"]) < 2e-5
+    want = oo.dynamic_mask(feats, refs, params, [c["Q"]] * c["B"], stride=8, up=2)
+    assert rel_err(got, want) < 2e-5
+
+
+def _vit_qkv(c, sd, x):
+    import torch.nn.functional as F
+    B, H, W, C = x.shape
+    qkv = F.linear(x, sd["qkv.weight"], sd["qkv.bias"]).reshape(B, H * W, 3 * C)
+    return qkv
+
+
+@pytest.mark.parametrize("dt,tol_same,tol_gold", [(torch.float16, 1e-3, 2e-3), (torch.bfloat16, 8e-3, 2e-2)])
+@pytest.mark.parametrize("name", ["window14", "global16", "global64", "global_rect"])
+def test_vit_attention(name, dt, tol_same, tol_gold):
+    """hipie_vit_attn (windowed 14x14, global with interpolated table, the real 64x64 grid, a non-square grid)."""
+    import torch.nn.functional as F
+    from hipie_amd import ops
+    g = Golden("vit_attn")
+    c, sd, x = vit_attn_case(g, name)
+    B, H, W, C = x.shape
+    heads = c["heads"]
+    hd = C // heads
+    qkv = _vit_qkv(c, sd, x).to(dt)                                   # the 16-bit operands the kernel sees
+    q, k, v = qkv.float().reshape(B, H * W, 3, heads, hd).permute(2, 0, 3, 1, 4).reshape(3, B * heads, H * W, hd).unbind(0)
+    Rh = oo.get_rel_pos(H, H, sd["rel_pos_h"])
+    Rw = oo.get_rel_pos(W, W, sd["rel_pos_w"])
+    rq = q.reshape(B * heads, H, W, hd)
+    rel_h = torch.einsum("bhwc,hkc->bhwk", rq, Rh).reshape(B * heads, H * W, H).contiguous()
+    rel_w = torch.einsum("bhwc,wkc->bhwk", rq, Rw).reshape(B * heads, H * W, W).contiguous()
+    got = ops.vit_attn(qkv.to(DEV), rel_h.to(DEV), rel_w.to(DEV), (H, W), heads, hd ** -0.5).float().cpu()
+    want = oo.vit_attention_core(q, k, v, sd["rel_pos_h"], sd["rel_pos_w"], (H, W), hd ** -0.5)
+    want = want.view(B, heads, H * W, hd).permute(0, 2, 1, 3).reshape(B, H * W, C)
+    assert rel_err(got, want) < tol_same
+    out = F.linear(got, sd["proj.weight"], sd["proj.bias"]).view(B, H, W, C)
+    assert rel_err(g.like(name + "_out", out), g[name + "_out"]) < tol_gold
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 1.5e-3), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("name", ["L20", "L600_pad", "clamp"])
+def test_bi_xattn(name, dt, tol):
+    """hipie_bi_xattn vs the oracle core on the same 16-bit-rounded projections (incl. the +-5e4 clamp case)."""
+    import torch.nn.functional as F
+    from hipie_amd import ops
+    g = Golden("bi_attn")
+    c, sd, v, l, mask = bi_case(g, name)
+    B, Nv, L, Hh, hd = c["B"], c["Nv"], c["L"], 8, 256
+    vn = F.layer_norm(v, (256,), sd["layer_norm_v.weight"], sd["layer_norm_v.bias"])
+    ln_ = F.layer_norm(l, (768,), sd["layer_norm_l.weight"], sd["layer_norm_l.bias"])
+    q = (F.linear(vn, sd["attn.v_proj.weight"], sd["attn.v_proj.bias"]) * hd ** -0.5).to(dt)
+    k = F.linear(ln_, sd["attn.l_proj.weight"], sd["attn.l_proj.bias"]).to(dt)
+    vv = F.linear(vn, sd["attn.values_v_proj.weight"], sd["attn.values_v_proj.bias"]).to(dt)
+    vl = F.linear(ln_, sd["attn.values_l_proj.weight"], sd["attn.values_l_proj.bias"]).to(dt)
+    if dt == torch.float16 and name == "clamp":
+        pytest.skip("3000x scaled activations overflow fp16 (the clamp case is a bf16/fp32-range case)")
+
+    def split(t, n):
+        return t.float().view(B, n, Hh, hd).transpose(1, 2).reshape(B * Hh, n, hd)
+    wv, wl = oo.bi_attention_core(split(q, Nv), split(k, L), split(vv, Nv), split(vl, L), mask)
+    wv = wv.view(B, Hh, Nv, hd).transpose(1, 2).reshape(B, Nv, Hh * hd)
+    wl = wl.view(B, Hh, L, hd).transpose(1, 2).reshape(B, L, Hh * hd)
+    ov, ol = ops.bi_xattn(q.view(B, Nv, Hh, hd).to(DEV), k.view(B, L, Hh, hd).to(DEV), vv.view(B, Nv, Hh, hd).to(DEV),
+                          vl.view(B, L, Hh, hd).to(DEV), mask.to(DEV))
+    assert rel_err(ov.float().cpu(), wv) < tol
+    assert rel_err(ol.float().cpu(), wl) < tol
+
+
+def test_flash_attn_no_tr_path_agrees():
+    """the plain-LDS-read V fetch (HIPIE_FA_NO_TR=1) and the ds_read_b64_tr_b16 fetch give the same result."""
+    import os
+    from hipie_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    q = torch.randn(2, 200, 4, 80, generator=gen).half().to(DEV)
+    k = torch.randn(2, 333, 4, 80, generator=gen).half().to(DEV)
+    v = torch.randn(2, 333, 4, 80, generator=gen).half().to(DEV)
+    a = ops.flash_attn(q, k, v, 80 ** -0.5)
+    os.environ["HIPIE_FA_NO_TR"] = "1"
+    try:
+        b = ops.flash_attn(q, k, v, 80 ** -0.5)
+    finally:
+        del os.environ["HIPIE_FA_NO_TR"]
+    assert rel_err(a.float().cpu(), b.float().cpu()) < 1e-6
+    ref = torch.nn.functional.scaled_dot_product_attention(q.float().cpu().transpose(1, 2), k.float().cpu().transpose(1, 2),
+                                                           v.float().cpu().transpose(1, 2)).transpose(1, 2).reshape(2, 200, 320)
+    assert rel_err(a.float().cpu(), ref) < 1e-3
