@@ -1,0 +1,143 @@
+"""Hyper-parameters of the hot path (the yacs keys the reference reads, flattened) and the precision policy.
+
+``add_hipie_config`` / ``HipieConfig.from_yacs`` map the reference's CfgNode (projects/HIPIE/hipie/config.py:5-284 and
+configs/mask_dino/*.yaml) onto this dataclass when detectron2/yacs are installed; without them the presets below are
+used (the GPU box has neither).
+"""
+from dataclasses import asdict, dataclass, field
+from typing import List
+
+import torch
+
+
+@dataclass
+class Precision:
+    """Arithmetic types of the path.  fp32 accumulate / softmax / LayerNorm everywhere.
+
+    gemm      dtype of the ViT linears (qkv, proj, mlp) -- library GEMMs (hipBLASLt through torch)
+    attn      16-bit operand type of the hand-written attention kernels (fp16 or bf16)
+    head      dtype of the linears/convs after the backbone (the reference runs them in fp32)
+    value     dtype of the MSDeformAttn value tensor (fp32 as the reference, or 16-bit to halve the gather traffic)
+    einsum    hipie_mask_einsum precision (0 exact fp32 MFMA, 1 bf16x3, 2 bf16)
+    """
+    gemm: torch.dtype = torch.bfloat16
+    attn: torch.dtype = torch.bfloat16
+    head: torch.dtype = torch.float32
+    value: torch.dtype = torch.float32
+    einsum: int = 1
+
+    @staticmethod
+    def parity():
+        """closest to the reference's fp32 eval arithmetic: only the attention operands are 16 bit (fp16)."""
+        return Precision(torch.float32, torch.float16, torch.float32, torch.float32, 0)
+
+    @staticmethod
+    def fast():
+        return Precision(torch.bfloat16, torch.bfloat16, torch.bfloat16, torch.bfloat16, 1)
+
+
+@dataclass
+class HipieConfig:
+    backbone: str = "vit"                       # "vit" | "r50"
+    vit_embed_dim: int = 1280
+    vit_depth: int = 32
+    vit_heads: int = 16
+    vit_window: int = 14
+    vit_window_blocks: List[int] = field(default_factory=lambda: [0, 1, 3, 4, 6, 7, 9, 10])   # vit.py:412-421
+    vit_img_size: int = 1024
+    vit_patch: int = 16
+    vit_pretrain_img_size: int = 224
+    vit_mlp_ratio: float = 4.0
+    hidden_dim: int = 256
+    nheads: int = 8
+    dim_feedforward: int = 2048
+    enc_layers: int = 6
+    dec_layers: int = 6
+    num_feature_levels: int = 4
+    enc_n_points: int = 4
+    dec_n_points: int = 4
+    num_queries: int = 900
+    num_bg_queries: int = 10
+    num_vl_layers: int = 1
+    vl_hidden_dim: int = 2048
+    lang_dim: int = 768
+    mask_stride: int = 4
+    ctrl_layers: int = 3
+    md_num_queries: int = 300
+    md_dec_layers: int = 9
+    md_enc_layers: int = 6
+    md_dim_feedforward: int = 2048
+    md_enc_dim_feedforward: int = 2048
+    md_mask_dim: int = 256
+    md_conv_dim: int = 256
+    bert_layers: int = 12
+    bert_hidden: int = 768
+    bert_heads: int = 12
+    bert_intermediate: int = 3072
+    bert_vocab: int = 30522
+    bert_max_pos: int = 512
+    pixel_mean: List[float] = field(default_factory=lambda: [123.675, 116.280, 103.530])
+    pixel_std: List[float] = field(default_factory=lambda: [58.395, 57.120, 57.375])
+    log_scale: float = 0.0
+    prior_prob: float = 0.01
+
+    # ---- presets -------------------------------------------------------------------------------------------
+    @staticmethod
+    def vit_huge():
+        """configs/eval/image_joint_vit_huge_32g_pan_maskdino_ade_test.yaml (ViT-huge: vit.py:392-396)."""
+        return HipieConfig()
+
+    @staticmethod
+    def vit_base():
+        return HipieConfig(vit_embed_dim=768, vit_depth=12, vit_heads=12)
+
+    @staticmethod
+    def vit_large():
+        return HipieConfig(vit_embed_dim=1024, vit_depth=24, vit_heads=16)
+
+    @staticmethod
+    def r50():
+        """configs/eval/image_joint_r50_pan_maskdino_ade_test.yaml."""
+        return HipieConfig(backbone="r50")
+
+    @staticmethod
+    def from_dict(d):
+        names = set(HipieConfig.__dataclass_fields__)
+        return HipieConfig(**{k: v for k, v in d.items() if k in names})
+
+    def to_dict(self):
+        return asdict(self)
+
+    @property
+    def backbone_channels(self):
+        if self.backbone == "r50":
+            return [512, 1024, 2048]
+        e = self.vit_embed_dim
+        return [e // 2, e, e]
+
+    @staticmethod
+    def from_yacs(cfg, md_cfg=None):
+        """reference CfgNode (after add_hipie_config + yaml merge) -> HipieConfig."""
+        m = cfg.MODEL
+        c = HipieConfig()
+        if m.BACKBONE.NAME == "D2ViT":
+            geo = {"ViT-Base": (768, 12, 12), "ViT-Large": (1024, 24, 16), "ViT-huge": (1280, 32, 16)}[m.VIT.NAME]
+            c.backbone, (c.vit_embed_dim, c.vit_depth, c.vit_heads) = "vit", geo
+        else:
+            c.backbone = "r50"
+        d = m.DDETRS
+        c.hidden_dim, c.nheads, c.dim_feedforward = d.HIDDEN_DIM, d.NHEADS, d.DIM_FEEDFORWARD
+        c.enc_layers, c.dec_layers, c.num_feature_levels = d.ENC_LAYERS, d.DEC_LAYERS, d.NUM_FEATURE_LEVELS
+        c.enc_n_points, c.dec_n_points = d.ENC_N_POINTS, d.DEC_N_POINTS
+        c.num_queries, c.num_bg_queries = d.TWO_STAGE_NUM_PROPOSALS, d.TWO_STAGE_NUM_BG_PROPOSALS
+        c.num_vl_layers, c.vl_hidden_dim = d.NUM_VL_LAYERS, d.VL_HIDDEN_DIM
+        c.mask_stride, c.ctrl_layers = d.MASK_STRIDE, d.CTRL_LAYERS
+        c.lang_dim = m.LANGUAGE_BACKBONE.LANG_DIM
+        c.pixel_mean, c.pixel_std = list(m.PIXEL_MEAN), list(m.PIXEL_STD)
+        c.log_scale, c.prior_prob = m.DYHEAD.LOG_SCALE, m.DYHEAD.PRIOR_PROB
+        if md_cfg is not None:
+            md, sh = md_cfg.MODEL.MaskDINO, md_cfg.MODEL.SEM_SEG_HEAD
+            c.md_num_queries, c.md_dec_layers, c.md_dim_feedforward = md.NUM_OBJECT_QUERIES, md.DEC_LAYERS, md.DIM_FEEDFORWARD
+            c.md_enc_layers, c.md_enc_dim_feedforward = sh.TRANSFORMER_ENC_LAYERS, sh.DIM_FEEDFORWARD
+            c.md_mask_dim, c.md_conv_dim = sh.MASK_DIM, sh.CONVS_DIM
+        return c

@@ -1,0 +1,141 @@
+"""HIPIE_IMG meta-architecture (inference): the drop-in boundary b1 of SURVEY 8b.
+
+Mirrors hipie/hipie_img.py: __init__ (:51-262, the parts the eval path touches), forward (:263-420, eval branch),
+preprocess_image (:880-898), forward_text (:900-922).  ``forward_raw`` returns the a22 parity surface
+(DDETRSegmUniDN.coco_inference's output dict); ``forward`` adds the per-image post-processing.
+
+Construction needs no detectron2: pass a HipieConfig (hipie_amd/config.py).  With detectron2 installed,
+hipie_amd.d2_registry registers this class as META_ARCH "HIPIE_IMG" with the reference's ``__init__(cfg)`` signature.
+"""
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .config import HipieConfig, Precision
+from .modeling.ddetrs_dn import DDETRSegmUniDN
+from .modeling.text import BertEncoder
+from .modeling.transformer import (DeformableDETRDINO, DeformableTransformerVLDINO, Joiner, MaskedBackbone,
+                                   PositionEmbeddingSine, cast_head)
+from .modeling.vit import D2ViT
+
+
+class ImageList(object):
+    """the slice of detectron2.structures.ImageList the path uses: padded batch + per-image sizes."""
+
+    def __init__(self, tensor, image_sizes):
+        self.tensor, self.image_sizes = tensor, image_sizes
+
+    def __len__(self):
+        return len(self.image_sizes)
+
+    def __iter__(self):
+        for t, (h, w) in zip(self.tensor, self.image_sizes):
+            yield t[:, :h, :w]
+
+    @staticmethod
+    def from_tensors(tensors):
+        sizes = [(int(t.shape[-2]), int(t.shape[-1])) for t in tensors]
+        H, W = max(s[0] for s in sizes), max(s[1] for s in sizes)
+        out = tensors[0].new_zeros(len(tensors), tensors[0].shape[0], H, W)
+        for i, t in enumerate(tensors):
+            out[i, :, :t.shape[-2], :t.shape[-1]].copy_(t)
+        return ImageList(out, sizes)
+
+
+def build_backbone(cfg, precision):
+    if cfg.backbone == "vit":
+        return D2ViT(cfg, precision)
+    if cfg.backbone == "r50":
+        from .modeling.resnet import ResNet50
+        return ResNet50(precision)
+    raise ValueError("unknown backbone %r" % cfg.backbone)
+
+
+class HIPIE_IMG(nn.Module):
+    def __init__(self, cfg: HipieConfig, precision: Precision = None, device="cuda"):
+        super().__init__()
+        _lib.load()       # fail loudly at construction when the HIP library is missing -- there is no fallback path
+        self.cfg = cfg
+        self.precision = precision or Precision()
+        self.device = torch.device(device)
+        self.demo_only = False
+        self.mask_stride = cfg.mask_stride
+        bb = build_backbone(cfg, self.precision)
+        d2_backbone = MaskedBackbone(bb, [8, 16, 32], cfg.backbone_channels)
+        backbone = Joiner(d2_backbone, PositionEmbeddingSine(cfg.hidden_dim // 2, offset=-0.5))
+        backbone.num_channels = d2_backbone.num_channels
+        backbone.strides = d2_backbone.feature_strides
+        transformer = DeformableTransformerVLDINO(cfg, self.precision)
+        model = DeformableDETRDINO(backbone, transformer, cfg)
+        self.tokenizer = None
+        tok_dir = "projects/HIPIE/bert-base-uncased"
+        if os.path.isdir(tok_dir):                         # hipie_img.py:153 (cwd-relative asset, absent on the GPU box)
+            from transformers import AutoTokenizer
+            self.tokenizer = AutoTokenizer.from_pretrained(tok_dir)
+        self.text_encoder = nn.Sequential(OrderedDict([("body", BertEncoder(cfg))]))
+        self.detr = DDETRSegmUniDN(model, cfg, self.precision)
+        self.register_buffer("pixel_mean", torch.tensor(cfg.pixel_mean).view(3, 1, 1), persistent=False)
+        self.register_buffer("pixel_std", torch.tensor(cfg.pixel_std).view(3, 1, 1), persistent=False)
+        self.eval()
+
+    def finalize(self):
+        """after loading weights: move to the device and put GEMM weights in the policy dtypes."""
+        self.to(self.device)
+        bb = self.detr.detr.backbone[0].backbone
+        if hasattr(bb, "cast_weights"):
+            bb.cast_weights()
+        cast_head(self.detr.detr.transformer, self.precision.head)
+        cast_head(self.detr.detr.input_proj, self.precision.head)
+        cast_head(self.detr.mask_dino, self.precision.head)
+        cast_head(self.detr.mask_head, self.precision.head)
+        return self
+
+    # ---- hipie_img.py:880-898 -------------------------------------------------------------------------------
+    def preprocess_image(self, batched_inputs):
+        images = [(x["image"].to(self.device).float() - self.pixel_mean) / self.pixel_std for x in batched_inputs]
+        return ImageList.from_tensors(images)
+
+    # ---- hipie_img.py:900-922 -------------------------------------------------------------------------------
+    def forward_text(self, batched_inputs, device=None):
+        if "input_ids" in batched_inputs[0]:               # synthetic / pre-tokenised path (no vocab on the GPU box)
+            ids = torch.stack([x["input_ids"] for x in batched_inputs]).to(self.device)
+            mask = torch.stack([x["attention_mask"] for x in batched_inputs]).to(self.device)
+            sep = 1012
+        else:
+            if self.tokenizer is None:
+                raise RuntimeError("no tokenizer assets (projects/HIPIE/bert-base-uncased): pass input_ids/attention_mask")
+            captions = [x["expressions"] for x in batched_inputs]
+            tok = self.tokenizer.batch_encode_plus(captions, padding="longest", return_special_tokens_mask=True,
+                                                   return_tensors="pt", truncation=True).to(self.device)
+            ids, mask = tok.input_ids, tok.attention_mask
+            sep = self.tokenizer(".").input_ids[1]
+        return self.text_encoder[0]({"input_ids": ids, "attention_mask": mask}, sep=sep)
+
+    @torch.no_grad()
+    def forward_raw(self, batched_inputs):
+        """list of {"image": (3,h,w) RGB 0..255, "task": ..., "expressions" | "input_ids"+"attention_mask"} -> a22 dict."""
+        tasks = set(x["task"] for x in batched_inputs)
+        assert len(tasks) == 1
+        task = tasks.pop()
+        images = self.preprocess_image(batched_inputs)
+        lang = self.forward_text(batched_inputs)
+        outputs, _ = self.detr.coco_inference(images, None, None, train=False, language_dict_features=lang, task=task)
+        outputs["image_sizes"] = images.image_sizes
+        return outputs
+
+    @torch.no_grad()
+    def forward(self, batched_inputs, do_postprocess=True):
+        from .postprocess import inference
+        out = self.forward_raw(batched_inputs)
+        return inference(self, out, batched_inputs)
+
+    # ---- test / bench hooks ---------------------------------------------------------------------------------
+    def pin_topk(self, topk_fg=None, topk_md=None):
+        self.detr.detr.transformer.pinned_topk = topk_fg
+        self.detr.mask_dino.predictor.pinned_topk = topk_md
+
+    def last_topk(self):
+        return self.detr.detr.transformer.last_topk, self.detr.mask_dino.predictor.last_topk

@@ -1,0 +1,189 @@
+"""MaskDINO "stuff/panoptic" branch: pixel decoder (6-layer MSDeformAttn encoder + one FPN
+level + mask_features) and the two-stage DINO decoder whose mask logits are the query x pixel contraction.
+
+Mirrors hipie/models/maskdino/pixel_decoder/maskdino_encoder.py (MaskDINOEncoder, feature_order low2high),
+transformer_decoder/maskdino_decoder.py (MaskDINODecoder, eval path), transformer_decoder/dino_decoder.py
+(TransformerDecoder) and meta_arch/maskdino_head.py (MaskDINOHead) with the reference's parameter names.
+The branch is called with mask=None (ddetrs_dn.py:885): all-False padding masks, valid_ratio 1.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .transformer import (MLP, DeformableTransformerDecoderLayer, DeformableTransformerEncoderLayer, FeatureResizer,
+                          PConv2d, PLinear, PositionEmbeddingSine, _get_clones, encoder_reference_points,
+                          gen_encoder_output_proposals, get_sine_pos_embed, inverse_sigmoid)
+
+
+class NormConv2d(PConv2d):
+    """detectron2.layers.Conv2d: conv (no bias) + norm (+ activation); parameter names <name>.weight, <name>.norm.*"""
+
+    def __init__(self, cin, cout, k, padding=0, relu=False):
+        super().__init__(cin, cout, kernel_size=k, padding=padding, bias=False)
+        self.norm = nn.GroupNorm(32, cout)
+        self.relu = relu
+
+    def forward(self, x):
+        x = self.norm(super().forward(x))
+        return F.relu(x) if self.relu else x
+
+
+class MSDeformAttnTransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer, num_layers):
+        super().__init__()
+        self.layers = _get_clones(encoder_layer, num_layers)
+
+
+class MSDeformAttnTransformerEncoderOnly(nn.Module):
+    """maskdino_encoder.py:42-115."""
+
+    def __init__(self, d_model, nhead, num_layers, dim_feedforward, num_levels, value_dtype):
+        super().__init__()
+        layer = DeformableTransformerEncoderLayer(d_model, dim_feedforward, num_levels, nhead, 4, value_dtype)
+        self.encoder = MSDeformAttnTransformerEncoder(layer, num_layers)
+        self.level_embed = nn.Parameter(torch.randn(num_levels, d_model))
+
+    def forward(self, srcs, pos_embeds):
+        shapes_list = [tuple(int(v) for v in s.shape[-2:]) for s in srcs]
+        src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+        pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[i].view(1, 1, -1) for i, p in enumerate(pos_embeds)], 1)
+        B = src.shape[0]
+        spatial_shapes = torch.as_tensor(shapes_list, dtype=torch.long, device=src.device)
+        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        valid_ratios = torch.ones(B, len(srcs), 2, device=src.device)
+        refs = encoder_reference_points(shapes_list, valid_ratios, src.device)
+        for layer in self.encoder.layers:
+            src = layer(src, pos, refs, spatial_shapes, level_start_index, None)
+        return src, shapes_list
+
+
+class MaskDINOEncoder(nn.Module):
+    """maskdino_encoder.py:190-434 for input features {res3,res4,res5}, 4 total levels, low2high, GN, num_fpn_levels 1."""
+
+    def __init__(self, cfg, in_channels, precision):
+        super().__init__()
+        cd = cfg.md_conv_dim
+        # input_proj[0..2] act on reversed transformer_in_features = [res3, res4, res5]; [3] = stride-2 conv on res5
+        self.input_proj = nn.ModuleList(
+            [nn.Sequential(PConv2d(c, cd, kernel_size=1), nn.GroupNorm(32, cd)) for c in in_channels] +
+            [nn.Sequential(PConv2d(max(in_channels), cd, kernel_size=3, stride=2, padding=1), nn.GroupNorm(32, cd))])
+        self.transformer = MSDeformAttnTransformerEncoderOnly(cd, 8, cfg.md_enc_layers, cfg.md_enc_dim_feedforward, 4, precision.value)
+        self.pe_layer = PositionEmbeddingSine(cd // 2, offset=0.0)
+        self.mask_features = nn.Sequential(nn.ConvTranspose2d(cd, cd, 2, stride=2), nn.GroupNorm(32, cd), nn.ReLU(),
+                                           PConv2d(cd, cfg.md_mask_dim, kernel_size=1))
+        self.adapter_1 = NormConv2d(in_channels[0], cd, 1)
+        self.layer_1 = NormConv2d(cd, cd, 3, padding=1, relu=True)
+
+    def forward_features(self, features, masks=None):
+        f3, f4, f5 = features["res3"].float(), features["res4"].float(), features["res5"].float()
+        extra = self.input_proj[3](f5)
+        srcs = [self.input_proj[i](f) for i, f in enumerate((f3, f4, f5))] + [extra]
+        zero = [torch.zeros(s.shape[0], s.shape[2], s.shape[3], dtype=torch.bool, device=s.device) for s in srcs]
+        pos = [self.pe_layer(z) for z in zero]
+        y, shapes = self.transformer(srcs, pos)
+        B = y.shape[0]
+        out, st = [], 0
+        for (H, W) in shapes:
+            out.append(y[:, st:st + H * W].transpose(1, 2).reshape(B, -1, H, W))
+            st += H * W
+        cur = self.adapter_1(f3)
+        z = cur + F.interpolate(out[0], size=cur.shape[-2:], mode="bilinear", align_corners=False)
+        z = self.layer_1(z)
+        mf = self.mask_features[0](z.to(self.mask_features[0].weight.dtype)).float()
+        mf = self.mask_features[3](self.mask_features[2](self.mask_features[1](mf)))
+        return mf, out[0], out          # mask_features (B,256,H/4,W/4), s8 level, [s8,s16,s32,s64]
+
+
+class TransformerDecoder(nn.Module):
+    """dino_decoder.py:19-168 (deformable, query_dim 4, shared bbox head, norm on every intermediate)."""
+
+    def __init__(self, decoder_layer, num_layers, norm, d_model):
+        super().__init__()
+        self.layers = _get_clones(decoder_layer, num_layers)
+        self.norm = norm
+        self.ref_point_head = MLP(2 * d_model, d_model, d_model, 2)
+        self.bbox_embed = None
+
+
+class MaskDINODecoder(nn.Module):
+    """maskdino_decoder.py:36-529, eval path (two_stage, initial_pred, initialize_box_type 'no', learn_tgt False)."""
+
+    def __init__(self, cfg, precision):
+        super().__init__()
+        d = cfg.hidden_dim
+        self.num_queries, self.num_layers, self.hidden_dim = cfg.md_num_queries, cfg.md_dec_layers, d
+        self.enc_output = PLinear(d, d)
+        self.enc_output_norm = nn.LayerNorm(d)
+        self.class_embed = PLinear(d, d)                     # num_classes = hidden_dim (ddetrs_dn.py:183-185)
+        self.resizer = FeatureResizer(768, d)                # dynamic_label_enc (training only; kept for the state_dict)
+        self.mask_embed = MLP(d, d, cfg.md_mask_dim, 3)
+        self.decoder_norm = nn.LayerNorm(d)
+        layer = DeformableTransformerDecoderLayer(d, cfg.md_dim_feedforward, 4, 8, 4, precision.value)
+        self.decoder = TransformerDecoder(layer, self.num_layers, self.decoder_norm, d)
+        self._bbox_embed = MLP(d, d, 4, 3)
+        self.bbox_embed = nn.ModuleList([self._bbox_embed for _ in range(self.num_layers)])
+        self.decoder.bbox_embed = self.bbox_embed
+        self.precision = precision
+        self.pinned_topk = None
+        self.last_topk = None
+
+    def forward_prediction_heads(self, output, mask_features, pred_mask=True):
+        """maskdino_decoder.py:520-529 -- the mask-logit contraction runs on hipie_mask_einsum."""
+        dec = self.decoder_norm(output)
+        cls = self.class_embed(dec)
+        masks = None
+        if pred_mask:
+            emb = self.mask_embed(dec)
+            masks = ops.mask_einsum(emb.float().contiguous(), mask_features.float().contiguous(), precision=self.precision.einsum)
+        return cls, masks
+
+    def forward(self, x, mask_features):
+        nl = len(x)
+        xs = [x[nl - 1 - i] for i in range(nl)]                         # memory order [s64,s32,s16,s8] (:385-397)
+        shapes_list = [tuple(int(v) for v in t.shape[-2:]) for t in xs]
+        src = torch.cat([t.flatten(2).transpose(1, 2) for t in xs], 1)
+        B = src.shape[0]
+        mask = torch.zeros(B, src.shape[1], dtype=torch.bool, device=src.device)
+        spatial_shapes = torch.as_tensor(shapes_list, dtype=torch.long, device=src.device)
+        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        vr2 = torch.ones(B, 1, nl, 4, device=src.device)
+        om, prop = gen_encoder_output_proposals(src, mask, shapes_list)
+        om = self.enc_output_norm(self.enc_output(om))
+        cls_un = self.class_embed(om)
+        coord_un = self._bbox_embed(om) + prop
+        if self.pinned_topk is not None:
+            topk = self.pinned_topk.to(src.device)
+        else:
+            topk = torch.topk(cls_un.max(-1)[0], self.num_queries, dim=1)[1]
+        self.last_topk = topk
+        ref_un = torch.gather(coord_un, 1, topk.unsqueeze(-1).repeat(1, 1, 4))
+        tgt = torch.gather(om, 1, topk.unsqueeze(-1).repeat(1, 1, self.hidden_dim))
+        interm_cls, interm_mask = self.forward_prediction_heads(tgt, mask_features)      # einsum #1 (:428)
+        ref = ref_un.sigmoid()
+        refs, out, hs = [ref], tgt, []
+        for lid, layer in enumerate(self.decoder.layers):
+            ref_in = ref[:, :, None] * vr2
+            query_pos = self.decoder.ref_point_head(get_sine_pos_embed(ref_in[:, :, 0, :]))
+            out = layer(out, query_pos, ref_in, src, spatial_shapes, level_start_index, None)
+            new_ref = (self.decoder.bbox_embed[lid](out) + inverse_sigmoid(ref)).sigmoid()
+            ref = new_ref.detach()
+            refs.append(new_ref)
+            hs.append(self.decoder.norm(out))
+        cls, masks = self.forward_prediction_heads(hs[-1], mask_features)                 # einsum #2 (:485)
+        boxes = (self.bbox_embed[-1](hs[-1]) + inverse_sigmoid(refs[-2])).sigmoid()       # pred_box (:357-375)
+        return {"pred_logits": cls, "pred_masks": masks, "pred_boxes": boxes,
+                "interm_outputs": {"pred_logits": interm_cls, "pred_masks": interm_mask, "pred_boxes": ref_un.sigmoid()}}
+
+
+class MaskDINOHead(nn.Module):
+    """meta_arch/maskdino_head.py:21-82."""
+
+    def __init__(self, cfg, in_channels, precision):
+        super().__init__()
+        self.pixel_decoder = MaskDINOEncoder(cfg, in_channels, precision)
+        self.predictor = MaskDINODecoder(cfg, precision)
+
+    def forward(self, features, mask=None):
+        mask_features, _, multi_scale = self.pixel_decoder.forward_features(features, mask)
+        return self.predictor(multi_scale, mask_features), None

@@ -1,0 +1,151 @@
+"""BERT text encoder: BertEncoder wrapper of hipie/models/deformable_detr/bert_model.py:11-153 with its
+long-prompt chunking, around a BERT-base encoder with HuggingFace's parameter names (the reference calls
+transformers.BertModel; the keys ``text_encoder.body.model.*`` of reference checkpoints load unchanged).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class BertSelfAttention(nn.Module):
+    def __init__(self, h, heads):
+        super().__init__()
+        self.query, self.key, self.value = nn.Linear(h, h), nn.Linear(h, h), nn.Linear(h, h)
+        self.heads = heads
+
+    def forward(self, x, ext_mask):
+        B, L, C = x.shape
+        hd = C // self.heads
+
+        def sp(t):
+            return t.view(B, L, self.heads, hd).permute(0, 2, 1, 3)
+        s = sp(self.query(x)) @ sp(self.key(x)).transpose(-1, -2) / math.sqrt(hd) + ext_mask
+        return (s.softmax(-1) @ sp(self.value(x))).permute(0, 2, 1, 3).reshape(B, L, C)
+
+
+class BertSelfOutput(nn.Module):
+    def __init__(self, hin, h):
+        super().__init__()
+        self.dense = nn.Linear(hin, h)
+        self.LayerNorm = nn.LayerNorm(h, eps=1e-12)
+
+    def forward(self, x, res):
+        return self.LayerNorm(self.dense(x) + res)
+
+
+class BertAttention(nn.Module):
+    def __init__(self, h, heads):
+        super().__init__()
+        self.self = BertSelfAttention(h, heads)
+        self.output = BertSelfOutput(h, h)
+
+    def forward(self, x, ext_mask):
+        return self.output(self.self(x, ext_mask), x)
+
+
+class BertIntermediate(nn.Module):
+    def __init__(self, h, inter):
+        super().__init__()
+        self.dense = nn.Linear(h, inter)
+
+    def forward(self, x):
+        return F.gelu(self.dense(x))
+
+
+class BertLayer(nn.Module):
+    def __init__(self, h, heads, inter):
+        super().__init__()
+        self.attention = BertAttention(h, heads)
+        self.intermediate = BertIntermediate(h, inter)
+        self.output = BertSelfOutput(inter, h)
+
+    def forward(self, x, ext_mask):
+        x = self.attention(x, ext_mask)
+        return self.output(self.intermediate(x), x)
+
+
+class BertEmbeddings(nn.Module):
+    def __init__(self, vocab, h, max_pos):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(vocab, h)
+        self.position_embeddings = nn.Embedding(max_pos, h)
+        self.token_type_embeddings = nn.Embedding(2, h)
+        self.LayerNorm = nn.LayerNorm(h, eps=1e-12)
+
+    def forward(self, ids):
+        L = ids.shape[1]
+        x = self.word_embeddings(ids) + self.position_embeddings.weight[:L][None] + self.token_type_embeddings.weight[0][None, None]
+        return self.LayerNorm(x)
+
+
+class BertLayers(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.layer = nn.ModuleList([BertLayer(cfg.bert_hidden, cfg.bert_heads, cfg.bert_intermediate) for _ in range(cfg.bert_layers)])
+
+
+class BertModel(nn.Module):
+    """BERT-base encoder, last hidden state (add_pooling_layer=False)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.embeddings = BertEmbeddings(cfg.bert_vocab, cfg.bert_hidden, cfg.bert_max_pos)
+        self.encoder = BertLayers(cfg)
+
+    def forward(self, input_ids, attention_mask):
+        x = self.embeddings(input_ids)
+        ext = (1.0 - attention_mask[:, None, None, :].to(x.dtype)) * torch.finfo(x.dtype).min
+        for layer in self.encoder.layer:
+            x = layer(x, ext)
+        return x
+
+
+class BertEncoder(nn.Module):
+    """hipie/models/deformable_detr/bert_model.py:11-153 (PARALLEL_DET False)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.model = BertModel(cfg)
+        self.language_dim = cfg.bert_hidden
+
+    def forward(self, x, task=None, sep=1012):
+        ids, mask = x["input_ids"], x["attention_mask"]
+        B, L = ids.shape
+        if L <= 512:
+            return {"masks": mask, "hidden": self.model(ids, mask)}
+        CLS, EOS = 101, 102
+        chunks = []
+        for b in range(B):       # host-side string-like processing of the token row (bert_model.py:74-110)
+            inp = ids[b].clone()
+            begin, start_src = 0, 0
+            while True:
+                seps = torch.where((inp == sep) | (inp == EOS))[0]
+                seps = seps[seps < 510]
+                if len(seps) == 0:
+                    break
+                last = int(seps[-1])
+                first = inp[:last + 1].clone()
+                first[-1] = EOS
+                on = torch.where(mask[b][:last + 1] == 1)[0]
+                n = len(first)
+                out_mask = torch.zeros(512, dtype=ids.dtype, device=ids.device)
+                if start_src == 0:
+                    row = torch.cat([first, torch.zeros(512 - n, dtype=ids.dtype, device=ids.device)])
+                    out_mask[on] = 1
+                else:
+                    pad = torch.zeros(512 - n - 1, dtype=ids.dtype, device=ids.device)
+                    pad[0] = sep
+                    row = torch.cat([torch.tensor([CLS], dtype=ids.dtype, device=ids.device), first, pad])
+                    out_mask[on + 1] = 1
+                    out_mask[0] = 1
+                chunks.append((b, row, out_mask, (start_src, start_src + n, begin, begin + n)))
+                start_src = 1
+                inp = inp[n:]
+                begin += n
+        hid = self.model(torch.stack([c[1] for c in chunks]), torch.stack([c[2] for c in chunks]))
+        out = torch.zeros(B, L, hid.shape[-1], dtype=torch.float32, device=ids.device)
+        for i, (b, _, _, (s0, s1, t0, t1)) in enumerate(chunks):
+            out[b, t0:t1] = hid[i, s0:s1]
+        return {"masks": mask, "hidden": out}

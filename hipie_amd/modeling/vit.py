@@ -1,0 +1,191 @@
+"""ViT backbone with windowed / global attention and decomposed relative position bias.
+
+Mirror of hipie/backbone/vit.py (ViT, Block, Attention, D2ViT) and hipie/backbone/utils.py with the reference's
+parameter names, so reference checkpoints load unchanged.  The attention core runs on the hand-written HIP kernel
+(hipie_vit_attn); the linears are library GEMMs.  The residual stream stays fp32, the GEMM/attention operands use the
+policy's 16-bit types.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+def get_rel_pos(q_size, k_size, rel_pos):
+    """hipie/backbone/utils.py:63-93."""
+    max_rel_dist = int(2 * max(q_size, k_size) - 1)
+    if rel_pos.shape[0] != max_rel_dist:
+        r = F.interpolate(rel_pos.reshape(1, rel_pos.shape[0], -1).permute(0, 2, 1), size=max_rel_dist, mode="linear")
+        r = r.reshape(-1, max_rel_dist).permute(1, 0)
+    else:
+        r = rel_pos
+    q_coords = torch.arange(q_size, device=rel_pos.device)[:, None] * max(k_size / q_size, 1.0)
+    k_coords = torch.arange(k_size, device=rel_pos.device)[None, :] * max(q_size / k_size, 1.0)
+    rel = (q_coords - k_coords) + (k_size - 1) * max(q_size / k_size, 1.0)
+    return r[rel.long()]
+
+
+def get_abs_pos(abs_pos, has_cls_token, hw):
+    """hipie/backbone/utils.py:128-157."""
+    h, w = hw
+    if has_cls_token:
+        abs_pos = abs_pos[:, 1:]
+    size = int(math.sqrt(abs_pos.shape[1]))
+    if size != h or size != w:
+        new = F.interpolate(abs_pos.reshape(1, size, size, -1).permute(0, 3, 1, 2), size=(h, w), mode="bicubic",
+                            align_corners=False)
+        return new.permute(0, 2, 3, 1)
+    return abs_pos.reshape(1, h, w, -1)
+
+
+def window_partition(x, ws):
+    B, H, W, C = x.shape
+    ph, pw = (ws - H % ws) % ws, (ws - W % ws) % ws
+    if ph or pw:
+        x = F.pad(x, (0, 0, 0, pw, 0, ph))
+    Hp, Wp = H + ph, W + pw
+    x = x.view(B, Hp // ws, ws, Wp // ws, ws, C)
+    return x.permute(0, 1, 3, 2, 4, 5).contiguous().view(-1, ws, ws, C), (Hp, Wp)
+
+
+def window_unpartition(win, ws, pad_hw, hw):
+    Hp, Wp = pad_hw
+    H, W = hw
+    B = win.shape[0] // (Hp * Wp // ws // ws)
+    x = win.view(B, Hp // ws, Wp // ws, ws, ws, -1).permute(0, 1, 3, 2, 4, 5).contiguous().view(B, Hp, Wp, -1)
+    if Hp > H or Wp > W:
+        x = x[:, :H, :W, :].contiguous()
+    return x
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, kernel_size=(16, 16), stride=(16, 16), in_chans=3, embed_dim=768):
+        super().__init__()
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=kernel_size, stride=stride)
+
+    def forward(self, x):
+        return self.proj(x).permute(0, 2, 3, 1)
+
+
+class Attention(nn.Module):
+    """hipie/backbone/vit.py:27-83."""
+
+    def __init__(self, dim, num_heads, input_size, precision):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+        self.rel_pos_h = nn.Parameter(torch.zeros(2 * input_size[0] - 1, dim // num_heads))
+        self.rel_pos_w = nn.Parameter(torch.zeros(2 * input_size[1] - 1, dim // num_heads))
+        self.precision = precision
+
+    def forward(self, x):
+        """x (B,H,W,C) already LayerNorm-ed, in the GEMM dtype -> (B,H,W,C) in the GEMM dtype."""
+        B, H, W, C = x.shape
+        nh = self.num_heads
+        hd = C // nh
+        qkv = self.qkv(x).reshape(B, H * W, 3 * C)
+        # decomposed rel-pos bias from the UNSCALED q (utils.py:113-123), as two small fp32 GEMMs
+        rq = qkv[:, :, :C].reshape(B, H, W, nh, hd).float()
+        Rh = get_rel_pos(H, H, self.rel_pos_h.float())
+        Rw = get_rel_pos(W, W, self.rel_pos_w.float())
+        rel_h = torch.einsum("bhwnc,hkc->bnhwk", rq, Rh).reshape(B * nh, H * W, H)
+        rel_w = torch.einsum("bhwnc,wkc->bnhwk", rq, Rw).reshape(B * nh, H * W, W)
+        qkv16 = qkv.to(self.precision.attn)
+        o = ops.vit_attn(qkv16.contiguous(), rel_h.contiguous(), rel_w.contiguous(), (H, W), nh, self.scale)
+        return self.proj(o.to(x.dtype)).view(B, H, W, C)
+
+
+class Mlp(nn.Module):
+    """timm.models.layers.Mlp as used at vit.py:193-197 (exact-erf GELU)."""
+
+    def __init__(self, in_features, hidden_features):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden_features, in_features)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class Block(nn.Module):
+    """hipie/backbone/vit.py:147-230; LayerNorm eps 1e-6."""
+
+    def __init__(self, dim, num_heads, mlp_ratio, window_size, input_size, precision):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = Attention(dim, num_heads, input_size if window_size == 0 else (window_size, window_size), precision)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+        self.window_size = window_size
+        self.precision = precision
+
+    def _ln(self, norm, x):
+        return F.layer_norm(x, x.shape[-1:], norm.weight.float(), norm.bias.float(), norm.eps).to(self.precision.gemm)
+
+    def forward(self, x):
+        """x: fp32 residual stream (B,H,W,C)."""
+        y = self._ln(self.norm1, x)
+        if self.window_size > 0:
+            H, W = y.shape[1], y.shape[2]
+            y, pad_hw = window_partition(y, self.window_size)
+        y = self.attn(y)
+        if self.window_size > 0:
+            y = window_unpartition(y, self.window_size, pad_hw, (H, W))
+        x = x + y.float()
+        x = x + self.mlp(self._ln(self.norm2, x)).float()
+        return x
+
+
+class ViT(nn.Module):
+    """hipie/backbone/vit.py:233-374 (use_abs_pos, use_rel_pos, no residual conv blocks, pretrain cls token)."""
+
+    def __init__(self, cfg, precision):
+        super().__init__()
+        E = cfg.vit_embed_dim
+        self.patch_embed = PatchEmbed((cfg.vit_patch,) * 2, (cfg.vit_patch,) * 2, 3, E)
+        n = (cfg.vit_pretrain_img_size // cfg.vit_patch) ** 2 + 1
+        self.pos_embed = nn.Parameter(torch.zeros(1, n, E))
+        g = cfg.vit_img_size // cfg.vit_patch
+        self.blocks = nn.ModuleList([
+            Block(E, cfg.vit_heads, cfg.vit_mlp_ratio, cfg.vit_window if i in cfg.vit_window_blocks else 0, (g, g), precision)
+            for i in range(cfg.vit_depth)])
+        self.fpn1 = nn.Sequential(nn.ConvTranspose2d(E, E // 2, kernel_size=2, stride=2))
+        self.fpn2 = nn.Identity()
+        self.fpn3 = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.precision = precision
+        self._out_feature_channels = {"res3": E // 2, "res4": E, "res5": E}
+        self._out_feature_strides = {"res3": 8, "res4": 16, "res5": 32}
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+
+    size_divisibility = 32
+
+    def forward(self, x):
+        """x (B,3,H,W) fp32 normalised image -> {"res3","res4","res5"} NCHW fp32."""
+        gd = self.precision.gemm
+        x = self.patch_embed(x.to(gd)).float()
+        x = x + get_abs_pos(self.pos_embed.float(), True, (x.shape[1], x.shape[2]))
+        for blk in self.blocks:
+            x = blk(x)
+        xp = x.permute(0, 3, 1, 2)
+        return {"res3": self.fpn1(xp.to(gd)).float(), "res4": xp, "res5": self.fpn3(xp)}
+
+    def cast_weights(self):
+        """put the GEMM/conv weights in the policy dtype (norms, pos tables stay fp32)."""
+        gd = self.precision.gemm
+        for m in self.modules():
+            if isinstance(m, (nn.Linear, nn.Conv2d, nn.ConvTranspose2d)):
+                m.to(gd)
+        return self
+
+
+class D2ViT(ViT):
+    """registered as "D2ViT" in detectron2's BACKBONE_REGISTRY when detectron2 is importable (hipie_amd/d2_registry.py)."""
+
+    def output_shape(self):
+        return {k: dict(channels=self._out_feature_channels[k], stride=self._out_feature_strides[k]) for k in ("res3", "res4", "res5")}

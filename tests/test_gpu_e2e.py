@@ -1,0 +1,81 @@
+"""GPU: the whole product path (HIPIE_IMG.forward_raw -> a22 dict) against the reference-generated golden and the oracle.
+
+The two top-k query selections are discontinuous (a 1-ulp score change swaps queries), so the end-to-end comparison pins
+their indices to the reference's (hard part (c)); the free-running selection is checked separately by overlap.
+Tolerances (max|a-b| / max|b|): Precision.parity() (fp32 GEMMs, fp16 attention operands) 2e-3 on every output;
+Precision.fast() (bf16 everywhere) 5e-2 -- bf16 has 8 mantissa bits, the reference path is fp32."""
+import pytest
+import torch
+
+import _synth
+from util import Golden, rel_err
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+KEYS = ["pred_logits", "pred_boxes", "pred_boxious", "pred_masks", "reference_points", "pred_masks_maskdino",
+        "pred_logits_maskdino", "pred_boxes_maskdino"]
+
+
+def build(precision):
+    from hipie_amd.config import HipieConfig
+    from hipie_amd.hipie_img import HIPIE_IMG
+    g = Golden("e2e_tiny")
+    cfg = HipieConfig.from_dict(g.meta["cfg"])
+    model = HIPIE_IMG(cfg, precision, device="cuda")
+    sd = _synth.synth_full_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()})
+    model.load_state_dict(sd, strict=True)
+    return g, model.finalize()
+
+
+def inputs(g, task):
+    imgs = _synth.synth_images([tuple(s) for s in g.meta["sizes"]], seed=73)
+    ids, mask, pmap = _synth.synth_token_ids(2, g.meta[task]["n_classes"], 64, seed=74)
+    return [{"image": im, "task": task, "input_ids": ids[i], "attention_mask": mask[i],
+             "positive_map_label_to_token": pmap} for i, im in enumerate(imgs)]
+
+
+@pytest.mark.parametrize("task", ["detection", "grounding"])
+def test_e2e_tiny_parity_policy(task):
+    from hipie_amd.config import Precision
+    g, model = build(Precision.parity())
+    model.pin_topk(g[task + "_topk_fg"], g[task + "_topk_md"])
+    out = model.forward_raw(inputs(g, task))
+    for k in KEYS:
+        assert rel_err(g.like(task + "_" + k, out[k].float().cpu()), g[task + "_" + k]) < 2e-3, k
+
+
+def test_e2e_tiny_free_topk_overlap():
+    from hipie_amd.config import Precision
+    g, model = build(Precision.parity())
+    model.forward_raw(inputs(g, "detection"))
+    fg, md = model.last_topk()
+    for got, want in ((fg.cpu(), g["detection_topk_fg"]), (md.cpu(), g["detection_topk_md"])):
+        for b in range(got.shape[0]):
+            inter = len(set(got[b].tolist()) & set(want[b].tolist()))
+            assert inter >= 0.9 * want.shape[1]
+
+
+def test_e2e_tiny_fast_policy():
+    from hipie_amd.config import Precision
+    g, model = build(Precision.fast())
+    model.pin_topk(g["detection_topk_fg"], g["detection_topk_md"])
+    out = model.forward_raw(inputs(g, "detection"))
+    for k in KEYS:
+        assert rel_err(g.like("detection_" + k, out[k].float().cpu()), g["detection_" + k]) < 5e-2, k
+
+
+def test_stage_vit_backbone():
+    """D2ViT alone (3 blocks: window, window, global; interpolated abs-pos and rel-pos tables) vs the reference golden."""
+    from hipie_amd.config import HipieConfig, Precision
+    from hipie_amd.modeling.vit import D2ViT
+    g = Golden("vit_backbone")
+    cfg = HipieConfig.from_dict(g.meta["cfg"])
+    for prec, tol in ((Precision.parity(), 2e-3), (Precision.fast(), 3e-2)):
+        m = D2ViT(cfg, prec)
+        m.load_state_dict(_synth.synth_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}, seed=31))
+        m = m.cuda().eval().cast_weights()
+        x = _synth.synth_tensor("vit_in", g.meta["x_shape"], seed=32).cuda()
+        out = m(x)
+        for k in ("res3", "res4", "res5"):
+            assert rel_err(g.like(k, out[k].float().cpu()), g[k]) < tol, (k, prec)

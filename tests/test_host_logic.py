@@ -1,0 +1,75 @@
+"""CPU: host-side logic of the product (no kernel launches): state_dict compatibility with the reference, config,
+preprocessing, chunked text encoder."""
+import pytest
+import torch
+
+import _synth
+from util import Golden, rel_err
+
+torch.set_grad_enabled(False)
+
+
+def tiny_model(device="cpu"):
+    from hipie_amd.config import HipieConfig, Precision
+    from hipie_amd.hipie_img import HIPIE_IMG
+    g = Golden("e2e_tiny")
+    cfg = HipieConfig.from_dict(g.meta["cfg"])
+    return g, cfg, HIPIE_IMG(cfg, Precision.parity(), device=device)
+
+
+def test_state_dict_matches_reference_manifest():
+    """every key/shape of the reference model's state_dict (DetectionCheckpointer must load unchanged)."""
+    g, cfg, model = tiny_model()
+    ours = {k: list(v.shape) for k, v in model.state_dict().items()}
+    ref = g.meta["manifest"]
+    assert sorted(ours) == sorted(ref)
+    for k in ref:
+        assert ours[k] == ref[k], k
+
+
+def test_tied_parameters_are_shared_like_the_reference():
+    g, cfg, model = tiny_model()
+    d = model.detr
+    assert d.detr.transformer.decoder.bbox_embed is d.detr.bbox_embed
+    assert d.detr.transformer.decoder.class_embed[0] is d.detr.class_embed[0]
+    p = d.mask_dino.predictor
+    assert p.bbox_embed[0] is p._bbox_embed and p.decoder.bbox_embed[1] is p._bbox_embed and p.decoder.norm is p.decoder_norm
+
+
+def test_full_size_vit_huge_key_count():
+    from hipie_amd.config import HipieConfig
+    c = HipieConfig.vit_huge()
+    assert (c.vit_embed_dim, c.vit_depth, c.vit_heads) == (1280, 32, 16) and c.vit_window_blocks == [0, 1, 3, 4, 6, 7, 9, 10]
+    assert c.backbone_channels == [640, 1280, 1280]
+
+
+def test_preprocess_matches_oracle():
+    from oracle import model as om
+    g, cfg, model = tiny_model()
+    imgs = _synth.synth_images([tuple(s) for s in g.meta["sizes"]], seed=73)
+    il = model.preprocess_image([{"image": im} for im in imgs])
+    from hipie_amd.modeling.transformer import nested_tensor_from_images
+    nt = nested_tensor_from_images(list(il), 32)
+    t, m, sizes = om.preprocess(imgs, g.meta["cfg"])
+    assert torch.equal(nt.mask, m) and rel_err(nt.tensors, t) < 1e-6 and il.image_sizes == sizes
+
+
+def test_text_encoder_matches_golden_cpu():
+    """the BERT wrapper is pure torch (no custom kernel): check short and chunked paths against the reference golden."""
+    from hipie_amd.config import HipieConfig
+    from hipie_amd.modeling.text import BertEncoder
+    g = Golden("bert")
+    enc = BertEncoder(HipieConfig.from_dict(g.meta["cfg"])).eval()
+    sd = _synth.synth_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}, seed=51)
+    enc.load_state_dict(sd, strict=True)
+    for tag in ("short", "long"):
+        out = enc({"input_ids": g[tag + "_ids"], "attention_mask": g[tag + "_mask"]}, sep=1012)["hidden"]
+        assert rel_err(g.like(tag + "_hidden", out), g[tag + "_hidden"]) < 5e-5
+
+
+def test_library_missing_fails_loudly(monkeypatch):
+    from hipie_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libhipie_mi355.so")
+    with pytest.raises(_lib.HipieLibraryError):
+        _lib.load()
