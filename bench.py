@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the HIPIE single-image inference hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path (HIPIE_IMG.forward_raw: preprocess -> BERT -> ViT -> fused deformable transformer ->
+MaskDINO -> a22 output dict, then the compact per-image top-100 predictions and -- for N > 1 -- their RCCL all-gather)
+over one batch of synthetic images that is already resident in HBM.  Workload (BASELINE.json configs[2], the one the
+metric is quoted on): ViT-H backbone, 1024x1024, batch 8 per GPU, COCO-80 class prompt (L = 194 tokens), task "detection".
+Data-parallel weak scaling: every rank processes its own batch of 8.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant hand-written kernel (global ViT attention,
+flash_attn_kernel<bf16, 80, 2, bias>), timed live with HIP events on the launch stream inside the timed steps;
+`cpu_baseline` times the oracle (CPU restatement of the reference) on a bounded sample on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def synth_batch(cfg, batch, size, n_classes, L, device, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.zeros(L, dtype=torch.long)
+    mask = torch.zeros(L, dtype=torch.long)
+    row, pmap = [101], {}
+    for c in range(n_classes):
+        k = int(torch.randint(1, 4, (1,), generator=g))
+        if len(row) + k + 2 > L:
+            break
+        pmap[c + 1] = list(range(len(row), len(row) + k))
+        row += torch.randint(1996, 29000, (k,), generator=g).tolist() + [1012]
+    row.append(102)
+    ids[:len(row)] = torch.tensor(row)
+    mask[:len(row)] = 1
+    out = []
+    for b in range(batch):
+        img = torch.randint(0, 256, (3, size, size), generator=g).float().to(device)      # resident in HBM before timing
+        out.append({"image": img, "task": "detection", "input_ids": ids.to(device), "attention_mask": mask.to(device),
+                    "positive_map_label_to_token": pmap})
+    return out
+
+
+def randomize_degenerate_inits(model):
+    """default module init leaves rel_pos tables / MSDA offset weights / last bbox layers at zero, which would make the
+    kernels' work trivial: redraw them N(0, 0.02) / a spread-out offset bias."""
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("rel_pos_h") or n.endswith("rel_pos_w") or "sampling_offsets.weight" in n or "attention_weights.weight" in n:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+            elif "sampling_offsets.bias" in n:
+                p.copy_(torch.randn(p.shape, generator=g) * 1.5)
+            elif p.dim() >= 2 and float(p.abs().sum()) == 0.0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+
+
+def cpu_baseline(cfg_dict, size, L, n_classes):
+    """oracle (kind "port") on the host cores, bounded: 1 image, the ViT truncated to 1 windowed + 1 global block (each
+    timed), everything after the backbone in full; s/img = t_rest + 8 t_win + 24 t_glob for the 32-block ViT-H."""
+    from oracle import model as om
+    from hipie_amd.config import HipieConfig, Precision
+    from hipie_amd.hipie_img import HIPIE_IMG
+    torch.set_num_threads(os.cpu_count())
+    c = dict(cfg_dict)
+    c.update(vit_depth=2, vit_window_blocks=[0])
+    m = HIPIE_IMG(HipieConfig.from_dict(c), Precision.parity(), device="cpu")
+    randomize_degenerate_inits(m)
+    sd = {k: v.float() for k, v in m.state_dict().items()}
+    del m
+    batch = synth_batch(None, 1, size, n_classes, L, "cpu", seed=1)
+    ids, mask = batch[0]["input_ids"][None], batch[0]["attention_mask"][None]
+    t0 = time.time()
+    lang = om.bert_encoder(ids, mask, sd, "text_encoder.body.model.", c)
+    out = om.coco_inference([batch[0]["image"]], lang, sd, c, task="detection")
+    t_total2 = time.time() - t0
+    x = torch.randn(1, size // 16, size // 16, c["vit_embed_dim"])
+    p = "detr.detr.backbone.0.backbone.blocks."
+    t0 = time.time()
+    om.vit_block(x, sd, p + "0.", c["vit_heads"], c["vit_window"])
+    t_win = time.time() - t0
+    t0 = time.time()
+    om.vit_block(x, sd, p + "1.", c["vit_heads"], 0)
+    t_glob = time.time() - t0
+    nwin = len(cfg_dict["vit_window_blocks"])
+    nglob = cfg_dict["vit_depth"] - nwin
+    s_img = t_total2 + (nwin - 1) * t_win + (nglob - 1) * t_glob
+    return {"value": round(1.0 / s_img, 5), "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
+            "sample": "oracle/ (fp32 PyTorch CPU restatement) on 1 image %dx%d, L=%d: full text encoder + everything after "
+                      "the backbone + 1 windowed and 1 global ViT block measured (%.2fs, %.2fs), scaled to %d+%d blocks; "
+                      "measured part %.1fs" % (size, size, L, t_win, t_glob, nwin, nglob, t_total2 + t_win + t_glob)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--model", default="vit_huge", choices=["vit_huge", "vit_large", "vit_base"])
+    ap.add_argument("--precision", default="fast", choices=["fast", "parity", "default"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from hipie_amd import ops, parallel
+    from hipie_amd.config import HipieConfig, Precision
+    from hipie_amd.hipie_img import HIPIE_IMG
+    from hipie_amd.postprocess import inference
+
+    rank, world, local = parallel.init_from_env()
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.set_grad_enabled(False)
+
+    cfg = getattr(HipieConfig, args.model)()
+    prec = {"fast": Precision.fast(), "parity": Precision.parity(), "default": Precision()}[args.precision]
+    torch.manual_seed(0)
+    model = HIPIE_IMG(cfg, prec, device=dev)
+    randomize_degenerate_inits(model)
+    model.finalize()
+    L, n_classes = 194, 80
+    batch = synth_batch(cfg, args.batch, args.size, n_classes, L, dev, seed=rank)
+
+    def step():
+        out = model.forward_raw(batch)
+        res = inference(model, out, batch)
+        block = parallel.compact_predictions(res, topk=100, device=dev)
+        return parallel.all_gather_predictions(block)
+
+    for _ in range(args.warmup):
+        step()
+    ops.PROFILE.enable("vit_attn_global")
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt = time.perf_counter() - t0
+    dt = parallel.max_over_ranks(dt, dev)
+    kern_ms, kern_n = ops.PROFILE.mean_ms("vit_attn_global")
+    ops.PROFILE.disable()
+
+    if rank == 0:
+        images = args.batch * world * args.steps
+        N = (args.size // 16) ** 2
+        flops = 4.0 * N * N * cfg.vit_embed_dim * args.batch          # QK^T + PV of one global block, all heads, this batch
+        ach = flops / (kern_ms * 1e-3) / 1e12 if kern_ms else None
+        line = {
+            "metric": "images/sec @1024x1024 ViT-H bs=8 (single-image inference hot path: box, class and mask logits)",
+            "value": round(images / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"fast": "bf16", "parity": "f32+f16attn", "default": "bf16+f32head"}[args.precision],
+            "data": "synthetic (uint8-valued random images resident in HBM, synthetic BERT token ids, random-init weights)",
+            "config": {"workload": "BASELINE.json configs[2]: %s, %dx%d, batch %d per GPU, %d class prompts (L=%d), detection"
+                                   % (args.model, args.size, args.size, args.batch, n_classes, L),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "precision_policy": args.precision},
+            "roofline": {"bound": "mfma", "kernel": "flash_attn_kernel<bf16,hd80,NB2,relpos> (ViT global attention, %d launches timed)" % kern_n,
+                         "achieved": None if ach is None else round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                         "frac": None if ach is None else round(ach / 2500.0, 4), "traffic": None,
+                         "avg_launch_ms": None if not kern_ms else round(kern_ms, 4),
+                         "flop_per_launch": flops},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(cfg.to_dict(), args.size, L, n_classes)
+            except Exception as e:  # the baseline must never break the measured line
+                line["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
+        print(json.dumps(line))
+    parallel.barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -45,6 +45,9 @@ def load():
         raise HipieLibraryError(
             "libhipie_mi355.so not found at %s -- build it with `make -C hipie_amd/csrc` (hipcc, gfx950). "
             "There is no PyTorch fallback for the hand-written kernels." % LIB_PATH)
+    # PyTorch-ROCm ships its own libamdhip64 (same SONAME as /opt/rocm's).  Import torch FIRST so that this library
+    # binds to the HIP runtime instance torch has initialised: one runtime per process, shared streams and pointers.
+    import torch  # noqa: F401
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # missing libamdhip64 etc.

@@ -34,9 +34,12 @@ class PConv2d(nn.Conv2d):
 
 
 def cast_head(module, dtype):
+    """put the GEMM/conv weights (only) of the policy-aware layers in ``dtype``; norms and embeddings stay fp32."""
     for m in module.modules():
         if isinstance(m, (PLinear, PConv2d, nn.ConvTranspose2d)):
-            m.to(dtype)
+            m.weight.data = m.weight.data.to(dtype)
+            if m.bias is not None:
+                m.bias.data = m.bias.data.to(dtype)
     return module
 
 

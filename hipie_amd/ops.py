@@ -11,6 +11,56 @@ from . import _lib
 _DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 
+class _Profile(object):
+    """Optional live timing of the hand-written kernels with HIP events recorded on the launch stream (torch's current
+    stream, the one every entry point is launched on).  Used by bench.py for the `roofline` object."""
+
+    def __init__(self):
+        self.tags, self.events = set(), {}
+
+    def enable(self, *tags):
+        self.tags, self.events = set(tags), {}
+
+    def disable(self):
+        self.tags = set()
+
+    def begin(self, tag):
+        if tag not in self.tags and "all" not in self.tags:
+            return None
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        self.events.setdefault(tag, []).append((a, b))
+        return b
+
+    def mean_ms(self, tag):
+        ev = self.events.get(tag, [])
+        if not ev:
+            return None, 0
+        torch.cuda.synchronize()
+        ts = [a.elapsed_time(b) for a, b in ev]
+        return sum(ts) / len(ts), len(ts)
+
+    def summary(self):
+        return {t: self.mean_ms(t) + (sum(a.elapsed_time(b) for a, b in self.events[t]),) for t in self.events}
+
+
+PROFILE = _Profile()
+
+
+def _timed(tag):
+    def deco(fn):
+        def wrapper(*a, **k):
+            end = PROFILE.begin(tag(*a, **k) if callable(tag) else tag) if PROFILE.tags else None
+            out = fn(*a, **k)
+            if end is not None:
+                end.record()
+            return out
+        wrapper.__doc__ = fn.__doc__
+        wrapper.__name__ = fn.__name__
+        return wrapper
+    return deco
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -43,6 +93,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return out
 
 
+@_timed("msda")
 def msda_fused(value, spatial_shapes, level_start_index, ref, offsets, logits):
     """value (B,S,M,D); ref (B,Lq,L,2|4) f32; offsets (B,Lq,M,L,P,2) f32; logits (B,Lq,M,L*P) f32 -> (B,Lq,M*D)."""
     lib = _lib.load()
@@ -86,6 +137,7 @@ def flash_attn(q, k, v, scale, bias_h=None, bias_w=None, key_mask=None, clamp=0.
     return out
 
 
+@_timed(lambda qkv, rel_h, rel_w, grid_hw, heads, scale: "vit_attn_global" if grid_hw[0] * grid_hw[1] > 256 else "vit_attn_window")
 def vit_attn(qkv, rel_h, rel_w, grid_hw, heads, scale):
     """qkv (B, gh*gw, 3*heads*hd) 16-bit packed as (3, heads, hd); rel_h (B*heads, N, gh), rel_w (B*heads, N, gw) f32
     -> (B, N, heads*hd)."""
@@ -100,6 +152,7 @@ def vit_attn(qkv, rel_h, rel_w, grid_hw, heads, scale):
     return out
 
 
+@_timed("bi_xattn")
 def bi_xattn(q, k, vv, vl, text_mask, clamp=50000.0):
     """q, vv (B,Nv,H,hd); k, vl (B,L,H,hd) 16-bit contiguous; text_mask (B,L) -> out_v (B,Nv,H*hd), out_l (B,L,H*hd)."""
     lib = _lib.load()
@@ -114,6 +167,7 @@ def bi_xattn(q, k, vv, vl, text_mask, clamp=50000.0):
     return out_v, out_l
 
 
+@_timed("mask_einsum")
 def mask_einsum(mask_embed, mask_features, precision=1, out_dtype=torch.float32):
     """einsum("bqc,bchw->bqhw"): mask_embed (B,Q,C) f32, mask_features (B,C,H,W) f32 -> (B,Q,H,W) out_dtype.
     precision 0 = exact fp32 MFMA, 1 = bf16x3 split (default; ~2^-16), 2 = plain bf16."""
@@ -128,6 +182,7 @@ def mask_einsum(mask_embed, mask_features, precision=1, out_dtype=torch.float32)
     return out
 
 
+@_timed("dynamic_mask")
 def dynamic_mask(mask_feats, ref_points, params, num_queries, stride=8, up=2, out_dtype=torch.float32):
     """mask_feats (B,8,H,W) f32; ref_points (B*Q,2) f32 pixels; params (B*Q,169) f32 -> (B*Q, up*H, up*W)."""
     lib = _lib.load()

@@ -1,0 +1,62 @@
+"""CPU, world_size 2 over gloo: the data-parallel layer (sharding, fixed-shape all-gather, max-over-ranks timing)."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from hipie_amd import parallel
+    r, w, _ = parallel.init_from_env(backend="gloo")
+    idx = list(parallel.shard_range(total, r, w))
+    n_local = (total + w - 1) // w
+    results = []
+    for i in range(n_local):
+        gi = idx[i] if i < len(idx) else -1
+        k = 3
+        results.append({"instances": {"pred_boxes": torch.full((k, 4), float(gi)), "scores": torch.full((k,), float(gi) + 0.5),
+                                      "pred_classes": torch.full((k,), gi, dtype=torch.long)}})
+    block = parallel.compact_predictions(results, topk=5)
+    out = parallel.all_gather_predictions(block)
+    t = parallel.max_over_ranks(1.0 + r, torch.device("cpu"))
+    parallel.barrier()
+    q.put((r, idx, out.tolist(), t))     # plain lists: no shared-memory handles across process exit
+
+
+def test_two_rank_shard_and_gather():
+    world, total = 2, 7
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in ps], key=lambda x: x[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0][1] == [0, 1, 2, 3] and got[1][1] == [4, 5, 6]           # contiguous ranges, first rank takes the extra
+    assert got[0][2] == got[1][2]                                          # every rank holds the full gather
+    full = torch.tensor(got[0][2])
+    assert full.shape == (8, 5, 7)
+    seen = sorted(int(v) for v in full[:, 0, 5].tolist())
+    assert seen == [-1, 0, 1, 2, 3, 4, 5, 6]                               # 7 images + one pad slot
+    assert got[0][3] == 2.0 and got[1][3] == 2.0                           # max over ranks
+
+
+def test_shard_range_covers_everything():
+    from hipie_amd.parallel import shard_range
+    for total in (0, 1, 8, 64, 65):
+        for world in (1, 2, 8):
+            allidx = [i for r in range(world) for i in shard_range(total, r, world)]
+            assert allidx == list(range(total))
