@@ -68,7 +68,9 @@ def cpu_baseline(cfg_dict, size, L, n_classes):
     from oracle import model as om
     from hipie_amd.config import HipieConfig, Precision
     from hipie_amd.hipie_img import HIPIE_IMG
-    torch.set_num_threads(os.cpu_count())
+    threads = min(os.cpu_count(), 32)       # more threads than this makes the many small fp32 ops slower, not faster
+    torch.set_num_threads(threads)
+    torch.set_grad_enabled(False)
     c = dict(cfg_dict)
     c.update(vit_depth=2, vit_window_blocks=[0])
     m = HIPIE_IMG(HipieConfig.from_dict(c), Precision.parity(), device="cpu")
@@ -92,7 +94,7 @@ def cpu_baseline(cfg_dict, size, L, n_classes):
     nwin = len(cfg_dict["vit_window_blocks"])
     nglob = cfg_dict["vit_depth"] - nwin
     s_img = t_total2 + (nwin - 1) * t_win + (nglob - 1) * t_glob
-    return {"value": round(1.0 / s_img, 5), "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
+    return {"value": round(1.0 / s_img, 5), "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": "oracle/ (fp32 PyTorch CPU restatement) on 1 image %dx%d, L=%d: full text encoder + everything after "
                       "the backbone + 1 windowed and 1 global ViT block measured (%.2fs, %.2fs), scaled to %d+%d blocks; "
                       "measured part %.1fs" % (size, size, L, t_win, t_glob, nwin, nglob, t_total2 + t_win + t_glob)}
@@ -108,7 +110,16 @@ def main():
     ap.add_argument("--model", default="vit_huge", choices=["vit_huge", "vit_large", "vit_base"])
     ap.add_argument("--precision", default="fast", choices=["fast", "parity", "default"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--breakdown", action="store_true", help="after the timed region, time every hand-written kernel class "
+                    "and the main stages of one extra step (stderr)")
     args = ap.parse_args()
+
+    if args.cpu_baseline_only:          # child process of the cpu_baseline leg (bounded by a timeout in the parent)
+        from hipie_amd.config import HipieConfig
+        cfg = getattr(HipieConfig, args.model)()
+        print("CPU_BASELINE " + json.dumps(cpu_baseline(cfg.to_dict(), args.size, 194, 80)))
+        return
 
     from hipie_amd import ops, parallel
     from hipie_amd.config import HipieConfig, Precision
@@ -151,6 +162,17 @@ def main():
     kern_ms, kern_n = ops.PROFILE.mean_ms("vit_attn_global")
     ops.PROFILE.disable()
 
+    if args.breakdown and rank == 0:
+        ops.PROFILE.enable("all")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        print("BREAKDOWN step %.1f ms" % ((time.perf_counter() - t1) * 1e3), file=sys.stderr)
+        for tag, (mean, n, tot) in sorted(ops.PROFILE.summary().items()):
+            print("BREAKDOWN %-18s n=%4d mean=%8.3f ms total=%8.2f ms" % (tag, n, mean, tot), file=sys.stderr)
+        ops.PROFILE.disable()
+
     if rank == 0:
         images = args.batch * world * args.steps
         N = (args.size // 16) ** 2
@@ -172,9 +194,17 @@ def main():
                          "flop_per_launch": flops},
         }
         if not args.no_cpu_baseline:
-            try:
-                line["cpu_baseline"] = cpu_baseline(cfg.to_dict(), args.size, L, n_classes)
-            except Exception as e:  # the baseline must never break the measured line
+            import subprocess
+            try:                        # separate process, hard time bound: the baseline must never break the measured line
+                env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+                for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                    env.pop(k, None)
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--model", args.model,
+                                    "--size", str(args.size)], capture_output=True, text=True, timeout=240, env=env)
+                tag = [l for l in r.stdout.splitlines() if l.startswith("CPU_BASELINE ")]
+                line["cpu_baseline"] = json.loads(tag[-1][len("CPU_BASELINE "):]) if tag else \
+                    {"value": None, "error": (r.stderr or r.stdout)[-300:]}
+            except Exception as e:
                 line["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
         print(json.dumps(line))
     parallel.barrier()
