@@ -41,12 +41,14 @@ struct FAParams {
   int nqt, ntiles, swz;
 };
 
-constexpr int FA_WAVES = 4;
-constexpr int FA_QT = FA_WAVES * 32;
 constexpr float kLog2e = 1.4426950408889634f;
 
-template <typename T, int HD, int NB, bool BIAS, bool USE_TR>
-__global__ __launch_bounds__(FA_WAVES * 64, (HD <= 80) ? 2 : 1) void flash_attn_kernel(const FAParams p) {
+// T: bf16_t | f16_t;  HD: head dim;  NB: 32-key blocks per tile;  QB: 32-query blocks per wave;  BIAS: decomposed rel-pos
+// bias (tile == key row);  CLAMP: clamp scale*q.k to +-clamp.
+// One wave per SIMD (4 waves, up to 512 registers each): with QB = 2 every K / V^T fragment fetched from LDS feeds two
+// MFMAs and the two query blocks give the scheduler independent MFMA and softmax streams to overlap.
+template <typename T, int HD, int NB, int QB, int WAVES, bool BIAS, bool CLAMP, bool MASKED>
+__global__ __launch_bounds__(WAVES * 64, (WAVES == 8) ? 2 : 1) void flash_attn_kernel(const FAParams p) {
   constexpr int KT = 32 * NB;                  // keys per tile
   constexpr int KS = HD / 16;                  // k16 steps of QK^T
   constexpr int DB = (HD + 31) / 32;           // 32-row d blocks of O^T
@@ -54,9 +56,11 @@ __global__ __launch_bounds__(FA_WAVES * 64, (HD <= 80) ? 2 : 1) void flash_attn_
   constexpr int VSTR = DB * 32 + 8;            // V tile row stride (covers the padded d blocks)
   constexpr int CPR = HD / 8;                  // 16-byte chunks per row
   constexpr int NCH = KT * CPR;                // chunks per tile
-  constexpr int NT = FA_WAVES * 64;
+  constexpr int NT = WAVES * 64;
   constexpr int CPT = (NCH + NT - 1) / NT;     // chunks per thread
   constexpr int BUF = KT * (KSTR + VSTR);      // elements per LDS buffer
+  constexpr int NW = (KT + 63) / 64;           // validity words per tile
+  constexpr int QPW = 32 * QB;                 // queries per wave
   typedef typename Mfma32<T>::frag frag;
   typedef typename Mfma32<T>::half_frag hfrag;
 
@@ -80,245 +84,350 @@ __global__ __launch_bounds__(FA_WAVES * 64, (HD <= 80) ? 2 : 1) void flash_attn_
   T* Og = reinterpret_cast<T*>(p.out) + b * p.o_sb + h * p.o_sh;
   const uint8_t* Mg = p.key_mask ? p.key_mask + (long)b * p.Nk : nullptr;
 
-  const int qi = qt * FA_QT + wave * 32 + li;          // this lane's query
-  const int qc = min(qi, p.Nq - 1);
+  int qi[QB], qc[QB];                          // this lane's queries
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    qi[qb] = qt * (WAVES * QPW) + wave * QPW + 32 * qb + li;
+    qc[qb] = min(qi[qb], p.Nq - 1);
+  }
 
-  // zero LDS once (pad columns of the V tile feed the padded d rows of O^T, which are discarded but must stay finite-free of traps)
+  // zero LDS once: the pad columns of the V tile feed the padded d rows of O^T (discarded, but keep them NaN-free)
   for (int i = tid; i < 2 * BUF / 8; i += NT) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
 
   // ---- Q fragments (B operand): lane (q = li, half hi) holds Q[q][16 ks + 8 hi + j] ----
-  frag qf[KS];
+  frag qf[QB][KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-    qf[ks] = *reinterpret_cast<const frag*>(Qg + (long)qc * p.q_st + 16 * ks + 8 * hi);
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      qf[qb][ks] = *reinterpret_cast<const frag*>(Qg + (long)qc[qb] * p.q_st + 16 * ks + 8 * hi);
 
-  // ---- bias_w in S^T register order ----
-  float bw[NB][16];
-  const float* bhp = nullptr;
-  if (BIAS) {
-    const float* bwp = p.bias_w + ((long)bh * p.Nq + qc) * p.kw;
+  // ---- bias_w in S^T register order, pre-multiplied by log2(e) (the softmax runs in the exp2 domain) ----
+  constexpr bool BWL = BIAS && (NB <= 2);     // bias_w rows in LDS (frees 16*NB VGPRs per query block); NB = 3 keeps registers
+  constexpr int BWS = 32 * NB + 4;            // bias_w LDS row stride (floats): 16-B aligned rows, conflict-free b128 reads
+  float bw[QB][NB][16];
+  // Inside the tile loop the ONLY vector-memory traffic is the prefetch of the next tile (K, V and the 4 x 32 x WAVES
+  // bias_h values of that key row, which arrive transposed as (BH, kh, Nq) so they are one coalesced line): no other
+  // s_waitcnt vmcnt can drain it early (vmcnt retires in order, and a loaded value carried across the loop back-edge
+  // makes the compiler wait vmcnt(0)).  bias_w rows and the key mask are staged in LDS once.
+  float* bh_lds = reinterpret_cast<float*>(smem_raw + (size_t)2 * BUF * sizeof(T));      // [2][WAVES*QPW]
+  float* bw_lds = bh_lds + 2 * WAVES * QPW;                                              // [WAVES*QPW][BWS]
+  uint8_t* mk_lds = reinterpret_cast<uint8_t*>(bw_lds + (BWL ? WAVES * QPW * BWS : 0));
 #pragma unroll
-    for (int blk = 0; blk < NB; ++blk)
+  for (int qb = 0; qb < QB; ++qb) {
+    if (BIAS && !BWL) {
+      const float* bwp = p.bias_w + ((long)bh * p.Nq + qc[qb]) * p.kw;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) bw[blk][r] = bwp[min(32 * blk + crow(r, hi), p.kw - 1)];
-    bhp = p.bias_h + ((long)bh * p.Nq + qc) * p.kh;
+      for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bw[qb][blk][r] = bwp[min(32 * blk + crow(r, hi), p.kw - 1)] * kLog2e;
+    }
+  }
+  if (BWL) {
+    for (int r = 0; r < QPW; ++r) {
+      const int q = min(qt * (WAVES * QPW) + wave * QPW + r, p.Nq - 1);
+      const float* srcw = p.bias_w + ((long)bh * p.Nq + q) * p.kw;
+      for (int j = lane; j < KT; j += 64) bw_lds[(wave * QPW + r) * BWS + j] = (j < p.kw ? srcw[j] : 0.f) * kLog2e;
+    }
+  }
+  if (MASKED && Mg != nullptr)
+    for (int i = tid; i < p.Nk; i += NT) mk_lds[i] = Mg[i];
+  // this thread's slot of the per-tile bias_h line
+  const float* bhsrc = BIAS ? p.bias_h + (long)bh * p.kh * p.Nq + min(qt * (WAVES * QPW) + tid, p.Nq - 1) : nullptr;
+  const bool bh_thread = BIAS && (tid < WAVES * QPW);
+  float bhr = 0.f;
+  const float c1 = p.scale * kLog2e;
+  const float cl2 = p.clamp * kLog2e;
+
+  // ---- tile streaming: HBM/L2 -> registers -> LDS.  Per-thread chunk coordinates are tile-invariant and hoisted; the
+  //      register arrays are native vectors indexed with compile-time constants and written unconditionally (clamped
+  //      duplicates for the tail) so that they stay in VGPRs and the loads stay in flight across the MFMA work. ----
+  int koff[CPT], voff[CPT], lk[CPT], lv[CPT], crow_[CPT];
+  bool cval[CPT];
+  const int nkeys_full = BIAS ? p.kw : KT;
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) {
+    const int idx = min(c * NT + tid, NCH - 1);
+    const int row = idx / CPR, ch = idx - row * CPR;
+    cval[c] = (c * NT + tid) < NCH;
+    crow_[c] = row;
+    const int rowc = min(row, nkeys_full - 1);             // padded rows re-read the last valid key (finite data, P = 0)
+    koff[c] = rowc * (int)p.k_st + ch * 8;
+    voff[c] = rowc * (int)p.v_st + ch * 8;
+    lk[c] = row * KSTR + ch * 8;
+    lv[c] = row * VSTR + ch * 8;
+  }
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in VGPRs (HIP's uint4 struct does not)
+  u32x4 kr[CPT], vr[CPT];
+#define FA_LOAD_REGS(t_)                                                                              \
+  {                                                                                                   \
+    const long key0_ = BIAS ? (long)(t_) * p.kw : (long)(t_) * KT;                                    \
+    const int nk_ = BIAS ? p.kw : min(KT, p.Nk - (int)key0_);                                         \
+    const T* kb_ = Kg + key0_ * p.k_st;                                                               \
+    const T* vb_ = Vg + key0_ * p.v_st;                                                               \
+    if (bh_thread) bhr = bhsrc[(long)(t_) * p.Nq];                                                    \
+    if (nk_ == nkeys_full) {                                                                          \
+      _Pragma("unroll") for (int c = 0; c < CPT; ++c) {                                               \
+        kr[c] = *reinterpret_cast<const u32x4*>(kb_ + koff[c]);                                       \
+        vr[c] = *reinterpret_cast<const u32x4*>(vb_ + voff[c]);                                       \
+      }                                                                                               \
+    } else { /* ragged last tile (no-bias mode): clamp the row per chunk */                            \
+      _Pragma("unroll") for (int c = 0; c < CPT; ++c) {                                               \
+        const int rc_ = min(crow_[c], nk_ - 1);                                                       \
+        const int ch8_ = lk[c] - crow_[c] * KSTR;                                                     \
+        kr[c] = *reinterpret_cast<const u32x4*>(kb_ + (long)rc_ * p.k_st + ch8_);                     \
+        vr[c] = *reinterpret_cast<const u32x4*>(vb_ + (long)rc_ * p.v_st + ch8_);                     \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+#define FA_STORE_LDS(buf_)                                                                            \
+  {                                                                                                   \
+    T* Ks_ = smem + (buf_) * BUF;                                                                     \
+    T* Vs_ = Ks_ + KT * KSTR;                                                                         \
+    if (bh_thread) bh_lds[(buf_) * (WAVES * QPW) + tid] = bhr * kLog2e;                                \
+    _Pragma("unroll") for (int c = 0; c < CPT; ++c) {                                                 \
+      if (cval[c]) {                                                                                  \
+        *reinterpret_cast<u32x4*>(Ks_ + lk[c]) = kr[c];                                               \
+        *reinterpret_cast<u32x4*>(Vs_ + lv[c]) = vr[c];                                               \
+      }                                                                                               \
+    }                                                                                                 \
   }
 
-  // ---- tile streaming helpers ----
-  uint4 kr[CPT], vr[CPT];
-  auto tile_geom = [&](int t, int& key0, int& nkeys) {
-    if (BIAS) { key0 = t * p.kw; nkeys = p.kw; }
-    else { key0 = t * KT; nkeys = min(KT, p.Nk - key0); }
-  };
-  auto load_regs = [&](int t) {
-    int key0, nkeys;
-    tile_geom(t, key0, nkeys);
+  // ---- online softmax state (exp2 domain) ----
+  f32x16 O[QB][DB];
+  float m_run[QB], l_run[QB];
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) {
-      const int idx = c * NT + tid;
-      if (idx < NCH) {
-        const int row = idx / CPR, ch = idx - row * CPR;
-        const long key = key0 + min(row, nkeys - 1);      // padded rows re-read the last valid key (finite data, P = 0)
-        kr[c] = *reinterpret_cast<const uint4*>(Kg + key * p.k_st + ch * 8);
-        vr[c] = *reinterpret_cast<const uint4*>(Vg + key * p.v_st + ch * 8);
-      }
-    }
-  };
-  auto store_lds = [&](int buf) {
-    T* Ks = smem + buf * BUF;
-    T* Vs = Ks + KT * KSTR;
+  for (int qb = 0; qb < QB; ++qb) {
+    m_run[qb] = -INFINITY;
+    l_run[qb] = 0.f;
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) {
-      const int idx = c * NT + tid;
-      if (idx < NCH) {
-        const int row = idx / CPR, ch = idx - row * CPR;
-        *reinterpret_cast<uint4*>(Ks + row * KSTR + ch * 8) = kr[c];
-        *reinterpret_cast<uint4*>(Vs + row * VSTR + ch * 8) = vr[c];
-      }
-    }
-  };
-
-  // ---- online softmax state ----
-  f32x16 O[DB];
+    for (int d = 0; d < DB; ++d)
 #pragma unroll
-  for (int d = 0; d < DB; ++d)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) O[d][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+      for (int r = 0; r < 16; ++r) O[qb][d][r] = 0.f;
+  }
 
   const int nt = p.ntiles;
+  // MASKED is instantiated only where some key can be invalid: padded key rows (BIAS, kw % 32 != 0), a ragged last tile
+  // or a key mask.  The full-tile instantiation contains no validity code at all.
   __syncthreads();                 // LDS zero fill done
-  load_regs(0);
-  store_lds(0);
+  FA_LOAD_REGS(0);
+  FA_STORE_LDS(0);
   __syncthreads();
-  if (nt > 1) load_regs(1);
-  float bh_next = BIAS ? bhp[0] : 0.f;
+  if (nt > 1) FA_LOAD_REGS(1);
+  const int l16 = lane & 15, g1 = (lane >> 4) & 1;
 
   for (int t = 0; t < nt; ++t) {
     const T* Ks = smem + (t & 1) * BUF;
     const T* Vs = Ks + KT * KSTR;
-    int key0, nkeys;
-    tile_geom(t, key0, nkeys);
-    const float bh_t = bh_next;
-    if (BIAS && t + 1 < nt) bh_next = bhp[t + 1];
-
-    // validity words: bit i of word w <=> key (64 w + i) of this tile is attended to
-    unsigned long long vw[(KT + 63) / 64];
+    const int key0 = BIAS ? t * p.kw : t * KT;
+    const int nkeys = BIAS ? p.kw : min(KT, p.Nk - key0);
+    float bh_t[QB];
 #pragma unroll
-    for (int w = 0; w < (KT + 63) / 64; ++w) {
-      const int kk = 64 * w + lane;
-      bool ok = kk < nkeys;
-      if (Mg != nullptr && ok) ok = Mg[key0 + kk] != 0;
-      vw[w] = __ballot(ok);
+    for (int qb = 0; qb < QB; ++qb) {
+      bh_t[qb] = BIAS ? bh_lds[(t & 1) * (WAVES * QPW) + wave * QPW + 32 * qb + li] : 0.f;
     }
 
-    // ---- S^T = K . Q^T ----
-    f32x16 S[NB];
+    // ---- S^T = K . Q^T  (each K fragment feeds QB MFMAs) ----
+    f32x16 S[QB][NB];
 #pragma unroll
-    for (int blk = 0; blk < NB; ++blk)
+    for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) S[blk][r] = 0.f;
+      for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+        for (int r = 0; r < 16; ++r) S[qb][blk][r] = 0.f;
+    {
+      const T* kbase = Ks + li * KSTR + 8 * hi;
+      frag kcur[NB], knxt[NB];
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk) kcur[blk] = *reinterpret_cast<const frag*>(kbase + 32 * blk * KSTR);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) {
+#pragma unroll
+          for (int blk = 0; blk < NB; ++blk) knxt[blk] = *reinterpret_cast<const frag*>(kbase + 32 * blk * KSTR + 16 * (ks + 1));
+        }
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) S[qb][blk] = Mfma32<T>::mma(kcur[blk], qf[qb][ks], S[qb][blk]);
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) kcur[blk] = knxt[blk];
+      }
+    }
+
+    unsigned long long vw[NW];
+    if (MASKED) {
+      // validity words: bit i of word w <=> key (64 w + i) of this tile is attended to
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const int kk = 64 * w + lane;
+        bool ok = kk < nkeys;
+        if (Mg != nullptr && ok) ok = mk_lds[key0 + kk] != 0;
+        vw[w] = __ballot(ok);
+      }
+    }
+
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      // ---- s' = log2e * (clamp(scale * qk) + bias_w); the tile-constant bias_h is folded into the exponent offset ----
 #pragma unroll
       for (int blk = 0; blk < NB; ++blk) {
-        const frag kf = *reinterpret_cast<const frag*>(Ks + (32 * blk + li) * KSTR + 16 * ks + 8 * hi);
-        S[blk] = Mfma32<T>::mma(kf, qf[ks], S[blk]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+          if (BWL) b4 = *reinterpret_cast<const f32x4*>(bw_lds + (wave * QPW + 32 * qb + li) * BWS + 32 * blk + 8 * g + 4 * hi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            float s = S[qb][blk][r] * c1;
+            if (CLAMP) s = fminf(fmaxf(s, -cl2), cl2);
+            if (BIAS) s += BWL ? b4[e] : bw[qb][blk][r];
+            S[qb][blk][r] = s;
+          }
+        }
+      }
+      if (MASKED) {
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kk = 32 * blk + crow(r, hi);
+            const bool ok = (vw[kk >> 6] >> (kk & 63)) & 1ull;
+            S[qb][blk][r] = ok ? S[qb][blk][r] : -INFINITY;
+          }
+        }
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[qb][blk][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32)) + bh_t[qb];
+      const float m_new = fmaxf(m_run[qb], mx);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;          // all keys so far masked: keep exp2() finite
+      const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_use);   // m_run = -inf -> 0
+      const float off = bh_t[qb] - m_use;
+      m_run[qb] = m_new;
+      float lsum = 0.f;
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(S[qb][blk][r] + off);
+          S[qb][blk][r] = pv;
+          lsum += pv;
+        }
+      l_run[qb] = l_run[qb] * alpha + lsum;
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {   // wave-uniform: no row max moved in this tile -> O stays as is
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) O[qb][d][r] *= alpha;
       }
     }
 
-    // ---- scale, clamp, bias, mask; tile max ----
-    float mx = -INFINITY;
-#pragma unroll
-    for (int blk = 0; blk < NB; ++blk) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kk = 32 * blk + crow(r, hi);
-        float s = S[blk][r] * p.scale;
-        if (p.clamp > 0.f) s = fminf(fmaxf(s, -p.clamp), p.clamp);
-        if (BIAS) s += bh_t + bw[blk][r];
-        const bool ok = (vw[kk >> 6] >> (kk & 63)) & 1ull;
-        s = ok ? s : -INFINITY;
-        S[blk][r] = s;
-        mx = fmaxf(mx, s);
-      }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;      // all keys so far masked: keep exp() finite
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * kLog2e);   // m_run = -inf -> 0
-    m_run = m_new;
-    float lsum = 0.f;
-#pragma unroll
-    for (int blk = 0; blk < NB; ++blk)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f((S[blk][r] - m_use) * kLog2e);
-        S[blk][r] = pv;
-        lsum += pv;
-      }
-    l_run = l_run * alpha + lsum;
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) O[d][r] *= alpha;
-
-    // ---- O^T += V^T . P^T ----
+    // ---- O^T += V^T . P^T  (each V^T fragment feeds QB MFMAs) ----
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        frag pf;
+        frag pf[QB];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = (T)S[blk][8 * s + j];
-        // keys of this lane-half for k slots j = 0..3 and 4..7
-        const int krow0 = 32 * blk + 16 * s + 4 * hi;
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[qb][j] = (T)S[qb][blk][8 * s + j];
+        const int krow0 = 32 * blk + 16 * s + 4 * hi;      // keys of this lane-half for k slots 0..3 (and +8 for 4..7)
 #pragma unroll
         for (int d = 0; d < DB; ++d) {
+          const T* a0 = Vs + (krow0 + (l16 >> 2)) * VSTR + 32 * d + 16 * g1 + 4 * (l16 & 3);
+          const hfrag lo = Mfma32<T>::tr_read(a0);
+          const hfrag hi4 = Mfma32<T>::tr_read(a0 + 8 * VSTR);
           frag vf;
-          if (USE_TR) {
-            const int l16 = lane & 15, g1 = (lane >> 4) & 1;
-            const T* a0 = Vs + (krow0 + (l16 >> 2)) * VSTR + 32 * d + 16 * g1 + 4 * (l16 & 3);
-            const hfrag lo = Mfma32<T>::tr_read(a0);
-            const hfrag hi4 = Mfma32<T>::tr_read(a0 + 8 * VSTR);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi4[j]; }
-          } else {
+          for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi4[j]; }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) vf[j] = Vs[(krow0 + (j & 3) + 8 * (j >> 2)) * VSTR + 32 * d + li];
-          }
-          O[d] = Mfma32<T>::mma(vf, pf, O[d]);
+          for (int qb = 0; qb < QB; ++qb) O[qb][d] = Mfma32<T>::mma(vf, pf[qb], O[qb][d]);
         }
       }
     }
 
-    if (t + 1 < nt) store_lds((t + 1) & 1);
+    if (t + 1 < nt) FA_STORE_LDS((t + 1) & 1);
     __syncthreads();
-    if (t + 2 < nt) load_regs(t + 2);
+    if (t + 2 < nt) FA_LOAD_REGS(t + 2);
   }
 
   // ---- epilogue ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.f / l_tot;
-  if (qi < p.Nq) {
-    T* orow = Og + (long)qi * p.o_st;
 #pragma unroll
-    for (int d = 0; d < DB; ++d) {
+  for (int qb = 0; qb < QB; ++qb) {
+    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
+    const float inv = 1.f / l_tot;
+    if (qi[qb] < p.Nq) {
+      T* orow = Og + (long)qi[qb] * p.o_st;
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int d0 = 32 * d + 8 * rr + 4 * hi;           // rows crow(4 rr + (0..3), hi) of block d
-        if (d0 < HD) {
-          typedef T t4 __attribute__((ext_vector_type(4)));
-          t4 o4;
+      for (int d = 0; d < DB; ++d) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o4[e] = (T)(O[d][4 * rr + e] * inv);
-          *reinterpret_cast<t4*>(orow + d0) = o4;
+        for (int rr = 0; rr < 4; ++rr) {
+          const int d0 = 32 * d + 8 * rr + 4 * hi;           // rows crow(4 rr + (0..3), hi) of block d
+          if (d0 < HD) {
+            typedef T t4 __attribute__((ext_vector_type(4)));
+            t4 o4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o4[e] = (T)(O[qb][d][4 * rr + e] * inv);
+            *reinterpret_cast<t4*>(orow + d0) = o4;
+          }
         }
       }
     }
   }
 }
+#undef FA_LOAD_REGS
+#undef FA_STORE_LDS
 
-template <typename T, int HD, int NB, bool BIAS>
-static int launch_fa(const FAParams& p, hipStream_t st, bool use_tr) {
+template <typename T, int HD, int NB, int QB, int WAVES, bool BIAS, bool CLAMP, bool MASKED>
+static int launch_fa(FAParams& p, hipStream_t st) {
   constexpr int KT = 32 * NB, DB = (HD + 31) / 32;
-  constexpr size_t lds = (size_t)2 * KT * ((HD + 8) + (DB * 32 + 8)) * sizeof(T);
+  size_t lds = (size_t)2 * KT * ((HD + 8) + (DB * 32 + 8)) * sizeof(T);
+  lds += (size_t)2 * WAVES * 32 * QB * sizeof(float);
+  if (BIAS && NB <= 2) lds += (size_t)WAVES * 32 * QB * (32 * NB + 4) * sizeof(float);
+  if (MASKED && p.key_mask != nullptr) lds += ((size_t)p.Nk + 15) / 16 * 16;
+  if (lds > 160 * 1024) return set_err(HIPIE_EINVAL, "flash_attn: %zu bytes of LDS needed (Nk=%d) > 160 KiB", lds, p.Nk);
+  p.nqt = (p.Nq + WAVES * 32 * QB - 1) / (WAVES * 32 * QB);
+  p.ntiles = BIAS ? p.kh : (p.Nk + KT - 1) / KT;
   const unsigned grid = (unsigned)(p.nqt * p.B * p.H);
-  if (use_tr) {
-    auto kern = flash_attn_kernel<T, HD, NB, BIAS, true>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(FA_WAVES * 64), lds, st, p);
-  } else {
-    auto kern = flash_attn_kernel<T, HD, NB, BIAS, false>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(FA_WAVES * 64), lds, st, p);
-  }
+  auto kern = flash_attn_kernel<T, HD, NB, QB, WAVES, BIAS, CLAMP, MASKED>;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st, p);
   return check_launch("flash_attn");
 }
 
-template <typename T, int HD>
-static int dispatch_nb(FAParams& p, hipStream_t st, bool use_tr) {
+// NBN: key blocks per tile without bias (smaller for the wide head); W: waves per workgroup for the large-Nq case
+template <typename T, int HD, int NBN, int W>
+static int dispatch_nb(FAParams& p, hipStream_t st, bool wide) {
   if (p.bias_h != nullptr) {
     const int nb = (p.kw + 31) / 32;
-    p.ntiles = p.kh;
+    const bool full = (p.kw % 32) == 0;
     switch (nb) {
-      case 1: return launch_fa<T, HD, 1, true>(p, st, use_tr);
-      case 2: return launch_fa<T, HD, 2, true>(p, st, use_tr);
-      case 3: return launch_fa<T, HD, 3, true>(p, st, use_tr);
+      case 1: return full ? launch_fa<T, HD, 1, 1, 4, true, false, false>(p, st) : launch_fa<T, HD, 1, 1, 4, true, false, true>(p, st);
+      case 2:
+        if (wide) return full ? launch_fa<T, HD, 2, 1, W, true, false, false>(p, st) : launch_fa<T, HD, 2, 1, W, true, false, true>(p, st);
+        return full ? launch_fa<T, HD, 2, 1, 4, true, false, false>(p, st) : launch_fa<T, HD, 2, 1, 4, true, false, true>(p, st);
+      case 3: return full ? launch_fa<T, HD, 3, 1, 4, true, false, false>(p, st) : launch_fa<T, HD, 3, 1, 4, true, false, true>(p, st);
       default: return set_err(HIPIE_EINVAL, "flash_attn: kw=%d > 96 unsupported with rel-pos bias", p.kw);
     }
   }
-  p.ntiles = (p.Nk + 63) / 64;
-  return launch_fa<T, HD, 2, false>(p, st, use_tr);
+  const bool masked = (p.key_mask != nullptr) || (p.Nk % (32 * NBN) != 0);
+  if (p.clamp > 0.f)
+    return masked ? launch_fa<T, HD, NBN, 1, 4, false, true, true>(p, st) : launch_fa<T, HD, NBN, 1, 4, false, true, false>(p, st);
+  return masked ? launch_fa<T, HD, NBN, 1, 4, false, false, true>(p, st) : launch_fa<T, HD, NBN, 1, 4, false, false, false>(p, st);
 }
 
 template <typename T>
-static int dispatch_hd(FAParams& p, int hd, hipStream_t st, bool use_tr) {
+static int dispatch_hd(FAParams& p, int hd, hipStream_t st, bool wide) {
   switch (hd) {
-    case 32: return dispatch_nb<T, 32>(p, st, use_tr);
-    case 64: return dispatch_nb<T, 64>(p, st, use_tr);
-    case 80: return dispatch_nb<T, 80>(p, st, use_tr);
-    case 256: return dispatch_nb<T, 256>(p, st, use_tr);
+    case 32: return dispatch_nb<T, 32, 2, 4>(p, st, false);
+    case 64: return dispatch_nb<T, 64, 2, 8>(p, st, wide);
+    case 80: return dispatch_nb<T, 80, 2, 8>(p, st, wide);
+    case 256: return dispatch_nb<T, 256, 1, 4>(p, st, false);
     default: return set_err(HIPIE_EINVAL, "flash_attn: head_dim %d unsupported (32, 64, 80, 256)", hd);
   }
 }
@@ -331,14 +440,15 @@ static int flash_attn_impl(FAParams p, int hd, int dtype, void* stream) {
   const long strides[] = {p.q_sb, p.q_st, p.q_sh, p.k_sb, p.k_st, p.k_sh, p.v_sb, p.v_st, p.v_sh, p.o_sb, p.o_st, p.o_sh};
   for (long s : strides) HIPIE_REQUIRE(s % 8 == 0, "flash_attn: strides must be multiples of 8 elements (16 bytes), got %ld", s);
   HIPIE_REQUIRE((((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v | (uintptr_t)p.out) & 15) == 0, "flash_attn: pointers must be 16-byte aligned");
-  p.nqt = (p.Nq + FA_QT - 1) / FA_QT;
   p.swz = ((p.B * p.H) % 8 == 0) ? 1 : 0;
-  const char* e = getenv("HIPIE_FA_NO_TR");
-  const bool use_tr = !(e && e[0] == '1');
+  // 8 waves (256 queries) per workgroup halve the K/V traffic per query; worth it once there are enough queries
+  bool wide = p.Nq >= 1024;
+  const char* e = getenv("HIPIE_FA_WAVES");
+  if (e && (e[0] == '4' || e[0] == '8')) wide = (e[0] == '8');
   hipStream_t st = (hipStream_t)stream;
   switch (dtype) {
-    case HIPIE_F16: return dispatch_hd<f16_t>(p, hd, st, use_tr);
-    case HIPIE_BF16: return dispatch_hd<bf16_t>(p, hd, st, use_tr);
+    case HIPIE_F16: return dispatch_hd<f16_t>(p, hd, st, wide);
+    case HIPIE_BF16: return dispatch_hd<bf16_t>(p, hd, st, wide);
     default: return set_err(HIPIE_EINVAL, "flash_attn: dtype must be HIPIE_F16 or HIPIE_BF16 (got %d)", dtype);
   }
 }

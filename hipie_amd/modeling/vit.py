@@ -93,7 +93,7 @@ class Attention(nn.Module):
         rq = qkv[:, :, :C].reshape(B, H, W, nh, hd).float()
         Rh = get_rel_pos(H, H, self.rel_pos_h.float())
         Rw = get_rel_pos(W, W, self.rel_pos_w.float())
-        rel_h = torch.einsum("bhwnc,hkc->bnhwk", rq, Rh).reshape(B * nh, H * W, H)
+        rel_h = torch.einsum("bhwnc,hkc->bnkhw", rq, Rh).reshape(B * nh, H, H * W)      # key-row major (see hipie_vit_attn)
         rel_w = torch.einsum("bhwnc,wkc->bnhwk", rq, Rw).reshape(B * nh, H * W, W)
         qkv16 = qkv.to(self.precision.attn)
         o = ops.vit_attn(qkv16.contiguous(), rel_h.contiguous(), rel_w.contiguous(), (H, W), nh, self.scale)

@@ -111,7 +111,7 @@ def msda_fused(value, spatial_shapes, level_start_index, ref, offsets, logits):
 
 def flash_attn(q, k, v, scale, bias_h=None, bias_w=None, key_mask=None, clamp=0.0):
     """q (B,Nq,H,hd), k,v (B,Nk,H,hd) 16-bit (may be strided views with hd contiguous) -> (B,Nq,H*hd).
-    bias_h (B*H,Nq,kh) / bias_w (B*H,Nq,kw) f32 decomposed rel-pos bias; key_mask (B,Nk) uint8/bool."""
+    bias_h (B*H,kh,Nq) / bias_w (B*H,Nq,kw) f32 decomposed rel-pos bias; key_mask (B,Nk) uint8/bool."""
     lib = _lib.load()
     B, Nq, H, hd = q.shape
     Nk = k.shape[1]
@@ -124,7 +124,7 @@ def flash_attn(q, k, v, scale, bias_h=None, bias_w=None, key_mask=None, clamp=0.
     kh = kw = 0
     bhp = bwp = mp = None
     if bias_h is not None:
-        kh, kw = bias_h.shape[-1], bias_w.shape[-1]
+        kh, kw = bias_h.shape[-2], bias_w.shape[-1]
         bhp, bwp = _chk(bias_h, "bias_h", torch.float32), _chk(bias_w, "bias_w", torch.float32)
     if key_mask is not None:
         key_mask = key_mask.to(torch.uint8).contiguous()
@@ -139,8 +139,8 @@ def flash_attn(q, k, v, scale, bias_h=None, bias_w=None, key_mask=None, clamp=0.
 
 @_timed(lambda qkv, rel_h, rel_w, grid_hw, heads, scale: "vit_attn_global" if grid_hw[0] * grid_hw[1] > 256 else "vit_attn_window")
 def vit_attn(qkv, rel_h, rel_w, grid_hw, heads, scale):
-    """qkv (B, gh*gw, 3*heads*hd) 16-bit packed as (3, heads, hd); rel_h (B*heads, N, gh), rel_w (B*heads, N, gw) f32
-    -> (B, N, heads*hd)."""
+    """qkv (B, gh*gw, 3*heads*hd) 16-bit packed as (3, heads, hd); rel_h (B*heads, gh, N) f32 (key-row major),
+    rel_w (B*heads, N, gw) f32 -> (B, N, heads*hd)."""
     lib = _lib.load()
     gh, gw = grid_hw
     B, N, C3 = qkv.shape

@@ -69,13 +69,14 @@ int hipie_msda_fused_forward(const void* value, const int64_t* spatial_shapes, c
 
 /*
  * Fused (flash-style) attention core shared by the ViT blocks and the VL fusion:
- *     out[b,i,h,:] = softmax_j( clamp(scale * q[b,i,h,:].k[b,j,h,:], +-clamp) + bias_h[bh,i,j / kw] + bias_w[bh,i,j % kw]
+ *     out[b,i,h,:] = softmax_j( clamp(scale * q[b,i,h,:].k[b,j,h,:], +-clamp) + bias_h[bh,j / kw,i] + bias_w[bh,i,j % kw]
  *                               + (key_mask[b,j] ? 0 : -inf) ) . v[b,j,h,:]
  * with fp32 scores / softmax / accumulation, 16-bit MFMA operands, nothing of size Nq x Nk in HBM.
  * q,k,v,out are addressed with explicit element strides (batch, token, head); head_dim contiguous.
  *   dtype      HIPIE_F16 or HIPIE_BF16 (q, k, v, out)
  *   head_dim   80 (ViT-H), 64 (ViT-B/L), 256 (VL fusion), 32
- *   bias_h     (B*H, Nq, kh) f32 or NULL;  bias_w (B*H, Nq, kw) f32 or NULL  (both or none; needs Nk == kh*kw)
+ *   bias_h     (B*H, kh, Nq) f32 (key-row major: one coalesced line per key row) or NULL;  bias_w (B*H, Nq, kw) f32 or
+ *              NULL  (both or none; needs Nk == kh*kw)
  *   key_mask   (B, Nk) uint8 (1 = keep) or NULL
  *   clamp      <= 0 disables the clamp
  * Replaces: Attention.forward's (q*scale)@k^T -> add_decomposed_rel_pos -> softmax -> @v (backbone/vit.py:72-80,
@@ -93,7 +94,8 @@ int hipie_flash_attn(const void* q, const void* k, const void* v, void* out,
  * ViT attention with decomposed relative position bias on a packed qkv tensor.
  * Replaces: Attention.forward between the qkv and proj Linears (backbone/vit.py:69-80) for both the 14x14 windowed
  * blocks (x already window-partitioned, B = batch*windows, gh=gw=14) and the global blocks (gh x gw token grid).
- *   qkv    (B, gh*gw, 3, heads, hd) 16-bit;  rel_h (B*heads, gh*gw, gh) f32 = q.Rh[hq,hk];  rel_w (.., gw) = q.Rw[wq,wk]
+ *   qkv    (B, gh*gw, 3, heads, hd) 16-bit;  rel_h (B*heads, gh, gh*gw) f32 = q.Rh[hq,hk] (key row major);
+ *          rel_w (B*heads, gh*gw, gw) f32 = q.Rw[wq,wk]
  *   out    (B, gh*gw, heads*hd) 16-bit
  */
 int hipie_vit_attn(const void* qkv, const float* rel_h, const float* rel_w, void* out,

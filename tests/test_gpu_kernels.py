@@ -152,7 +152,7 @@ def test_vit_attention(name, dt, tol_same, tol_gold):
     Rh = oo.get_rel_pos(H, H, sd["rel_pos_h"])
     Rw = oo.get_rel_pos(W, W, sd["rel_pos_w"])
     rq = q.reshape(B * heads, H, W, hd)
-    rel_h = torch.einsum("bhwc,hkc->bhwk", rq, Rh).reshape(B * heads, H * W, H).contiguous()
+    rel_h = torch.einsum("bhwc,hkc->bkhw", rq, Rh).reshape(B * heads, H, H * W).contiguous()       # key-row major
     rel_w = torch.einsum("bhwc,wkc->bhwk", rq, Rw).reshape(B * heads, H * W, W).contiguous()
     got = ops.vit_attn(qkv.to(DEV), rel_h.to(DEV), rel_w.to(DEV), (H, W), heads, hd ** -0.5).float().cpu()
     want = oo.vit_attention_core(q, k, v, sd["rel_pos_h"], sd["rel_pos_w"], (H, W), hd ** -0.5)
@@ -191,21 +191,21 @@ def test_bi_xattn(name, dt, tol):
     assert rel_err(ol.float().cpu(), wl) < tol
 
 
-def test_flash_attn_no_tr_path_agrees():
-    """the plain-LDS-read V fetch (HIPIE_FA_NO_TR=1) and the ds_read_b64_tr_b16 fetch give the same result."""
+@pytest.mark.parametrize("hd,nq,nk", [(80, 200, 333), (64, 1500, 640), (32, 77, 64), (256, 130, 100)])
+def test_flash_attn_generic(hd, nq, nk):
+    """hipie_flash_attn without bias: ragged tails, every head dim, strided q/k/v views, both workgroup shapes."""
     import os
     from hipie_amd import ops
     gen = torch.Generator().manual_seed(9)
-    q = torch.randn(2, 200, 4, 80, generator=gen).half().to(DEV)
-    k = torch.randn(2, 333, 4, 80, generator=gen).half().to(DEV)
-    v = torch.randn(2, 333, 4, 80, generator=gen).half().to(DEV)
-    a = ops.flash_attn(q, k, v, 80 ** -0.5)
-    os.environ["HIPIE_FA_NO_TR"] = "1"
+    qkv = torch.randn(2, max(nq, nk), 3, 4, hd, generator=gen).half().to(DEV)
+    q, k, v = qkv[:, :nq, 0], qkv[:, :nk, 1], qkv[:, :nk, 2]            # strided views, head_dim contiguous
+    a = ops.flash_attn(q, k, v, hd ** -0.5)
+    os.environ["HIPIE_FA_WAVES"] = "4"
     try:
-        b = ops.flash_attn(q, k, v, 80 ** -0.5)
+        b = ops.flash_attn(q, k, v, hd ** -0.5)
     finally:
-        del os.environ["HIPIE_FA_NO_TR"]
+        del os.environ["HIPIE_FA_WAVES"]
     assert rel_err(a.float().cpu(), b.float().cpu()) < 1e-6
     ref = torch.nn.functional.scaled_dot_product_attention(q.float().cpu().transpose(1, 2), k.float().cpu().transpose(1, 2),
-                                                           v.float().cpu().transpose(1, 2)).transpose(1, 2).reshape(2, 200, 320)
+                                                           v.float().cpu().transpose(1, 2)).transpose(1, 2).reshape(2, nq, 4 * hd)
     assert rel_err(a.float().cpu(), ref) < 1e-3
