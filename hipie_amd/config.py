@@ -19,21 +19,24 @@ class Precision:
     head      dtype of the linears/convs after the backbone (the reference runs them in fp32)
     value     dtype of the MSDeformAttn value tensor (fp32 as the reference, or 16-bit to halve the gather traffic)
     einsum    hipie_mask_einsum precision (0 exact fp32 MFMA, 1 bf16x3, 2 bf16)
+    act       storage dtype of the residual streams / activations between kernels (fp32, or bf16 to halve the
+              elementwise traffic and drop the cast kernels; statistics of LayerNorm / softmax stay fp32 either way)
     """
     gemm: torch.dtype = torch.bfloat16
     attn: torch.dtype = torch.bfloat16
     head: torch.dtype = torch.float32
     value: torch.dtype = torch.float32
     einsum: int = 1
+    act: torch.dtype = torch.float32
 
     @staticmethod
     def parity():
         """closest to the reference's fp32 eval arithmetic: only the attention operands are 16 bit (fp16)."""
-        return Precision(torch.float32, torch.float16, torch.float32, torch.float32, 0)
+        return Precision(torch.float32, torch.float16, torch.float32, torch.float32, 0, torch.float32)
 
     @staticmethod
     def fast():
-        return Precision(torch.bfloat16, torch.bfloat16, torch.bfloat16, torch.bfloat16, 1)
+        return Precision(torch.bfloat16, torch.bfloat16, torch.bfloat16, torch.bfloat16, 1, torch.bfloat16)
 
 
 @dataclass

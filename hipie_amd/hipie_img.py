@@ -87,10 +87,13 @@ class HIPIE_IMG(nn.Module):
         bb = self.detr.detr.backbone[0].backbone
         if hasattr(bb, "cast_weights"):
             bb.cast_weights()
-        cast_head(self.detr.detr.transformer, self.precision.head)
-        cast_head(self.detr.detr.input_proj, self.precision.head)
-        cast_head(self.detr.mask_dino, self.precision.head)
-        cast_head(self.detr.mask_head, self.precision.head)
+        hd, ad = self.precision.head, self.precision.act
+        cast_head(self.detr.detr.transformer.encoder, hd, ad)        # the Nv-token streams (21760 tokens / image)
+        cast_head(self.detr.detr.transformer.decoder.layers, hd)     # query-sized tensors stay fp32
+        cast_head(self.detr.detr.input_proj, hd, ad)
+        cast_head(self.detr.mask_dino.pixel_decoder, hd, ad)
+        cast_head(self.detr.mask_dino.predictor.decoder.layers, hd)
+        cast_head(self.detr.mask_head, hd, ad)
         return self
 
     # ---- hipie_img.py:880-898 -------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from .transformer import (MLP, DeformableTransformerDecoderLayer, DeformableTransformerEncoderLayer, FeatureResizer,
-                          PConv2d, PLinear, PositionEmbeddingSine, _get_clones, encoder_reference_points,
+                          PConv2d, PGroupNorm, PLayerNorm, PLinear, PositionEmbeddingSine, _get_clones, encoder_reference_points,
                           gen_encoder_output_proposals, get_sine_pos_embed, inverse_sigmoid)
 
 
@@ -21,7 +21,7 @@ class NormConv2d(PConv2d):
 
     def __init__(self, cin, cout, k, padding=0, relu=False):
         super().__init__(cin, cout, kernel_size=k, padding=padding, bias=False)
-        self.norm = nn.GroupNorm(32, cout)
+        self.norm = PGroupNorm(32, cout)
         self.relu = relu
 
     def forward(self, x):
@@ -66,11 +66,11 @@ class MaskDINOEncoder(nn.Module):
         cd = cfg.md_conv_dim
         # input_proj[0..2] act on reversed transformer_in_features = [res3, res4, res5]; [3] = stride-2 conv on res5
         self.input_proj = nn.ModuleList(
-            [nn.Sequential(PConv2d(c, cd, kernel_size=1), nn.GroupNorm(32, cd)) for c in in_channels] +
-            [nn.Sequential(PConv2d(max(in_channels), cd, kernel_size=3, stride=2, padding=1), nn.GroupNorm(32, cd))])
+            [nn.Sequential(PConv2d(c, cd, kernel_size=1), PGroupNorm(32, cd)) for c in in_channels] +
+            [nn.Sequential(PConv2d(max(in_channels), cd, kernel_size=3, stride=2, padding=1), PGroupNorm(32, cd))])
         self.transformer = MSDeformAttnTransformerEncoderOnly(cd, 8, cfg.md_enc_layers, cfg.md_enc_dim_feedforward, 4, precision.value)
         self.pe_layer = PositionEmbeddingSine(cd // 2, offset=0.0)
-        self.mask_features = nn.Sequential(nn.ConvTranspose2d(cd, cd, 2, stride=2), nn.GroupNorm(32, cd), nn.ReLU(),
+        self.mask_features = nn.Sequential(nn.ConvTranspose2d(cd, cd, 2, stride=2), PGroupNorm(32, cd), nn.ReLU(),
                                            PConv2d(cd, cfg.md_mask_dim, kernel_size=1))
         self.adapter_1 = NormConv2d(in_channels[0], cd, 1)
         self.layer_1 = NormConv2d(cd, cd, 3, padding=1, relu=True)
@@ -114,11 +114,11 @@ class MaskDINODecoder(nn.Module):
         d = cfg.hidden_dim
         self.num_queries, self.num_layers, self.hidden_dim = cfg.md_num_queries, cfg.md_dec_layers, d
         self.enc_output = PLinear(d, d)
-        self.enc_output_norm = nn.LayerNorm(d)
+        self.enc_output_norm = PLayerNorm(d)
         self.class_embed = PLinear(d, d)                     # num_classes = hidden_dim (ddetrs_dn.py:183-185)
         self.resizer = FeatureResizer(768, d)                # dynamic_label_enc (training only; kept for the state_dict)
         self.mask_embed = MLP(d, d, cfg.md_mask_dim, 3)
-        self.decoder_norm = nn.LayerNorm(d)
+        self.decoder_norm = PLayerNorm(d)
         layer = DeformableTransformerDecoderLayer(d, cfg.md_dim_feedforward, 4, 8, 4, precision.value)
         self.decoder = TransformerDecoder(layer, self.num_layers, self.decoder_norm, d)
         self._bbox_embed = MLP(d, d, 4, 3)

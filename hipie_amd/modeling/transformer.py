@@ -22,24 +22,43 @@ from .. import ops
 
 # --------------------------------------------------------------------------- policy-aware primitives
 class PLinear(nn.Linear):
-    """nn.Linear whose GEMM runs in the weight's dtype; input is cast in, output returned as fp32."""
+    """nn.Linear whose GEMM runs in the weight's dtype; input is cast in, output returned in ``out_dtype`` (fp32 unless
+    the policy stores activations in 16 bit)."""
+    out_dtype = torch.float32
 
     def forward(self, x):
-        return F.linear(x.to(self.weight.dtype), self.weight, self.bias).float()
+        return F.linear(x.to(self.weight.dtype), self.weight, self.bias).to(self.out_dtype)
 
 
 class PConv2d(nn.Conv2d):
+    out_dtype = torch.float32
+
     def forward(self, x):
-        return self._conv_forward(x.to(self.weight.dtype), self.weight, self.bias).float()
+        return self._conv_forward(x.to(self.weight.dtype), self.weight, self.bias).to(self.out_dtype)
 
 
-def cast_head(module, dtype):
-    """put the GEMM/conv weights (only) of the policy-aware layers in ``dtype``; norms and embeddings stay fp32."""
+class PLayerNorm(nn.LayerNorm):
+    """LayerNorm on whatever activation dtype arrives (fp32 parameters, fp32 statistics inside the kernel)."""
+
+    def forward(self, x):
+        return F.layer_norm(x, self.normalized_shape, self.weight.to(x.dtype), self.bias.to(x.dtype), self.eps)
+
+
+class PGroupNorm(nn.GroupNorm):
+    def forward(self, x):
+        return F.group_norm(x, self.num_groups, self.weight.to(x.dtype), self.bias.to(x.dtype), self.eps)
+
+
+def cast_head(module, dtype, act=torch.float32):
+    """put the GEMM/conv weights (only) of the policy-aware layers in ``dtype`` and make them emit ``act``;
+    norm parameters and embeddings stay fp32."""
     for m in module.modules():
         if isinstance(m, (PLinear, PConv2d, nn.ConvTranspose2d)):
             m.weight.data = m.weight.data.to(dtype)
             if m.bias is not None:
                 m.bias.data = m.bias.data.to(dtype)
+            if isinstance(m, (PLinear, PConv2d)):
+                m.out_dtype = act
     return module
 
 
@@ -69,7 +88,7 @@ class FeatureResizer(nn.Module):
     def __init__(self, input_feat_size, output_feat_size):
         super().__init__()
         self.fc = PLinear(input_feat_size, output_feat_size)
-        self.layer_norm = nn.LayerNorm(output_feat_size, eps=1e-12)
+        self.layer_norm = PLayerNorm(output_feat_size, eps=1e-12)
 
     def forward(self, x):
         return self.layer_norm(self.fc(x))
@@ -215,7 +234,7 @@ class BiAttentionBlockForCheckpoint(nn.Module):
 
     def __init__(self, v_dim, l_dim, embed_dim, num_heads, init_values, attn_dtype):
         super().__init__()
-        self.layer_norm_v, self.layer_norm_l = nn.LayerNorm(v_dim), nn.LayerNorm(l_dim)
+        self.layer_norm_v, self.layer_norm_l = PLayerNorm(v_dim), PLayerNorm(l_dim)
         self.attn = BiMultiHeadAttention(v_dim, l_dim, embed_dim, num_heads, attn_dtype)
         self.gamma_v = nn.Parameter(init_values * torch.ones(v_dim))
         self.gamma_l = nn.Parameter(init_values * torch.ones(l_dim))
@@ -246,9 +265,9 @@ class DeformableTransformerEncoderLayer(nn.Module):
     def __init__(self, d_model, d_ffn, n_levels, n_heads, n_points, value_dtype):
         super().__init__()
         self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points, value_dtype)
-        self.norm1 = nn.LayerNorm(d_model)
+        self.norm1 = PLayerNorm(d_model)
         self.linear1, self.linear2 = PLinear(d_model, d_ffn), PLinear(d_ffn, d_model)
-        self.norm2 = nn.LayerNorm(d_model)
+        self.norm2 = PLayerNorm(d_model)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         src2 = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index, padding_mask)
@@ -320,11 +339,11 @@ class DeformableTransformerDecoderLayer(nn.Module):
     def __init__(self, d_model, d_ffn, n_levels, n_heads, n_points, value_dtype):
         super().__init__()
         self.cross_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points, value_dtype)
-        self.norm1 = nn.LayerNorm(d_model)
+        self.norm1 = PLayerNorm(d_model)
         self.self_attn = MultiheadAttention(d_model, n_heads)
-        self.norm2 = nn.LayerNorm(d_model)
+        self.norm2 = PLayerNorm(d_model)
         self.linear1, self.linear2 = PLinear(d_model, d_ffn), PLinear(d_ffn, d_model)
-        self.norm3 = nn.LayerNorm(d_model)
+        self.norm3 = PLayerNorm(d_model)
 
     def forward(self, tgt, query_pos, reference_points, src, spatial_shapes, level_start_index, src_padding_mask=None):
         qk = tgt + query_pos
@@ -432,7 +451,7 @@ class DeformableTransformerVLDINO(nn.Module):
             self.tgt_embed_bg = nn.Embedding(cfg.num_bg_queries, d)
             self.bg_query_refs = nn.Embedding(cfg.num_bg_queries, 4)
         self.enc_output = PLinear(d, d)
-        self.enc_output_norm = nn.LayerNorm(d)
+        self.enc_output_norm = PLayerNorm(d)
         self.resizer = FeatureResizer(cfg.lang_dim, d)
         self.pinned_topk = None          # test hook: indices for the discontinuous top-k (SURVEY 7 hard part (c))
         self.last_topk = None
@@ -500,10 +519,10 @@ class Still_Classifier(nn.Module):
 
 
 def input_proj_list(channels, hidden_dim, num_levels):
-    lst = [nn.Sequential(PConv2d(c, hidden_dim, kernel_size=1), nn.GroupNorm(32, hidden_dim)) for c in channels]
+    lst = [nn.Sequential(PConv2d(c, hidden_dim, kernel_size=1), PGroupNorm(32, hidden_dim)) for c in channels]
     c = channels[-1]
     for _ in range(num_levels - len(channels)):
-        lst.append(nn.Sequential(PConv2d(c, hidden_dim, kernel_size=3, stride=2, padding=1), nn.GroupNorm(32, hidden_dim)))
+        lst.append(nn.Sequential(PConv2d(c, hidden_dim, kernel_size=3, stride=2, padding=1), PGroupNorm(32, hidden_dim)))
         c = hidden_dim
     return nn.ModuleList(lst)
 

@@ -62,12 +62,20 @@ def window_unpartition(win, ws, pad_hw, hw):
 
 
 class PatchEmbed(nn.Module):
+    """hipie/backbone/utils.py:160-186.  kernel == stride, so the conv is a GEMM over unfolded patches (a library GEMM on
+    (B*h*w, 3*p*p) x (3*p*p, E) instead of a 3-input-channel convolution)."""
+
     def __init__(self, kernel_size=(16, 16), stride=(16, 16), in_chans=3, embed_dim=768):
         super().__init__()
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=kernel_size, stride=stride)
+        self.patch = kernel_size[0]
 
     def forward(self, x):
-        return self.proj(x).permute(0, 2, 3, 1)
+        B, C, H, W = x.shape
+        p = self.patch
+        w = self.proj.weight
+        x = x.reshape(B, C, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(B, H // p, W // p, C * p * p)
+        return F.linear(x.to(w.dtype), w.reshape(w.shape[0], -1), self.proj.bias)
 
 
 class Attention(nn.Module):
@@ -126,10 +134,11 @@ class Block(nn.Module):
         self.precision = precision
 
     def _ln(self, norm, x):
-        return F.layer_norm(x, x.shape[-1:], norm.weight.float(), norm.bias.float(), norm.eps).to(self.precision.gemm)
+        w, b = norm.weight.to(x.dtype), norm.bias.to(x.dtype)       # statistics are fp32 inside the kernel either way
+        return F.layer_norm(x, x.shape[-1:], w, b, norm.eps).to(self.precision.gemm)
 
     def forward(self, x):
-        """x: fp32 residual stream (B,H,W,C)."""
+        """x: residual stream (B,H,W,C) in the policy's activation dtype."""
         y = self._ln(self.norm1, x)
         if self.window_size > 0:
             H, W = y.shape[1], y.shape[2]
@@ -137,8 +146,8 @@ class Block(nn.Module):
         y = self.attn(y)
         if self.window_size > 0:
             y = window_unpartition(y, self.window_size, pad_hw, (H, W))
-        x = x + y.float()
-        x = x + self.mlp(self._ln(self.norm2, x)).float()
+        x = x + y.to(x.dtype)
+        x = x + self.mlp(self._ln(self.norm2, x)).to(x.dtype)
         return x
 
 
@@ -167,13 +176,26 @@ class ViT(nn.Module):
 
     def forward(self, x):
         """x (B,3,H,W) fp32 normalised image -> {"res3","res4","res5"} NCHW fp32."""
-        gd = self.precision.gemm
-        x = self.patch_embed(x.to(gd)).float()
-        x = x + get_abs_pos(self.pos_embed.float(), True, (x.shape[1], x.shape[2]))
+        gd, ad = self.precision.gemm, self.precision.act
+        x = self.patch_embed(x).float()
+        x = (x + self._abs_pos((x.shape[1], x.shape[2]))).to(ad)
         for blk in self.blocks:
             x = blk(x)
-        xp = x.permute(0, 3, 1, 2)
-        return {"res3": self.fpn1(xp.to(gd)).float(), "res4": xp, "res5": self.fpn3(xp)}
+        # fpn1: ConvTranspose2d(k=2, s=2) == one GEMM (E -> 4 * E/2) + a pixel shuffle (vit.py:341-343)
+        B, H, W, E = x.shape
+        wt = self.fpn1[0].weight                                           # (E, E/2, 2, 2)
+        y = F.linear(x.to(wt.dtype), wt.reshape(E, -1).t()).view(B, H, W, E // 2, 2, 2)
+        res3 = y.permute(0, 3, 1, 4, 2, 5).reshape(B, E // 2, 2 * H, 2 * W).float() + self.fpn1[0].bias.float().view(1, -1, 1, 1)
+        xp = x.float().permute(0, 3, 1, 2)
+        return {"res3": res3, "res4": xp, "res5": self.fpn3(xp)}
+
+    def _abs_pos(self, hw):
+        """bicubic-resized absolute position table, cached per token grid (weights are frozen at inference)."""
+        key = (hw, self.pos_embed.data_ptr(), self.pos_embed.device)
+        if getattr(self, "_abs_pos_key", None) != key:
+            self._abs_pos_cache = get_abs_pos(self.pos_embed.float(), True, hw)
+            self._abs_pos_key = key
+        return self._abs_pos_cache
 
     def cast_weights(self):
         """put the GEMM/conv weights in the policy dtype (norms, pos tables stay fp32)."""
