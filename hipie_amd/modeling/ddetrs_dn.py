@@ -96,7 +96,11 @@ class DDETRSegmUniDN(nn.Module):
         outputs["reference_points"] = inter_references[-2, :, :, :2]
         params = self.controller(hs[lvl])                                     # (bs, nq, 169)
         bs, nq, _ = params.shape
-        scale = torch.tensor([[float(w), float(h)] for (h, w) in image_sizes], device=params.device)   # (bs, 2) = (w, h)
+        key = (tuple(image_sizes), str(params.device))
+        if getattr(self, "_scale_key", None) != key:                          # cached: no host->device copy per call
+            self._scale = torch.tensor([[float(w), float(h)] for (h, w) in image_sizes], device=params.device)   # (bs,2) = (w,h)
+            self._scale_key = key
+        scale = self._scale
         ref_px = (outputs["reference_points"] * scale[:, None, :]).reshape(bs * nq, 2)
         outputs["pred_masks"] = self.forward_mask_head(memory, spatial_shapes, ref_px, params.reshape(bs * nq, -1), bs, nq)
         outputs["pred_masks_maskdino"] = outputs_maskdino["pred_masks"]

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 from .. import ops
 from .transformer import (MLP, DeformableTransformerDecoderLayer, DeformableTransformerEncoderLayer, FeatureResizer,
                           PConv2d, PGroupNorm, PLayerNorm, PLinear, PositionEmbeddingSine, _get_clones, encoder_reference_points,
-                          gen_encoder_output_proposals, get_sine_pos_embed, inverse_sigmoid)
+                          gen_encoder_output_proposals, get_sine_pos_embed, inverse_sigmoid, level_tensors)
 
 
 class NormConv2d(PConv2d):
@@ -49,8 +49,7 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
         pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[i].view(1, 1, -1) for i, p in enumerate(pos_embeds)], 1)
         B = src.shape[0]
-        spatial_shapes = torch.as_tensor(shapes_list, dtype=torch.long, device=src.device)
-        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        spatial_shapes, level_start_index = level_tensors(shapes_list, src.device)
         valid_ratios = torch.ones(B, len(srcs), 2, device=src.device)
         refs = encoder_reference_points(shapes_list, valid_ratios, src.device)
         for layer in self.encoder.layers:
@@ -145,8 +144,7 @@ class MaskDINODecoder(nn.Module):
         src = torch.cat([t.flatten(2).transpose(1, 2) for t in xs], 1)
         B = src.shape[0]
         mask = torch.zeros(B, src.shape[1], dtype=torch.bool, device=src.device)
-        spatial_shapes = torch.as_tensor(shapes_list, dtype=torch.long, device=src.device)
-        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        spatial_shapes, level_start_index = level_tensors(shapes_list, src.device)
         vr2 = torch.ones(B, 1, nl, 4, device=src.device)
         om, prop = gen_encoder_output_proposals(src, mask, shapes_list)
         om = self.enc_output_norm(self.enc_output(om))

@@ -62,6 +62,21 @@ def cast_head(module, dtype, act=torch.float32):
     return module
 
 
+_CONST_CACHE = {}
+
+
+def level_tensors(shapes_list, device):
+    """(L,2) int64 spatial shapes + (L,) level start offsets on the device, cached per geometry: building them is a
+    host->device copy, which would otherwise happen in every MSDeformAttn call site and forbids hipGraph capture."""
+    key = (tuple(shapes_list), str(device))
+    v = _CONST_CACHE.get(key)
+    if v is None:
+        ss = torch.as_tensor(shapes_list, dtype=torch.long, device=device)
+        v = (ss, torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1])))
+        _CONST_CACHE[key] = v
+    return v
+
+
 def _get_clones(module, n):
     return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
 
@@ -193,8 +208,8 @@ class MSDeformAttn(nn.Module):
                 input_padding_mask=None):
         N, Lq, _ = query.shape
         value = self.project_value(input_flatten, input_padding_mask)
-        off = self.sampling_offsets(query).view(N, Lq, self.n_heads, self.n_levels, self.n_points, 2)
-        logits = self.attention_weights(query).view(N, Lq, self.n_heads, self.n_levels * self.n_points)
+        off = self.sampling_offsets(query).float().view(N, Lq, self.n_heads, self.n_levels, self.n_points, 2)
+        logits = self.attention_weights(query).float().view(N, Lq, self.n_heads, self.n_levels * self.n_points)
         if reference_points.shape[-1] not in (2, 4):
             raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(reference_points.shape[-1]))
         out = ops.msda_fused(value.contiguous(), input_spatial_shapes, input_level_start_index,
@@ -461,8 +476,7 @@ class DeformableTransformerVLDINO(nn.Module):
         src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
         mask = torch.cat([m.flatten(1) for m in masks], 1)
         pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[i].view(1, 1, -1) for i, p in enumerate(pos_embeds)], 1)
-        spatial_shapes = torch.as_tensor(shapes_list, dtype=torch.long, device=src.device)
-        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        spatial_shapes, level_start_index = level_tensors(shapes_list, src.device)
         valid_ratios = torch.stack([get_valid_ratio(m) for m in masks], 1)
 
         enc = self.encoder(src, shapes_list, spatial_shapes, level_start_index, valid_ratios, pos, mask,

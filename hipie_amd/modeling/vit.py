@@ -99,13 +99,22 @@ class Attention(nn.Module):
         qkv = self.qkv(x).reshape(B, H * W, 3 * C)
         # decomposed rel-pos bias from the UNSCALED q (utils.py:113-123), as two small fp32 GEMMs
         rq = qkv[:, :, :C].reshape(B, H, W, nh, hd).float()
-        Rh = get_rel_pos(H, H, self.rel_pos_h.float())
-        Rw = get_rel_pos(W, W, self.rel_pos_w.float())
+        Rh, Rw = self._rel_tables(H, W)
         rel_h = torch.einsum("bhwnc,hkc->bnkhw", rq, Rh).reshape(B * nh, H, H * W)      # key-row major (see hipie_vit_attn)
         rel_w = torch.einsum("bhwnc,wkc->bnhwk", rq, Rw).reshape(B * nh, H * W, W)
         qkv16 = qkv.to(self.precision.attn)
         o = ops.vit_attn(qkv16.contiguous(), rel_h.contiguous(), rel_w.contiguous(), (H, W), nh, self.scale)
         return self.proj(o.to(x.dtype)).view(B, H, W, C)
+
+
+    def _rel_tables(self, H, W):
+        """gathered (and, off the training resolution, re-interpolated) rel-pos tables, cached per token grid."""
+        key = (H, W, self.rel_pos_h.data_ptr(), self.rel_pos_h.device)
+        if getattr(self, "_rel_key", None) != key:
+            self._rel_cache = (get_rel_pos(H, H, self.rel_pos_h.float()).contiguous(),
+                               get_rel_pos(W, W, self.rel_pos_w.float()).contiguous())
+            self._rel_key = key
+        return self._rel_cache
 
 
 class Mlp(nn.Module):

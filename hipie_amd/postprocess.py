@@ -8,35 +8,59 @@ import torch
 import torch.nn.functional as F
 
 
+_PMAP_CACHE = {}
+
+
+def positive_map_matrix(positive_map, L, device):
+    """(L, num_classes) matrix M with M[t, c] = 1/len(tokens of class c+1) so that token scores @ M is the per-class mean of
+    convert_grounding_to_od_logits (hipie_img.py:1041-1049) -- one GEMM for the whole batch instead of a Python loop of
+    per-class gathers.  Cached per prompt (the prompt is fixed over an evaluation run)."""
+    key = (id(positive_map), L, str(device))
+    m = _PMAP_CACHE.get(key)
+    if m is None:
+        m = torch.zeros(L, len(positive_map))
+        for label_j, toks in positive_map.items():
+            m[list(toks), int(label_j) - 1] = 1.0 / len(toks)
+        m = m.to(device)
+        _PMAP_CACHE[key] = m
+    return m
+
+
 def convert_grounding_to_od_logits(logits, num_classes, positive_map):
-    """logits (Q, L) token logits -> (Q, num_classes) by averaging each class's token positions (hipie_img.py:1041-1049)."""
-    scores = torch.zeros(logits.shape[0], num_classes, device=logits.device)
-    for label_j, toks in positive_map.items():
-        scores[:, int(label_j) - 1] = logits[:, torch.as_tensor(toks, device=logits.device)].mean(-1)
-    return scores
+    """logits (..., Q, L) token scores -> (..., Q, num_classes) mean over each class's token span."""
+    return logits @ positive_map_matrix(positive_map, logits.shape[-1], logits.device)
 
 
 def inference(model, out, batched_inputs, topk=100):
-    results = []
+    """batched over the images (no per-image / per-class Python loops on the device path)."""
     task = batched_inputs[0]["task"]
     nbg = model.cfg.num_bg_queries
-    for i, inp in enumerate(batched_inputs):
-        h, w = out["image_sizes"][i]
-        logits = out["pred_logits"][i][nbg:].sigmoid()
-        iou = out["pred_boxious"][i][nbg:].sigmoid()
-        if task == "grounding":
-            cls = logits
-        else:
-            pmap = inp.get("positive_map_label_to_token", {1: [0]})
-            cls = convert_grounding_to_od_logits(logits, len(pmap), pmap)
-        score = torch.sqrt(cls * iou)
-        k = min(topk, score.numel())
-        top, idx = score.flatten().topk(k)
-        qi, ci = idx // score.shape[1], idx % score.shape[1]
-        boxes = out["pred_boxes"][i][nbg:][qi]
-        cx, cy, bw, bh = boxes.unbind(-1)
-        xyxy = torch.stack([(cx - bw / 2) * w, (cy - bh / 2) * h, (cx + bw / 2) * w, (cy + bh / 2) * h], -1)
-        m = out["pred_masks"][i][nbg:][qi]                               # (k,1,H/4,W/4)
-        m = F.interpolate(m, scale_factor=model.mask_stride, mode="bilinear", align_corners=False)[:, 0, :h, :w]
-        results.append({"instances": {"pred_boxes": xyxy, "scores": top, "pred_classes": ci, "pred_masks": m.sigmoid() > 0.5}})
+    sizes = out["image_sizes"]
+    B = len(batched_inputs)
+    logits = out["pred_logits"][:, nbg:].float().sigmoid()               # (B, Q, L)
+    iou = out["pred_boxious"][:, nbg:].float().sigmoid()                 # (B, Q, 1)
+    if task == "grounding":
+        cls = logits
+    else:
+        pmap = batched_inputs[0].get("positive_map_label_to_token", {1: [0]})
+        cls = convert_grounding_to_od_logits(logits, len(pmap), pmap)
+    score = torch.sqrt(cls * iou)                                         # (B, Q, C)
+    C = score.shape[-1]
+    k = min(topk, score.shape[1] * C)
+    top, idx = score.flatten(1).topk(k, dim=1)                            # (B, k)
+    qi, ci = idx // C, idx % C
+    boxes = torch.gather(out["pred_boxes"][:, nbg:].float(), 1, qi.unsqueeze(-1).expand(-1, -1, 4))
+    wh = torch.tensor([[w, h, w, h] for (h, w) in sizes], dtype=torch.float32, device=boxes.device).unsqueeze(1) \
+        if not hasattr(model, "_wh_cache") or model._wh_cache[0] != tuple(sizes) else model._wh_cache[1]
+    model._wh_cache = (tuple(sizes), wh)
+    cx, cy, bw, bh = boxes.unbind(-1)
+    xyxy = torch.stack([cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], -1) * wh
+    pm = out["pred_masks"][:, nbg:, 0]                                    # (B, Q, H/4, W/4)
+    m = torch.gather(pm, 1, qi[:, :, None, None].expand(-1, -1, pm.shape[-2], pm.shape[-1]))
+    m = F.interpolate(m.float(), scale_factor=model.mask_stride, mode="bilinear", align_corners=False) > 0.0   # sigmoid > 0.5
+    results = []
+    for i in range(B):
+        h, w = sizes[i]
+        results.append({"instances": {"pred_boxes": xyxy[i], "scores": top[i], "pred_classes": ci[i],
+                                      "pred_masks": m[i, :, :h, :w]}})
     return results
