@@ -73,3 +73,14 @@ def test_library_missing_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libhipie_mi355.so")
     with pytest.raises(_lib.HipieLibraryError):
         _lib.load()
+
+
+def test_msda_shim_installs_reference_module_name():
+    import sys
+    from hipie_amd import msda_shim
+    mod = msda_shim.install()
+    import MultiScaleDeformableAttention as MSDA
+    assert MSDA is mod and callable(MSDA.ms_deform_attn_forward)
+    with pytest.raises(NotImplementedError):
+        MSDA.ms_deform_attn_backward()
+    sys.modules.pop("MultiScaleDeformableAttention")
