@@ -1,0 +1,167 @@
+// layernorm.hip -- fused residual-add + LayerNorm + cast (glue kernel, HBM-bound).
+//
+//   s = x + delta (delta optional);  res_out = s (optional, dtype of x);  norm_out = LN(s) * gamma + beta  (dtype Tn)
+//
+// Replaces the add -> LayerNorm -> cast chains around every ViT block (hipie/backbone/vit.py:212-230, eps 1e-6) and the
+// post-norm residuals of the deformable encoder layers (deformable_transformer_dino.py:384-394), which in eager PyTorch
+// are 2-3 separate elementwise passes over the (B, tokens, C) stream.  One wave owns one row: the row is read once (8-byte
+// vector loads), statistics are fp32 wave reductions (two-pass: mean, then centred variance -- the same arithmetic as
+// torch's layer_norm), and both outputs are written once.  Bytes per row: C * (|x| + |delta| + |res| + |norm|).
+#include "common.h"
+
+namespace hipie {
+
+template <typename T> struct V4 {
+  static __device__ __forceinline__ void ld(const T* p, float (&v)[4]);
+  static __device__ __forceinline__ void st(T* p, const float (&v)[4]);
+};
+template <> struct V4<float> {
+  static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+    const float4 r = *reinterpret_cast<const float4*>(p);
+    v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+  }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <> struct V4<bf16_t> {
+  static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[4]) {
+    const bf16x4 r = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)r[i];
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[4]) {
+    bf16x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x4*>(p) = r;
+  }
+};
+template <> struct V4<f16_t> {
+  static __device__ __forceinline__ void ld(const f16_t* p, float (&v)[4]) {
+    const f16x4 r = *reinterpret_cast<const f16x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)r[i];
+  }
+  static __device__ __forceinline__ void st(f16_t* p, const float (&v)[4]) {
+    f16x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (f16_t)v[i];
+    *reinterpret_cast<f16x4*>(p) = r;
+  }
+};
+
+constexpr int LN_MAXV = 8;     // up to 8 x 4 elements per lane: C <= 2048
+
+template <typename Tx, typename Td, typename Tn>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const Tx* __restrict__ x, const Td* __restrict__ delta,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            Tx* __restrict__ res_out, Tn* __restrict__ norm_out, long rows,
+                                                            int C, float eps) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int nv = C / 256;                       // full 4-element vectors per lane (64 lanes x 4)
+  const int tail = (C - nv * 256) / 4;          // remaining vectors (< 64), one per lane for lane < tail
+  float v[LN_MAXV][4];
+  float sum = 0.f;
+  const Tx* xr = x + row * C;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const bool on = (i < nv) || (i == nv && lane < tail);
+    if (on) {
+      const int c = i * 256 + lane * 4;
+      V4<Tx>::ld(xr + c, v[i]);
+      if (delta != nullptr) {
+        float d[4];
+        V4<Td>::ld(delta + row * C + c, d);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] += d[e];
+      }
+      if (res_out != nullptr) V4<Tx>::st(res_out + row * C + c, v[i]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum += v[i][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const bool on = (i < nv) || (i == nv && lane < tail);
+    if (on) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  const float rstd = rsqrtf(sq / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const bool on = (i < nv) || (i == nv && lane < tail);
+    if (on) {
+      const int c = i * 256 + lane * 4;
+      const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+      const float4 b = *reinterpret_cast<const float4*>(beta + c);
+      float o[4];
+      o[0] = (v[i][0] - mean) * rstd * g.x + b.x;
+      o[1] = (v[i][1] - mean) * rstd * g.y + b.y;
+      o[2] = (v[i][2] - mean) * rstd * g.z + b.z;
+      o[3] = (v[i][3] - mean) * rstd * g.w + b.w;
+      V4<Tn>::st(norm_out + row * C + c, o);
+    }
+  }
+}
+
+template <typename Tx, typename Td, typename Tn>
+static int launch_ln(const void* x, const void* d, const float* g, const float* b, void* r, void* n, long rows, int C,
+                     float eps, hipStream_t st) {
+  hipLaunchKernelGGL((add_layernorm_kernel<Tx, Td, Tn>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const Tx*)x,
+                     (const Td*)d, g, b, (Tx*)r, (Tn*)n, rows, C, eps);
+  return check_launch("add_layernorm");
+}
+
+template <typename Tx, typename Td>
+static int ln_out(int nd, const void* x, const void* d, const float* g, const float* b, void* r, void* n, long rows, int C,
+                  float eps, hipStream_t st) {
+  switch (nd) {
+    case HIPIE_F32: return launch_ln<Tx, Td, float>(x, d, g, b, r, n, rows, C, eps, st);
+    case HIPIE_F16: return launch_ln<Tx, Td, f16_t>(x, d, g, b, r, n, rows, C, eps, st);
+    case HIPIE_BF16: return launch_ln<Tx, Td, bf16_t>(x, d, g, b, r, n, rows, C, eps, st);
+    default: return set_err(HIPIE_EINVAL, "add_layernorm: bad norm dtype %d", nd);
+  }
+}
+
+template <typename Tx>
+static int ln_delta(int dd, int nd, const void* x, const void* d, const float* g, const float* b, void* r, void* n,
+                    long rows, int C, float eps, hipStream_t st) {
+  switch (dd) {
+    case HIPIE_F32: return ln_out<Tx, float>(nd, x, d, g, b, r, n, rows, C, eps, st);
+    case HIPIE_F16: return ln_out<Tx, f16_t>(nd, x, d, g, b, r, n, rows, C, eps, st);
+    case HIPIE_BF16: return ln_out<Tx, bf16_t>(nd, x, d, g, b, r, n, rows, C, eps, st);
+    default: return set_err(HIPIE_EINVAL, "add_layernorm: bad delta dtype %d", dd);
+  }
+}
+
+}  // namespace hipie
+
+extern "C" int hipie_add_layernorm(const void* x, const void* delta, const float* gamma, const float* beta, void* res_out,
+                                   void* norm_out, int64_t rows, int C, float eps, int x_dtype, int delta_dtype,
+                                   int norm_dtype, void* stream) {
+  using namespace hipie;
+  HIPIE_REQUIRE(x && gamma && beta && norm_out, "add_layernorm: null pointer");
+  HIPIE_REQUIRE(rows >= 0 && C > 0 && C % 4 == 0 && C <= LN_MAXV * 256, "add_layernorm: C=%d must be a multiple of 4 and <= %d", C, LN_MAXV * 256);
+  if (rows == 0) return HIPIE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  switch (x_dtype) {
+    case HIPIE_F32: return ln_delta<float>(delta_dtype, norm_dtype, x, delta, gamma, beta, res_out, norm_out, rows, C, eps, st);
+    case HIPIE_F16: return ln_delta<f16_t>(delta_dtype, norm_dtype, x, delta, gamma, beta, res_out, norm_out, rows, C, eps, st);
+    case HIPIE_BF16: return ln_delta<bf16_t>(delta_dtype, norm_dtype, x, delta, gamma, beta, res_out, norm_out, rows, C, eps, st);
+    default: return set_err(HIPIE_EINVAL, "add_layernorm: bad x dtype %d", x_dtype);
+  }
+}

@@ -32,9 +32,13 @@ class PLinear(nn.Linear):
 
 class PConv2d(nn.Conv2d):
     out_dtype = torch.float32
+    nhwc = False          # 16-bit k>1 convs run channels-last (MIOpen's NHWC implicit-GEMM kernels)
 
     def forward(self, x):
-        return self._conv_forward(x.to(self.weight.dtype), self.weight, self.bias).to(self.out_dtype)
+        x = x.to(self.weight.dtype)
+        if self.nhwc:
+            x = x.contiguous(memory_format=torch.channels_last)
+        return self._conv_forward(x, self.weight, self.bias).to(self.out_dtype)
 
 
 class PLayerNorm(nn.LayerNorm):
@@ -59,6 +63,9 @@ def cast_head(module, dtype, act=torch.float32):
                 m.bias.data = m.bias.data.to(dtype)
             if isinstance(m, (PLinear, PConv2d)):
                 m.out_dtype = act
+            if isinstance(m, PConv2d) and dtype != torch.float32:
+                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+                m.nhwc = True
     return module
 
 
@@ -75,6 +82,12 @@ def level_tensors(shapes_list, device):
         v = (ss, torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1])))
         _CONST_CACHE[key] = v
     return v
+
+
+def _add_norm(x, delta, norm):
+    """LayerNorm(x + delta) in x's dtype through the fused kernel (post-norm residual of the encoder layers)."""
+    x = x.contiguous()
+    return ops.add_layernorm(x, delta.to(x.dtype).contiguous(), norm.weight, norm.bias, norm.eps, x.dtype, want_res=False)[1]
 
 
 def _get_clones(module, n):
@@ -286,9 +299,9 @@ class DeformableTransformerEncoderLayer(nn.Module):
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         src2 = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index, padding_mask)
-        src = self.norm1(src + src2)
+        src = _add_norm(src, src2, self.norm1)
         src2 = self.linear2(F.relu(self.linear1(src)))
-        return self.norm2(src + src2)
+        return _add_norm(src, src2, self.norm2)
 
 
 def encoder_reference_points(spatial_shapes, valid_ratios, device):

@@ -142,22 +142,20 @@ class Block(nn.Module):
         self.window_size = window_size
         self.precision = precision
 
-    def _ln(self, norm, x):
-        w, b = norm.weight.to(x.dtype), norm.bias.to(x.dtype)       # statistics are fp32 inside the kernel either way
-        return F.layer_norm(x, x.shape[-1:], w, b, norm.eps).to(self.precision.gemm)
-
-    def forward(self, x):
-        """x: residual stream (B,H,W,C) in the policy's activation dtype."""
-        y = self._ln(self.norm1, x)
+    def forward(self, x, delta=None):
+        """x: residual stream (B,H,W,C) in the policy's activation dtype; ``delta``: the previous block's MLP output that
+        has not been added yet.  Returns (x, delta'): every residual add is fused with the LayerNorm that follows it
+        (hipie_add_layernorm), so the stream is read and written once per half-block."""
+        gd = self.precision.gemm
+        x, y = ops.add_layernorm(x, delta, self.norm1.weight, self.norm1.bias, self.norm1.eps, gd)
         if self.window_size > 0:
             H, W = y.shape[1], y.shape[2]
             y, pad_hw = window_partition(y, self.window_size)
         y = self.attn(y)
         if self.window_size > 0:
             y = window_unpartition(y, self.window_size, pad_hw, (H, W))
-        x = x + y.to(x.dtype)
-        x = x + self.mlp(self._ln(self.norm2, x)).to(x.dtype)
-        return x
+        x, h = ops.add_layernorm(x, y.contiguous(), self.norm2.weight, self.norm2.bias, self.norm2.eps, gd)
+        return x, self.mlp(h)
 
 
 class ViT(nn.Module):
@@ -188,8 +186,10 @@ class ViT(nn.Module):
         gd, ad = self.precision.gemm, self.precision.act
         x = self.patch_embed(x).float()
         x = (x + self._abs_pos((x.shape[1], x.shape[2]))).to(ad)
+        x, delta = x.contiguous(), None
         for blk in self.blocks:
-            x = blk(x)
+            x, delta = blk(x, delta)
+        x = x + delta.to(x.dtype)
         # fpn1: ConvTranspose2d(k=2, s=2) == one GEMM (E -> 4 * E/2) + a pixel shuffle (vit.py:341-343)
         B, H, W, E = x.shape
         wt = self.fpn1[0].weight                                           # (E, E/2, 2, 2)

@@ -198,6 +198,22 @@ def dynamic_mask(mask_feats, ref_points, params, num_queries, stride=8, up=2, ou
     return out
 
 
+@_timed("add_layernorm")
+def add_layernorm(x, delta, weight, bias, eps, norm_dtype, want_res=True):
+    """s = x + delta (delta may be None); returns (s in x.dtype or None, LayerNorm(s) in norm_dtype).  x (..., C)."""
+    lib = _lib.load()
+    C = x.shape[-1]
+    rows = x.numel() // C
+    res = torch.empty_like(x) if (want_res and delta is not None) else None
+    out = torch.empty(x.shape, dtype=norm_dtype, device=x.device)
+    rc = lib.hipie_add_layernorm(_chk(x, "x"), None if delta is None else _chk(delta, "delta"),
+                                 _chk(weight, "weight", torch.float32), _chk(bias, "bias", torch.float32),
+                                 None if res is None else res.data_ptr(), out.data_ptr(), rows, C, float(eps),
+                                 _DT[x.dtype], _DT[x.dtype if delta is None else delta.dtype], _DT[norm_dtype], _stream())
+    _lib.check(rc, "hipie_add_layernorm")
+    return (x if delta is None else res), out
+
+
 def selftest(which, a, b=None):
     lib = _lib.load()
     out = torch.empty(32 * 32 if which == 0 else 256, dtype=torch.float32, device=a.device)

@@ -133,6 +133,17 @@ int hipie_mask_einsum(const float* embed, const float* feats, void* out, int B, 
 int hipie_dynamic_mask(const float* feats, const float* refs, const float* params, void* out,
                        int B, int Q, int H, int W, int stride, int up, int out_dtype, void* stream);
 
+/*
+ * Fused residual add + LayerNorm + cast:  s = x + delta;  res_out = s (optional);  norm_out = LN(s) * gamma + beta.
+ * Replaces the add -> nn.LayerNorm -> cast chains of Block.forward (backbone/vit.py:212-230, eps 1e-6) and of the post-norm
+ * residuals in DeformableTransformerEncoderLayer.forward (models/deformable_detr/deformable_transformer_dino.py:384-394).
+ *   x (rows, C) x_dtype; delta (rows, C) delta_dtype or NULL; gamma, beta (C) f32; res_out (rows, C) x_dtype or NULL;
+ *   norm_out (rows, C) norm_dtype.  C % 4 == 0, C <= 2048.  fp32 statistics (two-pass mean / centred variance).
+ */
+int hipie_add_layernorm(const void* x, const void* delta, const float* gamma, const float* beta, void* res_out,
+                        void* norm_out, int64_t rows, int C, float eps, int x_dtype, int delta_dtype, int norm_dtype,
+                        void* stream);
+
 /* device-side self-test helpers used by tests/ to pin the MFMA / LDS-transpose lane layouts this library assumes.
  *   which 0: D = A(32x16) . B(16x32) with v_mfma_f32_32x32x16_bf16, operands loaded with the layouts documented in
  *            csrc/mfma.h; out (32,32) f32.   which 1: ds_read_b64_tr_b16 of a (64,16) bf16 tile; out (64,4) f32 per lane.

@@ -209,3 +209,26 @@ def test_flash_attn_generic(hd, nq, nk):
     ref = torch.nn.functional.scaled_dot_product_attention(q.float().cpu().transpose(1, 2), k.float().cpu().transpose(1, 2),
                                                            v.float().cpu().transpose(1, 2)).transpose(1, 2).reshape(2, nq, 4 * hd)
     assert rel_err(a.float().cpu(), ref) < 1e-3
+
+
+@pytest.mark.parametrize("C,rows", [(1280, 1000), (256, 4099), (160, 37), (2048, 5)])
+def test_add_layernorm(C, rows):
+    """hipie_add_layernorm vs torch fp32: fp32 in/out 2e-6; 16-bit storage within its rounding."""
+    import torch.nn.functional as F
+    from hipie_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(rows, C, generator=gen) * 3
+    d = torch.randn(rows, C, generator=gen)
+    w = 1 + 0.1 * torch.randn(C, generator=gen)
+    b = 0.1 * torch.randn(C, generator=gen)
+    want_res = x + d
+    want = F.layer_norm(want_res, (C,), w, b, 1e-6)
+    res, out = ops.add_layernorm(x.to(DEV), d.to(DEV), w.to(DEV), b.to(DEV), 1e-6, torch.float32)
+    assert rel_err(res.cpu(), want_res) < 1e-6 and rel_err(out.cpu(), want) < 2e-6
+    _, out0 = ops.add_layernorm(x.to(DEV), None, w.to(DEV), b.to(DEV), 1e-6, torch.float32)
+    assert rel_err(out0.cpu(), F.layer_norm(x, (C,), w, b, 1e-6)) < 2e-6
+    xb, db = x.bfloat16(), d.half()
+    res, out = ops.add_layernorm(xb.to(DEV), db.to(DEV), w.to(DEV), b.to(DEV), 1e-6, torch.float16)
+    s = xb.float() + db.float()
+    assert rel_err(res.float().cpu(), s) < 8e-3
+    assert rel_err(out.float().cpu(), F.layer_norm(s, (C,), w, b, 1e-6)) < 2e-3
