@@ -28,6 +28,15 @@ def get_rel_pos(q_size, k_size, rel_pos):
     return r[rel.long()]
 
 
+def resize_rel_pos(size, rel_pos):
+    """the table-resize half of get_rel_pos for q_size == k_size == size: (2*size-1, hd)."""
+    n = 2 * size - 1
+    if rel_pos.shape[0] == n:
+        return rel_pos
+    r = F.interpolate(rel_pos.reshape(1, rel_pos.shape[0], -1).permute(0, 2, 1), size=n, mode="linear")
+    return r.reshape(-1, n).permute(1, 0)
+
+
 def get_abs_pos(abs_pos, has_cls_token, hw):
     """hipie/backbone/utils.py:128-157."""
     h, w = hw
@@ -96,23 +105,21 @@ class Attention(nn.Module):
         B, H, W, C = x.shape
         nh = self.num_heads
         hd = C // nh
-        qkv = self.qkv(x).reshape(B, H * W, 3 * C)
-        # decomposed rel-pos bias from the UNSCALED q (utils.py:113-123), as two small fp32 GEMMs
-        rq = qkv[:, :, :C].reshape(B, H, W, nh, hd).float()
-        Rh, Rw = self._rel_tables(H, W)
-        rel_h = torch.einsum("bhwnc,hkc->bnkhw", rq, Rh).reshape(B * nh, H, H * W)      # key-row major (see hipie_vit_attn)
-        rel_w = torch.einsum("bhwnc,wkc->bnhwk", rq, Rw).reshape(B * nh, H * W, W)
-        qkv16 = qkv.to(self.precision.attn)
-        o = ops.vit_attn(qkv16.contiguous(), rel_h.contiguous(), rel_w.contiguous(), (H, W), nh, self.scale)
+        qkv16 = self.qkv(x).reshape(B, H * W, 3 * C).to(self.precision.attn).contiguous()
+        # decomposed rel-pos bias from the UNSCALED q (utils.py:113-123): one MFMA launch on the packed qkv tensor
+        th, tw = self._rel_tables(H, W)
+        rel_h, rel_w = ops.vit_relpos(qkv16, th, tw, (H, W), nh)
+        o = ops.vit_attn(qkv16, rel_h, rel_w, (H, W), nh, self.scale)
         return self.proj(o.to(x.dtype)).view(B, H, W, C)
 
 
     def _rel_tables(self, H, W):
-        """gathered (and, off the training resolution, re-interpolated) rel-pos tables, cached per token grid."""
-        key = (H, W, self.rel_pos_h.data_ptr(), self.rel_pos_h.device)
+        """rel_pos_h / rel_pos_w linearly re-interpolated to 2*size-1 rows when needed (get_rel_pos, utils.py:63-86), in the
+        attention operand dtype, cached per token grid.  Entry [hq - hk + H - 1] is Rh[hq, hk] (:88-93)."""
+        key = (H, W, self.rel_pos_h.data_ptr(), self.rel_pos_h.device, self.precision.attn)
         if getattr(self, "_rel_key", None) != key:
-            self._rel_cache = (get_rel_pos(H, H, self.rel_pos_h.float()).contiguous(),
-                               get_rel_pos(W, W, self.rel_pos_w.float()).contiguous())
+            self._rel_cache = (resize_rel_pos(H, self.rel_pos_h.float()).to(self.precision.attn).contiguous(),
+                               resize_rel_pos(W, self.rel_pos_w.float()).to(self.precision.attn).contiguous())
             self._rel_key = key
         return self._rel_cache
 

@@ -198,6 +198,22 @@ def dynamic_mask(mask_feats, ref_points, params, num_queries, stride=8, up=2, ou
     return out
 
 
+@_timed("vit_relpos")
+def vit_relpos(qkv, tab_h, tab_w, grid_hw, heads):
+    """qkv (B, N, 3*heads*hd) 16-bit; tab_h (2gh-1, hd), tab_w (2gw-1, hd) same dtype -> rel_h (B*heads, gh, N), rel_w
+    (B*heads, N, gw) f32, the bias tables of hipie_vit_attn."""
+    lib = _lib.load()
+    gh, gw = grid_hw
+    B, N, C3 = qkv.shape
+    hd = C3 // (3 * heads)
+    rel_h = torch.empty(B * heads, gh, N, dtype=torch.float32, device=qkv.device)
+    rel_w = torch.empty(B * heads, N, gw, dtype=torch.float32, device=qkv.device)
+    rc = lib.hipie_vit_relpos(_chk(qkv, "qkv"), _chk(tab_h, "tab_h", qkv.dtype), _chk(tab_w, "tab_w", qkv.dtype),
+                              rel_h.data_ptr(), rel_w.data_ptr(), B, gh, gw, heads, hd, _DT[qkv.dtype], _stream())
+    _lib.check(rc, "hipie_vit_relpos")
+    return rel_h, rel_w
+
+
 @_timed("add_layernorm")
 def add_layernorm(x, delta, weight, bias, eps, norm_dtype, want_res=True):
     """s = x + delta (delta may be None); returns (s in x.dtype or None, LayerNorm(s) in norm_dtype).  x (..., C)."""

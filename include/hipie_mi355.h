@@ -134,6 +134,16 @@ int hipie_dynamic_mask(const float* feats, const float* refs, const float* param
                        int B, int Q, int H, int W, int stride, int up, int out_dtype, void* stream);
 
 /*
+ * Decomposed relative-position bias tables of one ViT block, straight from the packed 16-bit qkv tensor.
+ * Replaces: add_decomposed_rel_pos's two einsums + get_rel_pos gathers (backbone/utils.py:63-125) feeding hipie_vit_attn.
+ *   qkv (B, gh*gw, 3, heads, hd) 16-bit;  tab_h (2*gh-1, hd), tab_w (2*gw-1, hd) 16-bit = rel_pos_h / rel_pos_w after the
+ *   reference's linear re-interpolation to length 2*size-1;  rel_h (B*heads, gh, gh*gw) f32,  rel_w (B*heads, gh*gw, gw) f32.
+ *   hd in {64, 80}; gh, gw <= 96.
+ */
+int hipie_vit_relpos(const void* qkv, const void* tab_h, const void* tab_w, float* rel_h, float* rel_w,
+                     int B, int gh, int gw, int heads, int hd, int dtype, void* stream);
+
+/*
  * Fused residual add + LayerNorm + cast:  s = x + delta;  res_out = s (optional);  norm_out = LN(s) * gamma + beta.
  * Replaces the add -> nn.LayerNorm -> cast chains of Block.forward (backbone/vit.py:212-230, eps 1e-6) and of the post-norm
  * residuals in DeformableTransformerEncoderLayer.forward (models/deformable_detr/deformable_transformer_dino.py:384-394).

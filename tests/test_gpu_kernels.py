@@ -232,3 +232,26 @@ def test_add_layernorm(C, rows):
     s = xb.float() + db.float()
     assert rel_err(res.float().cpu(), s) < 8e-3
     assert rel_err(out.float().cpu(), F.layer_norm(s, (C,), w, b, 1e-6)) < 2e-3
+
+
+@pytest.mark.parametrize("name", ["window14", "global16", "global64", "global_rect"])
+def test_vit_relpos_tables(name):
+    """hipie_vit_relpos == the reference's two einsums over get_rel_pos (fp32) on the same 16-bit q and tables."""
+    from hipie_amd import ops
+    from hipie_amd.modeling.vit import resize_rel_pos
+    g = Golden("vit_attn")
+    c, sd, x = vit_attn_case(g, name)
+    B, H, W, C = x.shape
+    heads = c["heads"]
+    hd = C // heads
+    for dt, tol in ((torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)):
+        qkv = _vit_qkv(c, sd, x).to(dt)
+        th = resize_rel_pos(H, sd["rel_pos_h"]).to(dt)
+        tw = resize_rel_pos(W, sd["rel_pos_w"]).to(dt)
+        q = qkv.float().reshape(B, H * W, 3, heads, hd)[:, :, 0].permute(0, 2, 1, 3).reshape(B * heads, H, W, hd)
+        Rh = oo.get_rel_pos(H, H, th.float())
+        Rw = oo.get_rel_pos(W, W, tw.float())
+        want_h = torch.einsum("bhwc,hkc->bkhw", q, Rh).reshape(B * heads, H, H * W)
+        want_w = torch.einsum("bhwc,wkc->bhwk", q, Rw).reshape(B * heads, H * W, W)
+        rh, rw = ops.vit_relpos(qkv.to(DEV), th.to(DEV), tw.to(DEV), (H, W), heads)
+        assert rel_err(rh.cpu(), want_h) < 1e-5 and rel_err(rw.cpu(), want_w) < 1e-5    # fp32 accumulate of exact products
