@@ -59,29 +59,35 @@ template <> struct Vec4<f16_t> {
 constexpr int kMaxLP = 32;  // L*P supported by the fused softmax (reference geometry: 4*4 = 16)
 
 // D == 32: 8 lanes per (b,q,m), 4 channels per lane.
-template <typename T, bool FUSED>
+template <typename T, typename A, bool FUSED>
 __global__ __launch_bounds__(256) void msda_d32_kernel(const T* __restrict__ value, const int64_t* __restrict__ shapes,
                                                        const int64_t* __restrict__ lstart,
-                                                       const float* __restrict__ loc_or_off,
-                                                       const float* __restrict__ w_or_logit,
+                                                       const A* __restrict__ loc_or_off, const A* __restrict__ w_or_logit,
                                                        const float* __restrict__ ref, T* __restrict__ out, int S, int M,
-                                                       int L, int Lq, int P, int ref_dim, long total_groups) {
-  const long g = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
-  if (g >= total_groups) return;
+                                                       int L, int Lq, int P, int ref_dim, long total_groups,
+                                                       long off_stride, long w_stride) {
+  // XCD-aware block order: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md); give every XCD one CONTIGUOUS range of
+  // (image, query) groups so that neighbouring queries -- which sample neighbouring value pixels -- share that XCD's L2
+  // instead of all eight L2s streaming the whole value tensor.  Placement only affects speed.
+  const long nblk = gridDim.x, per = (nblk + 7) / 8;
+  const long blk = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const long g = blk * 32 + (threadIdx.x >> 3);
+  if (blk >= nblk || g >= total_groups) return;
   const int sub = threadIdx.x & 7;
   const int m = (int)(g % M);
   const long bq = g / M;
   const int b = (int)(bq / Lq);
   const int LP = L * P;
-  const float* lp = loc_or_off + g * (long)(LP * 2);
-  const float* wp = w_or_logit + g * (long)LP;
+  // row = one (batch, query); offsets / logits of head m inside the row (dense rows when the strides are M*L*P*2 / M*L*P)
+  const A* lp = loc_or_off + bq * off_stride + (long)m * (LP * 2);
+  const A* wp = w_or_logit + bq * w_stride + (long)m * LP;
 
   float wmax = 0.f, winv = 1.f;
   if (FUSED) {
     wmax = -INFINITY;
-    for (int i = 0; i < LP; ++i) wmax = fmaxf(wmax, wp[i]);
+    for (int i = 0; i < LP; ++i) wmax = fmaxf(wmax, elem<A>::to_f32(wp[i]));
     float s = 0.f;
-    for (int i = 0; i < LP; ++i) s += expf(wp[i] - wmax);
+    for (int i = 0; i < LP; ++i) s += expf(elem<A>::to_f32(wp[i]) - wmax);
     winv = 1.f / s;
   }
 
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(256) void msda_d32_kernel(const T* __restrict__ val
 #pragma unroll 4
     for (int p = 0; p < P; ++p) {
       const int i = l * P + p;
-      float x = lp[2 * i], y = lp[2 * i + 1], w;
+      float x = elem<A>::to_f32(lp[2 * i]), y = elem<A>::to_f32(lp[2 * i + 1]), w;
       if (FUSED) {
         if (ref_dim == 2) {                            // ref + off / (W_l, H_l)
           x = rx + x / (float)W;
@@ -109,9 +115,9 @@ __global__ __launch_bounds__(256) void msda_d32_kernel(const T* __restrict__ val
           x = rx + x / (float)P * rw * 0.5f;
           y = ry + y / (float)P * rh * 0.5f;
         }
-        w = expf(wp[i] - wmax) * winv;
+        w = expf(elem<A>::to_f32(wp[i]) - wmax) * winv;
       } else {
-        w = wp[i];
+        w = elem<A>::to_f32(wp[i]);
       }
       const float h_im = y * (float)H - 0.5f;
       const float w_im = x * (float)W - 0.5f;
@@ -143,13 +149,14 @@ __global__ __launch_bounds__(256) void msda_d32_kernel(const T* __restrict__ val
 }
 
 // any D: one thread per output element (b,q,m,c), the reference's own decomposition.
-template <typename T, bool FUSED>
+template <typename T, typename A, bool FUSED>
 __global__ __launch_bounds__(256) void msda_generic_kernel(const T* __restrict__ value, const int64_t* __restrict__ shapes,
                                                            const int64_t* __restrict__ lstart,
-                                                           const float* __restrict__ loc_or_off,
-                                                           const float* __restrict__ w_or_logit,
+                                                           const A* __restrict__ loc_or_off,
+                                                           const A* __restrict__ w_or_logit,
                                                            const float* __restrict__ ref, T* __restrict__ out, int S,
-                                                           int M, int D, int L, int Lq, int P, int ref_dim, long n) {
+                                                           int M, int D, int L, int Lq, int P, int ref_dim, long n,
+                                                           long off_stride, long w_stride) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n) return;
   const int c = (int)(idx % D);
@@ -158,14 +165,14 @@ __global__ __launch_bounds__(256) void msda_generic_kernel(const T* __restrict__
   const long bq = g / M;
   const int b = (int)(bq / Lq);
   const int LP = L * P;
-  const float* lp = loc_or_off + g * (long)(LP * 2);
-  const float* wp = w_or_logit + g * (long)LP;
+  const A* lp = loc_or_off + bq * off_stride + (long)m * (LP * 2);
+  const A* wp = w_or_logit + bq * w_stride + (long)m * LP;
   float wmax = 0.f, winv = 1.f;
   if (FUSED) {
     wmax = -INFINITY;
-    for (int i = 0; i < LP; ++i) wmax = fmaxf(wmax, wp[i]);
+    for (int i = 0; i < LP; ++i) wmax = fmaxf(wmax, elem<A>::to_f32(wp[i]));
     float s = 0.f;
-    for (int i = 0; i < LP; ++i) s += expf(wp[i] - wmax);
+    for (int i = 0; i < LP; ++i) s += expf(elem<A>::to_f32(wp[i]) - wmax);
     winv = 1.f / s;
   }
   const long row = (long)M * D;
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(256) void msda_generic_kernel(const T* __restrict__
     const T* vl = vb + (long)lstart[l] * row;
     for (int p = 0; p < P; ++p) {
       const int i = l * P + p;
-      float x = lp[2 * i], y = lp[2 * i + 1], w;
+      float x = elem<A>::to_f32(lp[2 * i]), y = elem<A>::to_f32(lp[2 * i + 1]), w;
       if (FUSED) {
         const float* r = ref + (bq * L + l) * ref_dim;
         if (ref_dim == 2) {
@@ -186,9 +193,9 @@ __global__ __launch_bounds__(256) void msda_generic_kernel(const T* __restrict__
           x = r[0] + x / (float)P * r[2] * 0.5f;
           y = r[1] + y / (float)P * r[3] * 0.5f;
         }
-        w = expf(wp[i] - wmax) * winv;
+        w = expf(elem<A>::to_f32(wp[i]) - wmax) * winv;
       } else {
-        w = wp[i];
+        w = elem<A>::to_f32(wp[i]);
       }
       const float h_im = y * (float)H - 0.5f, w_im = x * (float)W - 0.5f;
       if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {
@@ -206,43 +213,54 @@ __global__ __launch_bounds__(256) void msda_generic_kernel(const T* __restrict__
   out[idx] = elem<T>::from_f32(col);
 }
 
-template <typename T, bool FUSED>
-static int launch_msda(const void* value, const int64_t* shapes, const int64_t* lstart, const float* a, const float* w,
+template <typename T, typename A, bool FUSED>
+static int launch_msda(const void* value, const int64_t* shapes, const int64_t* lstart, const void* a, const void* w,
                        const float* ref, void* out, int B, int S, int M, int D, int L, int Lq, int P, int ref_dim,
-                       hipStream_t st) {
+                       long off_stride, long w_stride, hipStream_t st) {
   const long groups = (long)B * Lq * M;
   if (groups == 0) return HIPIE_OK;
   if (D == 32) {
     const long blocks = (groups + 31) / 32;
-    hipLaunchKernelGGL((msda_d32_kernel<T, FUSED>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)value, shapes,
-                       lstart, a, w, ref, (T*)out, S, M, L, Lq, P, ref_dim, groups);
+    hipLaunchKernelGGL((msda_d32_kernel<T, A, FUSED>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)value, shapes,
+                       lstart, (const A*)a, (const A*)w, ref, (T*)out, S, M, L, Lq, P, ref_dim, groups, off_stride, w_stride);
   } else {
     const long n = groups * D;
     const long blocks = (n + 255) / 256;
-    hipLaunchKernelGGL((msda_generic_kernel<T, FUSED>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)value,
-                       shapes, lstart, a, w, ref, (T*)out, S, M, D, L, Lq, P, ref_dim, n);
+    hipLaunchKernelGGL((msda_generic_kernel<T, A, FUSED>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)value,
+                       shapes, lstart, (const A*)a, (const A*)w, ref, (T*)out, S, M, D, L, Lq, P, ref_dim, n, off_stride, w_stride);
   }
   return check_launch("msda");
 }
 
+template <typename T, bool FUSED>
+static int dispatch_aux(int aux_dtype, const void* value, const int64_t* shapes, const int64_t* lstart, const void* a,
+                        const void* w, const float* ref, void* out, int B, int S, int M, int D, int L, int Lq, int P,
+                        int ref_dim, long off_stride, long w_stride, hipStream_t st) {
+  switch (aux_dtype) {
+    case HIPIE_F32: return launch_msda<T, float, FUSED>(value, shapes, lstart, a, w, ref, out, B, S, M, D, L, Lq, P, ref_dim, off_stride, w_stride, st);
+    case HIPIE_F16: return launch_msda<T, f16_t, FUSED>(value, shapes, lstart, a, w, ref, out, B, S, M, D, L, Lq, P, ref_dim, off_stride, w_stride, st);
+    case HIPIE_BF16: return launch_msda<T, bf16_t, FUSED>(value, shapes, lstart, a, w, ref, out, B, S, M, D, L, Lq, P, ref_dim, off_stride, w_stride, st);
+    default: return set_err(HIPIE_EINVAL, "msda: unsupported aux dtype %d", aux_dtype);
+  }
+}
+
 template <bool FUSED>
-static int dispatch_msda(const void* value, const int64_t* shapes, const int64_t* lstart, const float* a, const float* w,
+static int dispatch_msda(const void* value, const int64_t* shapes, const int64_t* lstart, const void* a, const void* w,
                          const float* ref, void* out, int B, int S, int M, int D, int L, int Lq, int P, int ref_dim,
-                         int dtype, void* stream) {
+                         int dtype, int aux_dtype, long off_stride, long w_stride, void* stream) {
   HIPIE_REQUIRE(value && shapes && lstart && a && w && out, "msda: null pointer");
   HIPIE_REQUIRE(B >= 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq >= 0 && P > 0, "msda: bad shape B=%d S=%d M=%d D=%d L=%d Lq=%d P=%d", B, S, M, D, L, Lq, P);
   HIPIE_REQUIRE((long)B * S * M * D < (1L << 40), "msda: tensor too large");
+  HIPIE_REQUIRE(off_stride >= (long)M * L * P * 2 && w_stride >= (long)M * L * P, "msda: row strides too small");
   if (FUSED) {
     HIPIE_REQUIRE(ref != nullptr && (ref_dim == 2 || ref_dim == 4), "msda_fused: ref_dim must be 2 or 4 (got %d)", ref_dim);
     HIPIE_REQUIRE(L * P <= kMaxLP, "msda_fused: L*P=%d > %d", L * P, kMaxLP);
   }
   hipStream_t st = (hipStream_t)stream;
   switch (dtype) {
-    case HIPIE_F32: return launch_msda<float, FUSED>(value, shapes, lstart, a, w, ref, out, B, S, M, D, L, Lq, P, ref_dim, st);
-    case HIPIE_F16:
-      HIPIE_REQUIRE(D % 4 == 0 || D != 32, "msda: D");
-      return launch_msda<f16_t, FUSED>(value, shapes, lstart, a, w, ref, out, B, S, M, D, L, Lq, P, ref_dim, st);
-    case HIPIE_BF16: return launch_msda<bf16_t, FUSED>(value, shapes, lstart, a, w, ref, out, B, S, M, D, L, Lq, P, ref_dim, st);
+    case HIPIE_F32: return dispatch_aux<float, FUSED>(aux_dtype, value, shapes, lstart, a, w, ref, out, B, S, M, D, L, Lq, P, ref_dim, off_stride, w_stride, st);
+    case HIPIE_F16: return dispatch_aux<f16_t, FUSED>(aux_dtype, value, shapes, lstart, a, w, ref, out, B, S, M, D, L, Lq, P, ref_dim, off_stride, w_stride, st);
+    case HIPIE_BF16: return dispatch_aux<bf16_t, FUSED>(aux_dtype, value, shapes, lstart, a, w, ref, out, B, S, M, D, L, Lq, P, ref_dim, off_stride, w_stride, st);
     default: return set_err(HIPIE_EINVAL, "msda: unsupported dtype %d", dtype);
   }
 }
@@ -253,13 +271,13 @@ extern "C" int hipie_msda_forward(const void* value, const int64_t* spatial_shap
                                   const float* sampling_loc, const float* attn_weight, void* out, int B, int S, int M,
                                   int D, int L, int Lq, int P, int value_dtype, void* stream) {
   return hipie::dispatch_msda<false>(value, spatial_shapes, level_start, sampling_loc, attn_weight, nullptr, out, B, S,
-                                     M, D, L, Lq, P, 2, value_dtype, stream);
+                                     M, D, L, Lq, P, 2, value_dtype, HIPIE_F32, (long)M * L * P * 2, (long)M * L * P, stream);
 }
 
 extern "C" int hipie_msda_fused_forward(const void* value, const int64_t* spatial_shapes, const int64_t* level_start,
-                                        const float* ref, const float* offsets, const float* logits, void* out, int B,
+                                        const float* ref, const void* offsets, const void* logits, void* out, int B,
                                         int S, int M, int D, int L, int Lq, int P, int ref_dim, int value_dtype,
-                                        void* stream) {
+                                        int aux_dtype, int64_t off_row_stride, int64_t logit_row_stride, void* stream) {
   return hipie::dispatch_msda<true>(value, spatial_shapes, level_start, offsets, logits, ref, out, B, S, M, D, L, Lq, P,
-                                    ref_dim, value_dtype, stream);
+                                    ref_dim, value_dtype, aux_dtype, off_row_stride, logit_row_stride, stream);
 }

@@ -48,6 +48,7 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         shapes_list = [tuple(int(v) for v in s.shape[-2:]) for s in srcs]
         src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
         pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[i].view(1, 1, -1) for i, p in enumerate(pos_embeds)], 1)
+        pos = pos.to(src.dtype)
         B = src.shape[0]
         spatial_shapes, level_start_index = level_tensors(shapes_list, src.device)
         valid_ratios = torch.ones(B, len(srcs), 2, device=src.device)

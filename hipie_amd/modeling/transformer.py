@@ -221,13 +221,26 @@ class MSDeformAttn(nn.Module):
                 input_padding_mask=None):
         N, Lq, _ = query.shape
         value = self.project_value(input_flatten, input_padding_mask)
-        off = self.sampling_offsets(query).float().view(N, Lq, self.n_heads, self.n_levels, self.n_points, 2)
-        logits = self.attention_weights(query).float().view(N, Lq, self.n_heads, self.n_levels * self.n_points)
         if reference_points.shape[-1] not in (2, 4):
             raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(reference_points.shape[-1]))
+        # sampling_offsets and attention_weights share their input: one GEMM on the concatenated weights, and the kernel
+        # reads both column blocks of that single output in place (row strides), in whatever dtype the GEMM produced
+        w, b = self._fused_proj()
+        no = self.n_heads * self.n_levels * self.n_points * 2
+        proj = F.linear(query.to(w.dtype), w, b)
+        off = proj[..., :no].unflatten(-1, (self.n_heads, self.n_levels, self.n_points, 2))
+        logits = proj[..., no:].unflatten(-1, (self.n_heads, self.n_levels * self.n_points))
         out = ops.msda_fused(value.contiguous(), input_spatial_shapes, input_level_start_index,
-                             reference_points.float().contiguous(), off.contiguous(), logits.contiguous())
+                             reference_points.float().contiguous(), off, logits)
         return self.output_proj(out)
+
+    def _fused_proj(self):
+        so, aw = self.sampling_offsets, self.attention_weights
+        key = (so.weight.data_ptr(), aw.weight.data_ptr(), so.weight.dtype)
+        if getattr(self, "_fp_key", None) != key:
+            self._fp = (torch.cat([so.weight, aw.weight], 0).contiguous(), torch.cat([so.bias, aw.bias], 0).contiguous())
+            self._fp_key = key
+        return self._fp
 
 
 # --------------------------------------------------------------------------- VL fusion
@@ -489,6 +502,7 @@ class DeformableTransformerVLDINO(nn.Module):
         src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
         mask = torch.cat([m.flatten(1) for m in masks], 1)
         pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[i].view(1, 1, -1) for i, p in enumerate(pos_embeds)], 1)
+        pos = pos.to(src.dtype)                      # one cast here instead of one per encoder layer (src + pos promotes)
         spatial_shapes, level_start_index = level_tensors(shapes_list, src.device)
         valid_ratios = torch.stack([get_valid_ratio(m) for m in masks], 1)
 

@@ -95,16 +95,26 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
 
 @_timed("msda")
 def msda_fused(value, spatial_shapes, level_start_index, ref, offsets, logits):
-    """value (B,S,M,D); ref (B,Lq,L,2|4) f32; offsets (B,Lq,M,L,P,2) f32; logits (B,Lq,M,L*P) f32 -> (B,Lq,M*D)."""
+    """value (B,S,M,D); ref (B,Lq,L,2|4) f32; offsets (B,Lq,M,L,P,2); logits (B,Lq,M,L*P) (f32/f16/bf16, same dtype; they
+    may be column slices of ONE projection output: only the last dim block must be contiguous) -> (B,Lq,M*D)."""
     lib = _lib.load()
     B, S, M, D = value.shape
     _, Lq, _, L, P, _ = offsets.shape
+    if offsets.dtype != logits.dtype or offsets.dtype not in _DT:
+        raise RuntimeError("msda_fused: offsets/logits must share a dtype in f32/f16/bf16")
+    off_stride, lg_stride = offsets.stride(1), logits.stride(1)
+    if offsets.stride(0) != Lq * off_stride or logits.stride(0) != Lq * lg_stride or \
+            offsets[0, 0].stride() != (L * P * 2, P * 2, 2, 1) or logits[0, 0].stride() != (L * P, 1):
+        raise RuntimeError("msda_fused: offsets/logits rows must be dense (M,L,P,2)/(M,L*P) blocks")
+    for t, n in ((offsets, "offsets"), (logits, "logits")):
+        if not t.is_cuda:
+            raise RuntimeError("Not implemented on the CPU (%s)" % n)
     out = torch.empty(B, Lq, M * D, dtype=value.dtype, device=value.device)
     rc = lib.hipie_msda_fused_forward(_chk(value, "value"), _chk(spatial_shapes, "spatial_shapes", torch.int64),
                                       _chk(level_start_index, "level_start_index", torch.int64),
-                                      _chk(ref, "ref", torch.float32), _chk(offsets, "offsets", torch.float32),
-                                      _chk(logits, "logits", torch.float32), out.data_ptr(),
-                                      B, S, M, D, L, Lq, P, ref.shape[-1], _DT[value.dtype], _stream())
+                                      _chk(ref, "ref", torch.float32), offsets.data_ptr(), logits.data_ptr(), out.data_ptr(),
+                                      B, S, M, D, L, Lq, P, ref.shape[-1], _DT[value.dtype], _DT[offsets.dtype],
+                                      off_stride, lg_stride, _stream())
     _lib.check(rc, "hipie_msda_fused_forward")
     return out
 

@@ -59,13 +59,15 @@ int hipie_msda_forward(const void* value, const int64_t* spatial_shapes, const i
  * Fused form used by the product path: sampling locations and the 16-way softmax are computed in the kernel from
  * the raw projections, so neither (B,Lq,M,L,P,2) locations nor normalised weights ever reach HBM.
  * Replaces: MSDeformAttn.forward lines 99-114 (ops/modules/ms_deform_attn.py) + the op above.
- *   offsets (B, Lq, M, L, P, 2) f32 = sampling_offsets(query);  logits (B, Lq, M, L*P) f32 = attention_weights(query)
+ *   offsets: row (b,q) at offsets + (b*Lq+q)*off_row_stride holds (M, L, P, 2) = sampling_offsets(query)
+ *   logits:  row (b,q) at logits  + (b*Lq+q)*logit_row_stride holds (M, L*P) = attention_weights(query)
+ *            (both `aux_dtype` f32|f16|bf16; the strides let one concatenated projection GEMM feed both)
  *   ref     (B, Lq, L, ref_dim) f32, ref_dim 2: loc = ref + off/(W_l,H_l); ref_dim 4: loc = ref_xy + off/P*ref_wh*0.5
  */
 int hipie_msda_fused_forward(const void* value, const int64_t* spatial_shapes, const int64_t* level_start,
-                             const float* ref, const float* offsets, const float* logits, void* out,
+                             const float* ref, const void* offsets, const void* logits, void* out,
                              int B, int S, int M, int D, int L, int Lq, int P, int ref_dim, int value_dtype,
-                             void* stream);
+                             int aux_dtype, int64_t off_row_stride, int64_t logit_row_stride, void* stream);
 
 /*
  * Fused (flash-style) attention core shared by the ViT blocks and the VL fusion:

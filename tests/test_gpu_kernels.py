@@ -246,8 +246,8 @@ def test_vit_relpos_tables(name):
     hd = C // heads
     for dt, tol in ((torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)):
         qkv = _vit_qkv(c, sd, x).to(dt)
-        th = resize_rel_pos(H, sd["rel_pos_h"]).to(dt)
-        tw = resize_rel_pos(W, sd["rel_pos_w"]).to(dt)
+        th = resize_rel_pos(H, sd["rel_pos_h"]).to(dt).contiguous()
+        tw = resize_rel_pos(W, sd["rel_pos_w"]).to(dt).contiguous()
         q = qkv.float().reshape(B, H * W, 3, heads, hd)[:, :, 0].permute(0, 2, 1, 3).reshape(B * heads, H, W, hd)
         Rh = oo.get_rel_pos(H, H, th.float())
         Rw = oo.get_rel_pos(W, W, tw.float())
