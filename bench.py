@@ -110,8 +110,9 @@ def main():
     ap.add_argument("--model", default="vit_huge", choices=["vit_huge", "vit_large", "vit_base"])
     ap.add_argument("--precision", default="fast", choices=["fast", "parity", "default"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one hipGraph "
-                    "of the forward (the eager path is host-launch-bound: several thousand launches per step)")
+    ap.add_argument("--graph", action="store_true", help="capture the forward once into a hipGraph and replay it (experimental: "
+                    "after the launch-count reductions the eager path is no longer host-bound, and whole-model replay "
+                    "showed an unexplained GPU memory fault -- DESIGN.md section 9)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--breakdown", action="store_true", help="after the timed region, time every hand-written kernel class "
                     "and the main stages of one extra step (stderr)")
@@ -154,10 +155,10 @@ def main():
     for _ in range(max(args.warmup, 1)):
         step()
 
-    # The forward has static shapes and no host<->device traffic, so it is captured once into a hipGraph and replayed:
-    # the eager path issues several thousand small launches per step and is bound by the host, not by the GPU.
+    # The forward has static shapes and no host<->device traffic, so it CAN be captured once into a hipGraph and replayed
+    # (--graph).  Default is eager: with batched post-processing and the fused glue kernels the step is GPU-bound.
     graph, gblock = None, None
-    if not args.no_graph:
+    if args.graph:
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())

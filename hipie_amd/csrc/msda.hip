@@ -69,10 +69,12 @@ __global__ __launch_bounds__(256) void msda_d32_kernel(const T* __restrict__ val
   // XCD-aware block order: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md); give every XCD one CONTIGUOUS range of
   // (image, query) groups so that neighbouring queries -- which sample neighbouring value pixels -- share that XCD's L2
   // instead of all eight L2s streaming the whole value tensor.  Placement only affects speed.
-  const long nblk = gridDim.x, per = (nblk + 7) / 8;
-  const long blk = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  // bijective for any grid size: XCD x owns q+1 blocks if x < r else q  (nblk = 8 q + r)
+  const long nblk = gridDim.x, qn = nblk >> 3, rn = nblk & 7;
+  const long xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const long blk = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
   const long g = blk * 32 + (threadIdx.x >> 3);
-  if (blk >= nblk || g >= total_groups) return;
+  if (g >= total_groups) return;
   const int sub = threadIdx.x & 7;
   const int m = (int)(g % M);
   const long bq = g / M;

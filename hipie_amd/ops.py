@@ -47,9 +47,22 @@ class _Profile(object):
 PROFILE = _Profile()
 
 
+import os as _os
+import sys as _sys
+
+_DEBUG_SYNC = _os.environ.get("HIPIE_DEBUG_SYNC") == "1"      # debugging aid: synchronise + log around every custom op
+
+
 def _timed(tag):
     def deco(fn):
         def wrapper(*a, **k):
+            if _DEBUG_SYNC:
+                torch.cuda.synchronize()
+                print("[hipie] > %s %s" % (fn.__name__, [tuple(t.shape) for t in a if torch.is_tensor(t)]), file=_sys.stderr, flush=True)
+                out = fn(*a, **k)
+                torch.cuda.synchronize()
+                print("[hipie] < %s" % fn.__name__, file=_sys.stderr, flush=True)
+                return out
             end = PROFILE.begin(tag(*a, **k) if callable(tag) else tag) if PROFILE.tags else None
             out = fn(*a, **k)
             if end is not None:

@@ -255,3 +255,27 @@ def test_vit_relpos_tables(name):
         want_w = torch.einsum("bhwc,wkc->bhwk", q, Rw).reshape(B * heads, H * W, W)
         rh, rw = ops.vit_relpos(qkv.to(DEV), th.to(DEV), tw.to(DEV), (H, W), heads)
         assert rel_err(rh.cpu(), want_h) < 1e-5 and rel_err(rw.cpu(), want_w) < 1e-5    # fp32 accumulate of exact products
+
+
+def test_msda_fused_full_scale_strided_aux():
+    """BASELINE-size geometry (Nv = 21760 @1024^2, batch 2), 16-bit value and a single strided bf16 projection tensor for
+    offsets + logits: size-independent property check -- with all logits equal and zero offsets the op is a plain bilinear
+    resample of `value` at the reference points, and it is linear in `value`."""
+    from hipie_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    B, M, D, L, P = 2, 8, 32, 4, 4
+    shapes = torch.tensor([(128, 128), (64, 64), (32, 32), (16, 16)])
+    S = int(shapes.prod(1).sum())
+    Lq = S
+    value = torch.randn(B, S, M, D, generator=gen).bfloat16().to(DEV)
+    proj = (torch.randn(B, Lq, 384, generator=gen) * 0.5).bfloat16().to(DEV)
+    off = proj[..., :256].unflatten(-1, (M, L, P, 2))
+    lg = proj[..., 256:].unflatten(-1, (M, L * P))
+    ref = torch.rand(B, Lq, L, 2, generator=gen).to(DEV)
+    ss, ls = shapes.to(DEV), _lsi(shapes).to(DEV)
+    a = ops.msda_fused(value, ss, ls, ref, off, lg)
+    b = ops.msda_fused(value, ss, ls, ref, off.float().contiguous(), lg.float().contiguous())   # dense fp32 aux, same numbers
+    assert rel_err(a.float().cpu(), b.float().cpu()) < 1e-6
+    c = ops.msda_fused((2 * value.float()).bfloat16(), ss, ls, ref, off, lg)                     # linearity in value
+    assert rel_err(c.float().cpu(), 2 * a.float().cpu()) < 1e-2
+    assert torch.isfinite(a.float()).all()
