@@ -48,12 +48,14 @@ constexpr float kLog2e = 1.4426950408889634f;
 // One wave per SIMD (4 waves, up to 512 registers each): with QB = 2 every K / V^T fragment fetched from LDS feeds two
 // MFMAs and the two query blocks give the scheduler independent MFMA and softmax streams to overlap.
 template <typename T, int HD, int NB, int QB, int WAVES, bool BIAS, bool CLAMP, bool MASKED>
-__global__ __launch_bounds__(WAVES * 64, (WAVES == 8) ? 2 : 1) void flash_attn_kernel(const FAParams p) {
+__global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || HD <= 80) ? 2 : 1) void flash_attn_kernel(const FAParams p) {
   constexpr int KT = 32 * NB;                  // keys per tile
   constexpr int KS = HD / 16;                  // k16 steps of QK^T
   constexpr int DB = (HD + 31) / 32;           // 32-row d blocks of O^T
   constexpr int KSTR = HD + 8;                 // K tile row stride (elements): 16-B aligned, conflict-free b128 reads
-  constexpr int VSTR = DB * 32 + 8;            // V tile row stride (covers the padded d blocks)
+  // V tile row stride: covers the padded d blocks and makes the 4 key rows of one ds_read_b64_tr_b16 land on disjoint
+  // 16-bank windows: (VSTR / 2) % 64 in {16, 48}  (bank = dword address % 64, each row of a 32-lane group spans 16 banks)
+  constexpr int VSTR = (DB * 32 == 96 || DB * 32 == 32) ? DB * 32 : DB * 32 + 32;
   constexpr int CPR = HD / 8;                  // 16-byte chunks per row
   constexpr int NCH = KT * CPR;                // chunks per tile
   constexpr int NT = WAVES * 64;
@@ -61,6 +63,11 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8) ? 2 : 1) void flash_attn_k
   constexpr int BUF = KT * (KSTR + VSTR);      // elements per LDS buffer
   constexpr int NW = (KT + 63) / 64;           // validity words per tile
   constexpr int QPW = 32 * QB;                 // queries per wave
+  // HD = 80 pads O^T to 96 rows: row HD of the padded block is free, so a column of ones at V[:, HD] makes the PV MFMAs
+  // accumulate the softmax denominator  l = sum_k P[k]  there (from the same 16-bit-rounded P as the numerator) -- the 32
+  // per-tile VALU adds of the row sum disappear.
+  constexpr bool LTRICK = (HD % 32) != 0;
+  constexpr int L_ROW = HD % 32, L_HI = (L_ROW >> 2) & 1, L_REG = (L_ROW & 3) + 4 * (L_ROW >> 3);
   typedef typename Mfma32<T>::frag frag;
   typedef typename Mfma32<T>::half_frag hfrag;
 
@@ -93,6 +100,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8) ? 2 : 1) void flash_attn_k
 
   // zero LDS once: the pad columns of the V tile feed the padded d rows of O^T (discarded, but keep them NaN-free)
   for (int i = tid; i < 2 * BUF / 8; i += NT) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  if (LTRICK) {
+    __syncthreads();
+    for (int i = tid; i < 2 * KT; i += NT) smem[(i / KT) * BUF + KT * KSTR + (i % KT) * VSTR + HD] = (T)1.0f;   // never overwritten by tile stores
+  }
 
   // ---- Q fragments (B operand): lane (q = li, half hi) holds Q[q][16 ks + 8 hi + j] ----
   frag qf[QB][KS];
@@ -103,7 +114,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8) ? 2 : 1) void flash_attn_k
       qf[qb][ks] = *reinterpret_cast<const frag*>(Qg + (long)qc[qb] * p.q_st + 16 * ks + 8 * hi);
 
   // ---- bias_w in S^T register order, pre-multiplied by log2(e) (the softmax runs in the exp2 domain) ----
-  constexpr bool BWL = BIAS && (NB <= 2);     // bias_w rows in LDS (frees 16*NB VGPRs per query block); NB = 3 keeps registers
+  // bias_w rows: in LDS for the 8-wave workgroup (one workgroup per CU; frees 16*NB VGPRs so two waves fit per SIMD); in
+  // registers for 4-wave workgroups, whose smaller LDS footprint lets TWO independent workgroups share a CU
+  constexpr bool BWL = BIAS && (NB <= 2) && (WAVES == 8);
   constexpr int BWS = 32 * NB + 4;            // bias_w LDS row stride (floats): 16-B aligned rows, conflict-free b128 reads
   float bw[QB][NB][16];
   // Inside the tile loop the ONLY vector-memory traffic is the prefetch of the next tile (K, V and the 4 x 32 x WAVES
@@ -315,9 +328,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8) ? 2 : 1) void flash_attn_k
         for (int r = 0; r < 16; ++r) {
           const float pv = __builtin_amdgcn_exp2f(S[qb][blk][r] + off);
           S[qb][blk][r] = pv;
-          lsum += pv;
+          if (!LTRICK) lsum += pv;
         }
-      l_run[qb] = l_run[qb] * alpha + lsum;
+      if (!LTRICK) l_run[qb] = l_run[qb] * alpha + lsum;
       if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {   // wave-uniform: no row max moved in this tile -> O stays as is
 #pragma unroll
         for (int d = 0; d < DB; ++d)
@@ -359,7 +372,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8) ? 2 : 1) void flash_attn_k
   // ---- epilogue ----
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
+    const float l_tot = LTRICK ? __shfl(O[qb][DB - 1][L_REG], li + 32 * L_HI) : l_run[qb] + __shfl_xor(l_run[qb], 32);
     const float inv = 1.f / l_tot;
     if (qi[qb] < p.Nq) {
       T* orow = Og + (long)qi[qb] * p.o_st;
@@ -386,9 +399,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8) ? 2 : 1) void flash_attn_k
 template <typename T, int HD, int NB, int QB, int WAVES, bool BIAS, bool CLAMP, bool MASKED>
 static int launch_fa(FAParams& p, hipStream_t st) {
   constexpr int KT = 32 * NB, DB = (HD + 31) / 32;
-  size_t lds = (size_t)2 * KT * ((HD + 8) + (DB * 32 + 8)) * sizeof(T);
+  constexpr int VSTR = (DB * 32 == 96 || DB * 32 == 32) ? DB * 32 : DB * 32 + 32;
+  size_t lds = (size_t)2 * KT * ((HD + 8) + VSTR) * sizeof(T);
   lds += (size_t)2 * WAVES * 32 * QB * sizeof(float);
-  if (BIAS && NB <= 2) lds += (size_t)WAVES * 32 * QB * (32 * NB + 4) * sizeof(float);
+  if (BIAS && NB <= 2 && WAVES == 8) lds += (size_t)WAVES * 32 * QB * (32 * NB + 4) * sizeof(float);
   if (MASKED && p.key_mask != nullptr) lds += ((size_t)p.Nk + 15) / 16 * 16;
   if (lds > 160 * 1024) return set_err(HIPIE_EINVAL, "flash_attn: %zu bytes of LDS needed (Nk=%d) > 160 KiB", lds, p.Nk);
   p.nqt = (p.Nq + WAVES * 32 * QB - 1) / (WAVES * 32 * QB);
@@ -445,8 +459,8 @@ static int flash_attn_impl(FAParams p, int hd, int dtype, void* stream) {
   for (long s : strides) HIPIE_REQUIRE(s % 8 == 0, "flash_attn: strides must be multiples of 8 elements (16 bytes), got %ld", s);
   HIPIE_REQUIRE((((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v | (uintptr_t)p.out) & 15) == 0, "flash_attn: pointers must be 16-byte aligned");
   p.swz = ((p.B * p.H) % 8 == 0) ? 1 : 0;
-  // 8 waves (256 queries) per workgroup halve the K/V traffic per query; worth it once there are enough queries
-  bool wide = p.Nq >= 1024;
+  // 8 waves (256 queries) per workgroup halve the K/V traffic per query but keep all waves of a CU in lockstep
+  bool wide = false;       // measured: two independent 4-wave workgroups per CU (1.09 ms) beat one 8-wave workgroup (1.16 ms)
   const char* e = getenv("HIPIE_FA_WAVES");
   if (e && (e[0] == '4' || e[0] == '8')) wide = (e[0] == '8');
   hipStream_t st = (hipStream_t)stream;
