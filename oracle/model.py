@@ -506,7 +506,10 @@ def coco_inference(images, lang, sd, cfg, task="detection", topk_fg=None, topk_m
     Returns the a22 dict (+ "topk_fg", "topk_md", and stage tensors when want_stages)."""
     x, pad, sizes = preprocess(images, cfg)
     p = "detr.detr."
-    feats = vit_backbone(x, sd, p + "backbone.0.backbone.", cfg)
+    if cfg.get("backbone", "vit") == "r50":
+        feats = resnet50_backbone(x, sd, p + "backbone.0.backbone.")
+    else:
+        feats = vit_backbone(x, sd, p + "backbone.0.backbone.", cfg)
     names = ["res3", "res4", "res5"]
     fmasks = [down_mask(pad, feats[n].shape[-2:]) for n in names]
     poses = [pos_sine(m, cfg["hidden_dim"] // 2) for m in fmasks]
@@ -556,4 +559,33 @@ def coco_inference(images, lang, sd, cfg, task="detection", topk_fg=None, topk_m
         out["_stages"] = dict(feats=feats, poses=poses, fmasks=fmasks4, memory=tr["memory"], hs=hs, inter=inter,
                               lang_hidden=tr["lang_hidden"], mask_head=mh, md_mask_features=mf, md_ms=ms,
                               md_enc_memory=md_mem)
+    return out
+
+
+# --------------------------------------------------------------------------- ResNet-50 backbone (R50 configs 1-2)
+def frozen_bn(x, sd, p, eps=1e-5):
+    """detectron2.layers.FrozenBatchNorm2d (D2/layers/batch_norm.py:44-65): F.batch_norm(training=False)."""
+    return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"], sd[p + "bias"], False, 0.0, eps)
+
+
+def resnet50_backbone(x, sd, p):
+    """detectron2 ResNet-50 (D2/modeling/backbone/resnet.py:330-359 BasicStem, :100-212 BottleneckBlock, :362-470 ResNet) with
+    FrozenBN and STRIDE_IN_1X1 False (stride on the 3x3 conv): 7x7/2 conv + 3x3/2 max-pool, stages [3,4,6,3];
+    returns res3 (512, /8), res4 (1024, /16), res5 (2048, /32)."""
+    x = F.relu(frozen_bn(F.conv2d(x, sd[p + "stem.conv1.weight"], stride=2, padding=3), sd, p + "stem.conv1.norm."))
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    out = {}
+    for si, (name, nblk) in enumerate((("res2", 3), ("res3", 4), ("res4", 6), ("res5", 3))):
+        for b in range(nblk):
+            q = "%s%s.%d." % (p, name, b)
+            stride = 2 if (b == 0 and si > 0) else 1
+            y = F.relu(frozen_bn(F.conv2d(x, sd[q + "conv1.weight"]), sd, q + "conv1.norm."))
+            y = F.relu(frozen_bn(F.conv2d(y, sd[q + "conv2.weight"], stride=stride, padding=1), sd, q + "conv2.norm."))
+            y = frozen_bn(F.conv2d(y, sd[q + "conv3.weight"]), sd, q + "conv3.norm.")
+            sc = x
+            if (q + "shortcut.weight") in sd:
+                sc = frozen_bn(F.conv2d(x, sd[q + "shortcut.weight"], stride=stride), sd, q + "shortcut.norm.")
+            x = F.relu(y + sc)
+        if name != "res2":
+            out[name] = x
     return out

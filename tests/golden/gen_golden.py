@@ -285,28 +285,35 @@ def build_ref_model(c):
     """Assemble HIPIE_IMG.detr (DDETRSegmUniDN) from the reference's own classes, following
     hipie_img.py:77-176 and ddetrs_dn.py:90-215, without detectron2's config/registry layer."""
     cfg = hipie_cfg(c)
-    vit = build_ref_vit(c)
     mb_m = ref("backbone.masked_backbone")
     bb_m = ref("models.deformable_detr.backbone")
     pe_m = ref("models.deformable_detr.position_encoding")
     tr_m = ref("models.deformable_detr.deformable_transformer_dino")
     dd_m = ref("models.deformable_detr.deformable_detr")
     dn_m = ref("models.ddetrs_dn")
-    E = c["vit_embed_dim"]
-    in_shape = {"res3": ref_shim.ShapeSpec(channels=E // 2, stride=8), "res4": ref_shim.ShapeSpec(channels=E, stride=16),
-                "res5": ref_shim.ShapeSpec(channels=E, stride=32)}
+    if c["backbone"] == "r50":     # build_resnet_backbone (D2 resnet.py:614-694) with the R50 yaml's values
+        rn = ref_shim.ref_d2_resnet()
+        vit = rn.ResNet(rn.BasicStem(3, 64, norm="FrozenBN"), rn.ResNet.make_default_stages(50, norm="FrozenBN", stride_in_1x1=False),
+                        out_features=["res3", "res4", "res5"])
+        chans = [512, 1024, 2048]
+    else:
+        vit = build_ref_vit(c)
+        E = c["vit_embed_dim"]
+        chans = [E // 2, E, E]
+    in_shape = {"res3": ref_shim.ShapeSpec(channels=chans[0], stride=8), "res4": ref_shim.ShapeSpec(channels=chans[1], stride=16),
+                "res5": ref_shim.ShapeSpec(channels=chans[2], stride=32)}
 
-    class _D2ViT(vit.__class__):  # D2ViT.forward/output_shape/size_divisibility (vit.py:440-466)
+    class _D2BB(vit.__class__):  # D2ViT.forward/output_shape/size_divisibility (vit.py:440-466)
         size_divisibility = 32
 
         def output_shape(self):
             return in_shape
-    vit.__class__ = _D2ViT
+    vit.__class__ = _D2BB
     masked = mb_m.MaskedBackbone.__new__(mb_m.MaskedBackbone)
     nn.Module.__init__(masked)
     masked.backbone = vit
     masked.feature_strides = [8, 16, 32]
-    masked.num_channels = [E // 2, E, E]
+    masked.num_channels = chans
     backbone = bb_m.Joiner(masked, pe_m.PositionEmbeddingSine(c["hidden_dim"] // 2, normalize=True))
     backbone.num_channels = masked.num_channels
     backbone.strides = masked.feature_strides
@@ -337,8 +344,8 @@ def build_ref_model(c):
     return model.eval()
 
 
-def gen_e2e():
-    c = TINY
+def gen_e2e(c=None, name="e2e_tiny", tasks=(("detection", 9), ("grounding", 1))):
+    c = c or TINY
     model = build_ref_model(c)
     bert = build_ref_bert(c)
     man = _synth.load_synth(model, seed=71)
@@ -364,7 +371,7 @@ def gen_e2e():
         r = real_topk(*a, **k)
         topk_log.append(r[1].clone())
         return r
-    for task, ncls in (("detection", 9), ("grounding", 1)):
+    for task, ncls in tasks:
         ids, mask, pmap = _synth.synth_token_ids(2, ncls, 64, seed=74)
         lang = bert({"input_ids": ids, "attention_mask": mask}, sep=1012)
         arrays[task + "_lang_hidden"] = lang["hidden"].clone()
@@ -382,7 +389,12 @@ def gen_e2e():
         arrays[task + "_topk_fg"] = topk_log[0]
         arrays[task + "_topk_md"] = topk_log[1]
         meta[task] = dict(n_classes=ncls, L=int(ids.shape[1]), pmap={str(k): v for k, v in pmap.items()})
-    save("e2e_tiny", meta, **arrays)
+    save(name, meta, **arrays)
+
+
+def gen_e2e_r50():
+    """the R50 configs (BASELINE configs[0]/[1]): same tiny heads behind the reference's detectron2 ResNet-50."""
+    gen_e2e(dict(TINY, backbone="r50"), "e2e_r50_tiny", (("detection", 9),))
 
 
 # ------------------------------------------------------------------------------ sub-module goldens from the e2e model
@@ -446,8 +458,21 @@ def gen_stages():
     save("stages_tiny", dict(cfg=c, sizes=sizes), **arrays)
 
 
-ALL = dict(msda=gen_msda, vit_attn=gen_vit_attn, vit_backbone=gen_vit_backbone, bi_attn=gen_bi_attn, bert=gen_bert,
-           dynamic_mask=gen_dynamic_mask, e2e=gen_e2e, stages=gen_stages)
+def gen_resnet50():
+    """detectron2 ResNet-50 (the R50 configs' backbone): BasicStem + [3,4,6,3] BottleneckBlocks, FrozenBN, stride in the
+    3x3 conv (STRIDE_IN_1X1 False), outputs res3/res4/res5 -- built from the reference's own resnet.py."""
+    rn = ref_shim.ref_d2_resnet()
+    stem = rn.BasicStem(3, 64, norm="FrozenBN")
+    stages = rn.ResNet.make_default_stages(50, norm="FrozenBN", stride_in_1x1=False)
+    m = rn.ResNet(stem, stages, out_features=["res3", "res4", "res5"]).eval()
+    man = _synth.load_synth(m, seed=81)
+    x = _synth.synth_tensor("r50_in", (1, 3, 64, 96), seed=82) * 2
+    out = m(x)
+    save("resnet50", dict(manifest=man_json(man), x_shape=list(x.shape)), res3=out["res3"], res4=out["res4"], res5=out["res5"])
+
+
+ALL = dict(resnet50=gen_resnet50, msda=gen_msda, vit_attn=gen_vit_attn, vit_backbone=gen_vit_backbone, bi_attn=gen_bi_attn, bert=gen_bert,
+           dynamic_mask=gen_dynamic_mask, e2e=gen_e2e, stages=gen_stages, e2e_r50=gen_e2e_r50)
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)

@@ -114,9 +114,26 @@ class _Registry:
         return self._d[name]
 
 
+class _FrozenBatchNorm2d(nn.Module):
+    """detectron2.layers.FrozenBatchNorm2d (batch_norm.py:13-65): four buffers, F.batch_norm(training=False)."""
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.register_buffer("weight", torch.ones(num_features))
+        self.register_buffer("bias", torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features) - eps)
+
+    def forward(self, x):
+        return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, training=False, eps=self.eps)
+
+
 def _get_norm(norm, out_channels):
     if norm is None or norm == "":
         return None
+    if norm == "FrozenBN":
+        return _FrozenBatchNorm2d(out_channels)
     if norm == "GN":
         return nn.GroupNorm(32, out_channels)
     if norm == "LN":
@@ -266,6 +283,27 @@ def install():
         fn.MSDeformAttnFunction = _Fn
         mod = importlib.import_module(sub + ".modules.ms_deform_attn")
         mod.MSDeformAttnFunction = _Fn
+
+
+def ref_d2_resnet():
+    """load the reference's detectron2/modeling/backbone/resnet.py itself (its package imports are served by the
+    stand-ins above: CNNBlockBase, Conv2d, get_norm(FrozenBN), ShapeSpec, Backbone, BACKBONE_REGISTRY, weight_init)."""
+    install()
+    import importlib.util
+    pkg = types.ModuleType("ref_d2bb")
+    pkg.__path__ = []
+    sys.modules["ref_d2bb"] = pkg
+    bb = types.ModuleType("ref_d2bb.backbone")
+    bb.Backbone = nn.Module
+    sys.modules["ref_d2bb.backbone"] = bb
+    bd = types.ModuleType("ref_d2bb.build")
+    bd.BACKBONE_REGISTRY = _Registry()
+    sys.modules["ref_d2bb.build"] = bd
+    spec = importlib.util.spec_from_file_location("ref_d2bb.resnet", REF_ROOT + "/detectron2/modeling/backbone/resnet.py")
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["ref_d2bb.resnet"] = mod
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def ref(modname):

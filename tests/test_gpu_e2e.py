@@ -17,10 +17,10 @@ KEYS = ["pred_logits", "pred_boxes", "pred_boxious", "pred_masks", "reference_po
         "pred_logits_maskdino", "pred_boxes_maskdino"]
 
 
-def build(precision):
+def build(precision, fixture="e2e_tiny"):
     from hipie_amd.config import HipieConfig
     from hipie_amd.hipie_img import HIPIE_IMG
-    g = Golden("e2e_tiny")
+    g = Golden(fixture)
     cfg = HipieConfig.from_dict(g.meta["cfg"])
     model = HIPIE_IMG(cfg, precision, device="cuda")
     sd = _synth.synth_full_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()})
@@ -63,6 +63,17 @@ def test_e2e_tiny_fast_policy():
     out = model.forward_raw(inputs(g, "detection"))
     for k in KEYS:
         assert rel_err(g.like("detection_" + k, out[k].float().cpu()), g["detection_" + k]) < 5e-2, k
+
+
+def test_e2e_r50_tiny():
+    """the R50 configs (BASELINE configs[0]/[1]): MIOpen ResNet-50 + the same HIP heads; parity then fast policy."""
+    from hipie_amd.config import Precision
+    for prec, tol in ((Precision.parity(), 2e-3), (Precision.fast(), 5e-2)):
+        g, model = build(prec, "e2e_r50_tiny")
+        model.pin_topk(g["detection_topk_fg"], g["detection_topk_md"])
+        out = model.forward_raw(inputs(g, "detection"))
+        for k in KEYS:
+            assert rel_err(g.like("detection_" + k, out[k].float().cpu()), g["detection_" + k]) < tol, (k, str(prec))
 
 
 def test_stage_vit_backbone():

@@ -138,6 +138,16 @@ def test_e2e_tiny(task):
     assert torch.equal(free["topk_md"], g[task + "_topk_md"])
 
 
+def test_e2e_r50_tiny():
+    """BASELINE configs[0]/[1] (R50 backbone): a22 against the reference run behind its own detectron2 ResNet-50."""
+    g = Golden("e2e_r50_tiny")
+    cfg, sd, imgs, ids, mask = e2e_inputs(g, "detection")
+    lang = om.bert_encoder(ids, mask, sd, "text_encoder.body.model.", cfg)
+    out = om.coco_inference(imgs, lang, sd, cfg, task="detection", topk_fg=g["detection_topk_fg"], topk_md=g["detection_topk_md"])
+    for k in E2E_KEYS:
+        assert rel_err(g.like("detection_" + k, out[k]), g["detection_" + k]) < 2e-4, k
+
+
 def test_stages_tiny():
     g = Golden("stages_tiny")
     e = Golden("e2e_tiny")
@@ -158,3 +168,12 @@ def test_stages_tiny():
     assert rel_err(g.like("md_mask_features", st["md_mask_features"]), g["md_mask_features"]) < 1e-4
     for i in range(4):
         assert rel_err(g.like("md_ms%d" % i, st["md_ms"][i]), g["md_ms%d" % i]) < 1e-4
+
+
+def test_resnet50_backbone():
+    g = Golden("resnet50")
+    sd = _synth.synth_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}, seed=81)
+    x = _synth.synth_tensor("r50_in", g.meta["x_shape"], seed=82) * 2
+    out = om.resnet50_backbone(x, sd, "")
+    for k in ("res3", "res4", "res5"):
+        assert rel_err(g.like(k, out[k]), g[k]) < 5e-5
