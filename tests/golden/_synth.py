@@ -164,3 +164,45 @@ def synth_full_state_dict(manifest, seed_detr=71, seed_text=72):
         else:
             raise KeyError(k)
     return out
+
+
+def synth_a22(sizes, n_bg, n_fg, n_md, L, seed=0, stride=4):
+    """a synthetic a22 dictionary (DDETRSegmUniDN.coco_inference's outputs) for the post-processing row: clustered boxes
+    (so NMS has duplicates to remove), token logits with a few confident queries, smooth low-frequency mask logits (so
+    panoptic segments have area).  sizes: [(h, w)] per image; padded canvas = max over images."""
+    B = len(sizes)
+    Hm, Wm = max(s[0] for s in sizes), max(s[1] for s in sizes)
+    hm, wm = Hm // stride, Wm // stride
+    g = _gen(seed, "a22")
+    Q = n_bg + n_fg
+
+    def rnd(*shape):
+        return torch.randn(*shape, generator=g)
+
+    def smooth(n):
+        """one blob per query (logit +5 inside, -5 outside, soft edge) at a random place, plus low-frequency noise: mostly
+        disjoint segments with some overlaps, so the panoptic merge both accepts and rejects segments."""
+        ys = torch.linspace(0, 1, hm).view(1, 1, hm, 1)
+        xs = torch.linspace(0, 1, wm).view(1, 1, 1, wm)
+        cy, cx = torch.rand(B, n, 1, 1, generator=g), torch.rand(B, n, 1, 1, generator=g)
+        r = 0.08 + 0.17 * torch.rand(B, n, 1, 1, generator=g)
+        d = torch.sqrt((ys - cy) ** 2 + (xs - cx) ** 2)
+        blob = 5.0 * torch.tanh((r - d) * 30.0)
+        lo = rnd(B * n, 1, 5, 5)
+        noise = torch.nn.functional.interpolate(lo, size=(hm, wm), mode="bicubic", align_corners=False).view(B, n, hm, wm)
+        return (blob + 0.7 * noise + 0.2 * rnd(B, n, hm, wm)).unsqueeze(2)
+    n_clu = max(3, n_fg // 4)
+    centers = torch.rand(B, n_clu, 4, generator=g) * torch.tensor([0.8, 0.8, 0.4, 0.4]) + torch.tensor([0.1, 0.1, 0.1, 0.1])
+    which = torch.randint(0, n_clu, (B, Q), generator=g)
+    boxes = torch.gather(centers, 1, which[..., None].expand(-1, -1, 4)) + 0.02 * rnd(B, Q, 4)
+    boxes[..., 2:] = boxes[..., 2:].abs().clamp_min(0.02)
+    out = {
+        "pred_logits": rnd(B, Q, L) * 2.5 - 1.0,
+        "pred_boxes": boxes,
+        "pred_boxious": rnd(B, Q, 1) * 2.0 + 0.5,
+        "pred_masks": smooth(Q),
+        "pred_logits_maskdino": rnd(B, n_md, L) * 2.5 - 0.5,
+        "pred_boxes_maskdino": torch.rand(B, n_md, 4, generator=g),
+        "pred_masks_maskdino": smooth(n_md)[:, :, 0],
+    }
+    return out

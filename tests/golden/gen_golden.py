@@ -34,14 +34,14 @@ def NS(**kw):
     return types.SimpleNamespace(**kw)
 
 
-def save(name, meta, **arrays):
+def save(name, meta, _full=(), **arrays):
     """tensors with more than _synth.MAX_ELEMS elements are stored as a strided subsample of the flattened
     tensor (meta["subsampled"][key] = [step, full_shape]); tests compare with _synth.subsample()."""
     out = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()}
     meta = dict(meta)
     meta["subsampled"] = {}
     for k in list(out):
-        if out[k].size > _synth.MAX_ELEMS:
+        if out[k].size > _synth.MAX_ELEMS and k not in _full and not k.startswith(tuple(_full) or ("\0",)):
             step = _synth.sub_step(out[k].size)
             meta["subsampled"][k] = [step, list(out[k].shape)]
             out[k] = out[k].reshape(-1)[::step].copy()
@@ -471,7 +471,62 @@ def gen_resnet50():
     save("resnet50", dict(manifest=man_json(man), x_shape=list(x.shape)), res3=out["res3"], res4=out["res4"], res5=out["res5"])
 
 
-ALL = dict(resnet50=gen_resnet50, msda=gen_msda, vit_attn=gen_vit_attn, vit_backbone=gen_vit_backbone, bi_attn=gen_bi_attn, bert=gen_bert,
+# ------------------------------------------------------------------------------ post-processing
+POST = dict(sizes=[(200, 256), (256, 224)], n_bg=10, n_fg=40, n_md=30, L=64, n_classes=9, seed=91,
+            is_thing={"1": True, "2": True, "3": False, "4": True, "5": False, "6": False, "7": True, "8": True, "9": False})
+POST_CASES = {
+    # hipie/config.py defaults (:255-257)
+    "default": dict(task="detection", use_bg_for_pano=True, bg_cls_agnostic=False, max_pool=False, out_hw=None),
+    # configs/eval/image_joint_r50_pan_maskdino_ade_test.yaml:88-90 + evaluator-style output sizes
+    "evalyaml": dict(task="detection", use_bg_for_pano=False, bg_cls_agnostic=True, max_pool=True, out_hw=[[150, 192], [300, 260]]),
+    "grounding": dict(task="grounding", use_bg_for_pano=True, bg_cls_agnostic=False, max_pool=False, out_hw=None),
+}
+
+
+def gen_post():
+    """HIPIE_IMG.inference (hipie_img.py:537-766) + panoptic_inference (:473-535) + semantic_inference (:870-878) +
+    convert_grounding_to_od_logits (:1025-1052) + segmentation_postprocess (ddetrs.py:1029-1076), executed from the
+    reference's own files on a synthetic a22 dictionary; CLIP fusion off (row f-2)."""
+    m = ref_shim.ref_hipie_img()
+    dd = ref("models.ddetrs")
+    P = POST
+    a22 = _synth.synth_a22([tuple(s) for s in P["sizes"]], P["n_bg"], P["n_fg"], P["n_md"], P["L"], seed=P["seed"])
+    _, _, pmap = _synth.synth_token_ids(2, P["n_classes"], P["L"], seed=74)
+    is_thing = {int(k): v for k, v in P["is_thing"].items()}
+    arrays, meta = {}, dict(post=P, cases=POST_CASES, pmap={str(k): v for k, v in pmap.items()})
+    for cname, c in POST_CASES.items():
+        me = NS(num_bg=P["n_bg"], num_fg=P["n_fg"], ota=True, mode_free_inference=False, max_pool_token_test=c["max_pool"],
+                enable_clip=False, demo_only=False, mask_on=True, mask_stride=4, mask_thres=0.5,
+                use_bg_for_pano=c["use_bg_for_pano"], bg_cls_agnostic=c["bg_cls_agnostic"], transform_eval=True, pano_temp=0.06,
+                object_mask_threshold=0.25, overlap_threshold=0.8,
+                detr=NS(bg_query_from_lang=False, decouple_decoder=True, mask_dino_fixed_linear_head=False))
+        for fn in ("semantic_inference", "panoptic_inference"):
+            setattr(me, fn, types.MethodType(getattr(m.HIPIE_IMG, fn), me))
+        sizes = [tuple(s) for s in P["sizes"]]
+        out_hw = [tuple(x) for x in c["out_hw"]] if c["out_hw"] else sizes
+        grounding = c["task"] == "grounding"
+        pm = {1: [0]} if grounding else pmap                                       # hipie_img.py:322-326
+        out = {k: v.clone() for k, v in a22.items()}
+        res = m.HIPIE_IMG.inference(me, out["pred_logits"], out["pred_boxes"], out["pred_masks"], sizes, pm, len(pm),
+                                    task=c["task"], iou_pred=out["pred_boxious"], is_thing=[is_thing] * len(sizes),
+                                    sizes=out_hw, output=out, bg_queries_lang=None, test_labels=None, images=None)
+        for i, r in enumerate(res):
+            inst = dd.segmentation_postprocess(r["instances"], out_hw[i][0], out_hw[i][1])   # hipie_img.py:358-362
+            pre = "%s_%d_" % (cname, i)
+            arrays[pre + "boxes"] = inst.pred_boxes.tensor
+            arrays[pre + "scores"] = inst.scores
+            arrays[pre + "classes"] = inst.pred_classes
+            arrays[pre + "masks"] = np.packbits(inst.pred_masks.numpy().astype(bool), axis=None)
+            meta[pre + "masks_shape"] = list(inst.pred_masks.shape)
+            if not grounding:
+                pan, info = r["panoptic_seg"]
+                arrays[pre + "panoptic"] = pan.to(torch.int16)
+                meta[pre + "segments"] = info
+                arrays[pre + "semseg"] = r["sem_seg"]
+    save("post", meta, _full=tuple(k for k in arrays if k.endswith(("masks", "panoptic"))), **arrays)
+
+
+ALL = dict(post=gen_post, resnet50=gen_resnet50, msda=gen_msda, vit_attn=gen_vit_attn, vit_backbone=gen_vit_backbone, bi_attn=gen_bi_attn, bert=gen_bert,
            dynamic_mask=gen_dynamic_mask, e2e=gen_e2e, stages=gen_stages, e2e_r50=gen_e2e_r50)
 
 if __name__ == "__main__":

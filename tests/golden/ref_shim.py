@@ -306,6 +306,78 @@ def ref_d2_resnet():
     return mod
 
 
+def tv_batched_nms(boxes, scores, idxs, iou_threshold):
+    """torchvision.ops.batched_nms -- THIRD-PARTY, absent from /root/reference and from this image (the reference does not
+    pin a torchvision version; INSTALL follows detectron2's "torchvision matching the PyTorch install").  Restated from the
+    published algorithm: boxes.numel() <= 4000 -> coordinate trick (offset every box by idx * (max_coordinate + 1)), then
+    greedy NMS (torchvision/csrc/ops/cpu/nms_kernel.cpp: stable descending sort by score; IoU = inter / (a_i + a_j - inter),
+    suppress when IoU > threshold); keep indices are returned in decreasing-score order."""
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64)
+    if boxes.numel() > 4000:
+        keep_mask = torch.zeros_like(scores, dtype=torch.bool)
+        for c in torch.unique(idxs):
+            ci = torch.where(idxs == c)[0]
+            keep_mask[ci[_tv_nms(boxes[ci], scores[ci], iou_threshold)]] = True
+        k = torch.where(keep_mask)[0]
+        return k[scores[k].sort(descending=True)[1]]
+    max_coordinate = boxes.max()
+    offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+    return _tv_nms(boxes + offsets[:, None], scores, iou_threshold)
+
+
+def _tv_nms(boxes, scores, thr):
+    x1, y1, x2, y2 = boxes.unbind(1)
+    areas = (x2 - x1) * (y2 - y1)
+    order = scores.sort(dim=0, descending=True, stable=True)[1]
+    n = boxes.shape[0]
+    dead = [False] * n
+    keep = []
+    for _i in range(n):
+        i = int(order[_i])
+        if dead[i]:
+            continue
+        keep.append(i)
+        for _j in range(_i + 1, n):
+            j = int(order[_j])
+            if dead[j]:
+                continue
+            w = torch.clamp(torch.min(x2[i], x2[j]) - torch.max(x1[i], x1[j]), min=0)
+            h = torch.clamp(torch.min(y2[i], y2[j]) - torch.max(y1[i], y1[j]), min=0)
+            inter = w * h
+            if float(inter / (areas[i] + areas[j] - inter)) > thr:
+                dead[j] = True
+    return torch.tensor(keep, dtype=torch.int64)
+
+
+def ref_hipie_img():
+    """the reference's hipie_img.py itself (for HIPIE_IMG.inference / panoptic_inference / semantic_inference /
+    convert_grounding_to_od_logits and ddetrs.segmentation_postprocess), with the data pipeline / SAM / MaskCLIP
+    sub-packages it imports at module level left as inert stubs, detectron2's own (vendored, dependency-free)
+    structures/{boxes,instances}.py loaded from /root/reference, and torchvision's batched_nms restated above."""
+    install()
+    import importlib.util
+    for n in ("hipie_ref.data", "hipie_ref.data.coco_dataset_mapper_uni", "hipie_ref.models.sam", "hipie_ref.open_vocab.clip"):
+        if n not in sys.modules:
+            mod = _StubModule(n)
+            mod.__path__ = []
+            sys.modules[n] = mod
+    m = ref("hipie_img")
+    st = {}
+    for name in ("boxes", "instances"):
+        spec = importlib.util.spec_from_file_location("ref_d2st." + name, REF_ROOT + "/detectron2/structures/%s.py" % name)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        st[name] = mod
+    dd = ref("models.ddetrs")
+    for tgt in (m, dd):
+        tgt.Instances = st["instances"].Instances
+        tgt.Boxes = st["boxes"].Boxes
+    m.retry_if_cuda_oom = lambda f: f
+    m.ops = types.SimpleNamespace(batched_nms=tv_batched_nms)
+    return m
+
+
 def ref(modname):
     """import ``hipie_ref.<modname>`` (a module path below projects/HIPIE/hipie)."""
     install()
