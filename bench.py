@@ -146,7 +146,9 @@ def main():
 
     def local_step():
         out = model.forward_raw(batch)
-        res = inference(model, out, batch)
+        # the step ends at the compact per-image predictions that the data-parallel all-gather carries;
+        # instance masks and the semantic/panoptic maps of the full post-processing are timed separately below
+        res = inference(model, out, batch, with_masks=False, with_sem_pan=False)
         return parallel.compact_predictions(res, topk=100, device=dev)
 
     def step():

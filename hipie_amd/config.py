@@ -83,6 +83,18 @@ class HipieConfig:
     pixel_std: List[float] = field(default_factory=lambda: [58.395, 57.120, 57.375])
     log_scale: float = 0.0
     prior_prob: float = 0.01
+    # post-processing (hipie_img.py:60-135: values of hipie/config.py:190-257; the eval yamls override the last three)
+    ota: bool = True
+    mask_thres: float = 0.5
+    transform_eval: bool = True
+    pano_temp: float = 0.06
+    overlap_threshold: float = 0.8
+    object_mask_threshold: float = 0.25
+    mode_free: bool = False
+    nms_thresh: float = 0.7                     # hipie_img.py:629 (literal)
+    use_bg_for_pano: bool = True
+    bg_cls_agnostic: bool = False
+    max_pool: bool = False
 
     # ---- presets -------------------------------------------------------------------------------------------
     @staticmethod
@@ -138,6 +150,10 @@ class HipieConfig:
         c.lang_dim = m.LANGUAGE_BACKBONE.LANG_DIM
         c.pixel_mean, c.pixel_std = list(m.PIXEL_MEAN), list(m.PIXEL_STD)
         c.log_scale, c.prior_prob = m.DYHEAD.LOG_SCALE, m.DYHEAD.PRIOR_PROB
+        c.ota, c.mask_thres, c.mode_free = m.OTA, d.MASK_THRES, m.MODE_FREE_MATCHING_INFERENCE
+        c.transform_eval, c.pano_temp = m.PANO_TRANSFORM_EVAL, m.PANO_TEMPERATURE
+        c.overlap_threshold, c.object_mask_threshold = m.OVERLAP_THRESHOLD, m.OBJECT_MASK_THRESHOLD
+        c.use_bg_for_pano, c.bg_cls_agnostic, c.max_pool = cfg.TEST.USE_BG_FOR_PANO_ON, cfg.TEST.BG_CLS_AGNOSTIC, cfg.TEST.MAX_POOL
         if md_cfg is not None:
             md, sh = md_cfg.MODEL.MaskDINO, md_cfg.MODEL.SEM_SEG_HEAD
             c.md_num_queries, c.md_dec_layers, c.md_dim_feedforward = md.NUM_OBJECT_QUERIES, md.DEC_LAYERS, md.DIM_FEEDFORWARD

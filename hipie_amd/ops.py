@@ -253,6 +253,38 @@ def add_layernorm(x, delta, weight, bias, eps, norm_dtype, want_res=True):
     return (x if delta is None else res), out
 
 
+@_timed("batched_nms")
+def batched_nms(boxes, scores, classes, iou_threshold, coordinate_trick=None):
+    """boxes (B,Q,4) normalised cxcywh, scores (B,Q), classes (B,Q) int64 -> keep (B,Q) int32 (query indices in
+    decreasing-score order, -1 padded), count (B) int32.  torchvision.ops.batched_nms semantics per image."""
+    lib = _lib.load()
+    B, Q = scores.shape
+    if coordinate_trick is None:
+        coordinate_trick = Q * 4 <= 4000                  # torchvision/ops/boxes.py batched_nms switch
+    order = scores.sort(dim=1, descending=True, stable=True)[1].to(torch.int32)
+    keep = torch.empty(B, Q, dtype=torch.int32, device=boxes.device)
+    count = torch.empty(B, dtype=torch.int32, device=boxes.device)
+    rc = lib.hipie_batched_nms(_chk(boxes, "boxes", torch.float32), _chk(classes, "classes", torch.int64), order.data_ptr(),
+                               keep.data_ptr(), count.data_ptr(), B, Q, float(iou_threshold), int(coordinate_trick), _stream())
+    _lib.check(rc, "hipie_batched_nms")
+    return keep, count
+
+
+@_timed("mask_finalize")
+def mask_finalize(masks, qidx, up, crop_hw, out_hw, threshold):
+    """masks (Q,hm,wm) stride-`up` logits, qidx (n) int32 rows (or None) -> (n,out_h,out_w) uint8:
+    bilinear x`up` -> sigmoid > threshold -> crop -> nearest resize to out_hw."""
+    lib = _lib.load()
+    Q, hm, wm = masks.shape
+    n = Q if qidx is None else int(qidx.shape[0])
+    out = torch.empty(n, out_hw[0], out_hw[1], dtype=torch.uint8, device=masks.device)
+    rc = lib.hipie_mask_finalize(_chk(masks, "masks"), _DT[masks.dtype], None if qidx is None else _chk(qidx, "qidx", torch.int32),
+                                 n, hm, wm, int(up), int(crop_hw[0]), int(crop_hw[1]), int(out_hw[0]), int(out_hw[1]),
+                                 float(threshold), out.data_ptr(), _stream())
+    _lib.check(rc, "hipie_mask_finalize")
+    return out
+
+
 def selftest(which, a, b=None):
     lib = _lib.load()
     out = torch.empty(32 * 32 if which == 0 else 256, dtype=torch.float32, device=a.device)

@@ -39,14 +39,14 @@ def shard_range(total, rank, world):
 def compact_predictions(results, topk=100, device=None):
     """list of per-image result dicts (postprocess.inference) -> (n_img, topk, PRED_FIELDS) float32 block, zero padded."""
     n = len(results)
-    dev = device or results[0]["instances"]["scores"].device
+    dev = device or results[0]["instances"].scores.device
     block = torch.zeros(n, topk, PRED_FIELDS, dtype=torch.float32, device=dev)
     for i, r in enumerate(results):
         inst = r["instances"]
-        k = min(topk, inst["scores"].shape[0])
-        block[i, :k, :4] = inst["pred_boxes"][:k]
-        block[i, :k, 4] = inst["scores"][:k]
-        block[i, :k, 5] = inst["pred_classes"][:k].float()
+        k = min(topk, inst.scores.shape[0])
+        block[i, :k, :4] = inst.pred_boxes.tensor[:k]
+        block[i, :k, 4] = inst.scores[:k]
+        block[i, :k, 5] = inst.pred_classes[:k].float()
         block[i, :k, 6] = torch.arange(k, device=dev, dtype=torch.float32)
     return block
 

@@ -1,66 +1,256 @@
-"""Per-image post-processing after the parity surface (HIPIE_IMG.inference, hipie_img.py:537-766).
+"""Post-processing after the parity surface, on the device and batched.
 
-Round-1 scope: token logits -> class scores (convert_grounding_to_od_logits, hipie_img.py:1025-1052, mean pooling over each
-class's token span), score = sqrt(sigmoid(cls) * sigmoid(iou)) (hipie_img.py:610-617), top-k instances with their masks
-up-sampled to the image and thresholded.  NMS, CLIP fusion and the panoptic merge are the next row.
+Mirrors HIPIE_IMG.inference (projects/HIPIE/hipie/hipie_img.py:537-766), panoptic_inference (:473-535), semantic_inference
+(:870-878), convert_grounding_to_od_logits (:1025-1052) and segmentation_postprocess (hipie/models/ddetrs.py:1029-1076)
+for decouple_decoder True / bg_query_from_lang False / demo_only False / score_thres 0 (the shipped eval settings);
+MaskCLIP score fusion is the next row (f-2) and raises if requested.
+
+What changed relative to the reference's per-image, per-class, per-segment Python loops:
+  * token -> class pooling is one GEMM (mean) or one padded gather + max for the whole batch, FG/BG masking a `where`;
+  * NMS is hipie_batched_nms (one launch for the batch, suppression matrix in LDS, bit-exact keep lists);
+  * the top-100 selection, box conversion / scaling / clipping are batched; one host sync fetches the per-image counts;
+  * instance masks go through hipie_mask_finalize (x4 bilinear -> sigmoid -> threshold -> crop -> nearest resize, one pass);
+  * the panoptic merge has no .item() loop: segment areas are bincounts, the first-come-first-served id assignment with
+    stuff merging is a cumulative sum + first-occurrence scatter, the label map one LUT gather; segments_info is built
+    from a single small device->host copy per batch.
 """
 import torch
 import torch.nn.functional as F
 
+from . import ops
+from .structures import Boxes, Instances
 
-_PMAP_CACHE = {}
+NEG = -9999.0                                              # the reference's "class not allowed" logit (hipie_img.py:1047-1050)
+_CACHE = {}
+
+
+def _cached(key, build):
+    v = _CACHE.get(key)
+    if v is None:
+        if len(_CACHE) > 64:
+            _CACHE.clear()
+        v = _CACHE[key] = build()
+    return v
+
+
+def _pmap_key(positive_map):
+    return tuple((int(k), tuple(v)) for k, v in positive_map.items())
 
 
 def positive_map_matrix(positive_map, L, device):
-    """(L, num_classes) matrix M with M[t, c] = 1/len(tokens of class c+1) so that token scores @ M is the per-class mean of
-    convert_grounding_to_od_logits (hipie_img.py:1041-1049) -- one GEMM for the whole batch instead of a Python loop of
-    per-class gathers.  Cached per prompt (the prompt is fixed over an evaluation run)."""
-    key = (id(positive_map), L, str(device))
-    m = _PMAP_CACHE.get(key)
-    if m is None:
+    """(L, C) matrix M, M[t, c] = 1/len(tokens of class c+1): token logits @ M is the per-class mean of
+    convert_grounding_to_od_logits (hipie_img.py:1041-1046).  Cached per prompt."""
+    def build():
         m = torch.zeros(L, len(positive_map))
         for label_j, toks in positive_map.items():
             m[list(toks), int(label_j) - 1] = 1.0 / len(toks)
-        m = m.to(device)
-        _PMAP_CACHE[key] = m
-    return m
+        return m.to(device)
+    return _cached(("mean", _pmap_key(positive_map), L, str(device)), build)
 
 
-def convert_grounding_to_od_logits(logits, num_classes, positive_map):
-    """logits (..., Q, L) token scores -> (..., Q, num_classes) mean over each class's token span."""
-    return logits @ positive_map_matrix(positive_map, logits.shape[-1], logits.device)
+def positive_map_table(positive_map, device):
+    """(C, T) padded token-index table + validity mask for the max-pool variant (TEST.MAX_POOL, hipie_img.py:1043-1044)."""
+    def build():
+        C = len(positive_map)
+        T = max(len(v) for v in positive_map.values())
+        idx = torch.zeros(C, T, dtype=torch.long)
+        ok = torch.zeros(C, T, dtype=torch.bool)
+        for label_j, toks in positive_map.items():
+            idx[int(label_j) - 1, :len(toks)] = torch.as_tensor(list(toks))
+            ok[int(label_j) - 1, :len(toks)] = True
+        return idx.to(device), ok.to(device)
+    return _cached(("max", _pmap_key(positive_map), str(device)), build)
 
 
-def inference(model, out, batched_inputs, topk=100):
-    """batched over the images (no per-image / per-class Python loops on the device path)."""
-    task = batched_inputs[0]["task"]
-    nbg = model.cfg.num_bg_queries
-    sizes = out["image_sizes"]
-    B = len(batched_inputs)
-    logits = out["pred_logits"][:, nbg:].float().sigmoid()               # (B, Q, L)
-    iou = out["pred_boxious"][:, nbg:].float().sigmoid()                 # (B, Q, 1)
-    if task == "grounding":
-        cls = logits
+def thing_vector(is_thing, num_classes, device):
+    """(C) bool, True where class c+1 is a thing (missing keys default to thing, hipie_img.py:509,1047)."""
+    key = ("thing", tuple(sorted((int(k), bool(v)) for k, v in is_thing.items())), num_classes, str(device))
+    return _cached(key, lambda: torch.tensor([bool(is_thing.get(c + 1, True)) for c in range(num_classes)], device=device))
+
+
+def convert_grounding_to_od_logits(logits, num_classes, positive_map, is_thing=None, mode=None, model_free=False, max_pool=False):
+    """logits (B, Q, L) -> (B, Q, num_classes).  is_thing: list (one dict per image) or a single dict; mode: None | "FG" | "BG"
+    or a list of them per image."""
+    assert logits.dim() == 3
+    B = logits.shape[0]
+    if max_pool:
+        idx, ok = positive_map_table(positive_map, logits.device)
+        scores = torch.where(ok, logits[:, :, idx], logits.new_tensor(float("-inf"))).amax(-1)
     else:
-        pmap = batched_inputs[0].get("positive_map_label_to_token", {1: [0]})
-        cls = convert_grounding_to_od_logits(logits, len(pmap), pmap)
-    score = torch.sqrt(cls * iou)                                         # (B, Q, C)
-    C = score.shape[-1]
-    k = min(topk, score.shape[1] * C)
-    top, idx = score.flatten(1).topk(k, dim=1)                            # (B, k)
-    qi, ci = idx // C, idx % C
-    boxes = torch.gather(out["pred_boxes"][:, nbg:].float(), 1, qi.unsqueeze(-1).expand(-1, -1, 4))
-    wh = torch.tensor([[w, h, w, h] for (h, w) in sizes], dtype=torch.float32, device=boxes.device).unsqueeze(1) \
-        if not hasattr(model, "_wh_cache") or model._wh_cache[0] != tuple(sizes) else model._wh_cache[1]
-    model._wh_cache = (tuple(sizes), wh)
-    cx, cy, bw, bh = boxes.unbind(-1)
-    xyxy = torch.stack([cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], -1) * wh
-    pm = out["pred_masks"][:, nbg:, 0]                                    # (B, Q, H/4, W/4)
-    m = torch.gather(pm, 1, qi[:, :, None, None].expand(-1, -1, pm.shape[-2], pm.shape[-1]))
-    m = F.interpolate(m.float(), scale_factor=model.mask_stride, mode="bilinear", align_corners=False) > 0.0   # sigmoid > 0.5
+        scores = logits @ positive_map_matrix(positive_map, logits.shape[-1], logits.device)
+    modes = list(mode) if isinstance(mode, (list, tuple)) else [mode] * B
+    if model_free or all(m is None for m in modes):
+        return scores
+    things = is_thing if isinstance(is_thing, (list, tuple)) else [is_thing or {}] * B
+    block = []
+    for b in range(B):
+        tv = thing_vector(things[b], num_classes, logits.device)
+        block.append(~tv if modes[b] == "FG" else tv if modes[b] == "BG" else torch.zeros_like(tv))
+    return torch.where(torch.stack(block)[:, None, :], scores.new_tensor(NEG), scores)
+
+
+def _cxcywh_to_xyxy(b):
+    cx, cy, w, h = b.unbind(-1)
+    return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], -1)
+
+
+# ------------------------------------------------------------------------------------------------ panoptic / semantic
+def _sem_pan(cls_all, masks_lo, stride, crop_hw, out_hw, thing_vec, cfg):
+    """semantic_inference + the tensor part of panoptic_inference for one image.
+    cls_all (N, C) class probabilities, masks_lo (N, hm, wm) stride-`stride` logits.  Returns sem_seg (C, oh, ow) and a
+    dict of device tensors describing the panoptic result (label map + per-segment table)."""
+    N, C = cls_all.shape
+    up = F.interpolate(masks_lo[:, None].float(), scale_factor=float(stride), mode="bilinear", align_corners=False)
+    up = up[:, :, :crop_hw[0], :crop_hw[1]]
+    if tuple(out_hw) != tuple(crop_hw):
+        up = F.interpolate(up, size=tuple(out_hw), mode="bilinear", align_corners=False)
+    sig = up[:, 0].sigmoid_()                                                   # (N, oh, ow)
+    oh, ow = sig.shape[-2:]
+    sem = (cls_all.t() @ sig.view(N, -1)).view(C, oh, ow)                       # einsum("qc,qhw->chw")
+    scores, labels = cls_all.max(-1)
+    kept = scores > cfg.object_mask_threshold
+    w = torch.where(kept, scores, scores.new_tensor(-1.0))                      # never wins the argmax unless nothing is kept
+    ids = (w.view(-1, 1, 1) * sig).argmax(0)                                    # (oh, ow) index into N
+    own = sig.gather(0, ids[None])[0] >= 0.5                                    # the winner's own mask >= 0.5
+    flat = ids.view(-1)
+    mask_area = torch.bincount(flat, minlength=N)
+    inter_area = torch.bincount(flat[own.view(-1)], minlength=N)
+    orig_area = (sig >= 0.5).view(N, -1).sum(1)
+    ratio_ok = mask_area.double() / orig_area.clamp_min(1).double() >= cfg.overlap_threshold
+    valid = kept & (mask_area > 0) & (orig_area > 0) & (inter_area > 0) & ratio_ok
+    isthing = thing_vec[labels]
+    # first-come-first-served ids; a stuff class re-uses the id of its first valid segment (hipie_img.py:519-527)
+    ar = torch.arange(N, device=cls_all.device)
+    stuff = valid & ~isthing
+    first_of_class = torch.full((C,), N, dtype=torch.long, device=cls_all.device)
+    first_of_class.scatter_reduce_(0, labels[stuff], ar[stuff], reduce="amin")
+    is_first = stuff & (first_of_class[labels] == ar)
+    new = valid & (isthing | is_first)
+    new_id = torch.cumsum(new.to(torch.int32), 0, dtype=torch.int32)
+    seg_id = torch.where(new, new_id, new_id[first_of_class[labels].clamp_max(N - 1)])
+    seg_id = torch.where(valid, seg_id, torch.zeros_like(seg_id))
+    pan = torch.where(own, seg_id[ids], torch.zeros_like(seg_id[ids])).to(torch.int32)
+    return sem, dict(pan=pan, new=new, labels=labels, isthing=isthing, valid=valid)
+
+
+def _segments_info(tables):
+    """one device->host copy for the whole batch -> the reference's segments_info lists (hipie_img.py:529-535)."""
+    if not tables:
+        return []
+    lens = [int(t["new"].numel()) for t in tables]
+    packed = torch.cat([torch.stack([t["new"].long(), t["labels"].long(), t["isthing"].long()]) for t in tables], 1).cpu()
+    out, st = [], 0
+    for n in lens:
+        new, lab, thing = packed[:, st:st + n].tolist()
+        st += n
+        info, sid = [], 0
+        for k in range(n):
+            if new[k]:
+                sid += 1
+                info.append({"id": sid, "isthing": bool(thing[k]), "category_id": int(lab[k])})
+        out.append(info)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ the entry point
+@torch.no_grad()
+def inference(model, out, batched_inputs, do_postprocess=True, with_masks=True, with_sem_pan=True):
+    """a22 dictionary -> list of {"instances": Instances, "panoptic_seg": (label map, segments_info), "sem_seg"} like
+    HIPIE_IMG.forward's eval branch (hipie_img.py:313-362).  with_masks / with_sem_pan False skip the instance masks /
+    the semantic + panoptic maps (e.g. a detection-only consumer, or the compact all-gather block of parallel.py)."""
+    cfg = model.cfg
+    if getattr(model, "enable_clip", False):
+        raise NotImplementedError("MaskCLIP score fusion (MODEL.CLIP.ENABLED) is not part of this build (SURVEY 8f-2)")
+    task = batched_inputs[0]["task"]
+    max_num_inst = {"detection": 100, "grounding": 1}[task]
+    nbg, s = cfg.num_bg_queries, cfg.mask_stride
+    image_sizes = [tuple(x) for x in out["image_sizes"]]
+    B = len(image_sizes)
+    dev = out["pred_logits"].device
+    out_sizes = [(int(x.get("height", sz[0])), int(x.get("width", sz[1]))) for x, sz in zip(batched_inputs, image_sizes)]
+    if not do_postprocess:
+        out_sizes_inst = image_sizes
+    else:
+        out_sizes_inst = out_sizes
+    pmap = {1: [0]} if task == "grounding" else batched_inputs[0]["positive_map_label_to_token"]      # hipie_img.py:322-326
+    C = len(pmap)
+    is_thing = [x.get("is_thing", {}) for x in batched_inputs]
+    has_thing = [any(t.values()) for t in is_thing]
+
+    box_cls, box_pred = out["pred_logits"][:, nbg:].float(), out["pred_boxes"][:, nbg:].float().contiguous()
+    iou = out["pred_boxious"][:, nbg:].float()
+    pred_masks = out["pred_masks"][:, nbg:, 0]                                   # (B, Q, hm, wm)
+    Q = box_cls.shape[1]
+    logits = convert_grounding_to_od_logits(box_cls, C, pmap, is_thing, ["FG" if h else None for h in has_thing],
+                                            cfg.mode_free, cfg.max_pool)        # (B, Q, C)
+    prob = torch.sqrt(logits.sigmoid() * iou.sigmoid())
+    if cfg.ota:
+        nms_scores, idxs = prob.max(2)
+        keep, count = ops.batched_nms(box_pred, nms_scores.contiguous(), idxs.contiguous(), cfg.nms_thresh)
+    else:
+        if task == "detection" and not cfg.use_bg_for_pano:
+            raise ValueError("OTA off needs TEST.USE_BG_FOR_PANO_ON (the reference has no NMS keep list in that branch)")
+        keep = torch.arange(Q, device=dev, dtype=torch.int32).expand(B, Q).contiguous()
+        count = torch.full((B,), Q, dtype=torch.int32, device=dev)
+    keep_l = keep.long().clamp_min(0)
+    rows_ok = torch.arange(Q, device=dev)[None, :] < count[:, None]             # (B, Q) kept rows, score order
+    prob_k = torch.gather(prob, 1, keep_l[:, :, None].expand(-1, -1, C))
+    prob_k = torch.where(rows_ok[:, :, None], prob_k, prob_k.new_tensor(-2.0))
+    K = min(max_num_inst, Q * C)
+    top_v, top_i = torch.topk(prob_k.flatten(1), K, dim=1)
+    top_row, labels = torch.div(top_i, C, rounding_mode="floor"), top_i % C
+    top_q = torch.gather(keep_l, 1, top_row)                                     # fg query index of every instance
+    boxes = _cxcywh_to_xyxy(torch.gather(box_pred, 1, top_q[:, :, None].expand(-1, -1, 4)))
+    wh = _cached(("wh", tuple(image_sizes), str(dev)),
+                 lambda: torch.tensor([[w, h, w, h] for (h, w) in image_sizes], dtype=torch.float32, device=dev)[:, None, :])
+    boxes = boxes * wh
+    # segmentation_postprocess: scale to the output resolution, clip, drop empty boxes (ddetrs.py:1046-1063)
+    sc = _cached(("sc", tuple(image_sizes), tuple(out_sizes_inst), str(dev)), lambda: torch.tensor(
+        [[ow / w, oh / h, ow / w, oh / h] for (h, w), (oh, ow) in zip(image_sizes, out_sizes_inst)], dtype=torch.float32, device=dev)[:, None, :])
+    lim = _cached(("lim", tuple(out_sizes_inst), str(dev)), lambda: torch.tensor(
+        [[ow, oh, ow, oh] for (oh, ow) in out_sizes_inst], dtype=torch.float32, device=dev)[:, None, :])
+    if do_postprocess:
+        boxes = torch.minimum((boxes * sc).clamp_min(0), lim)
+        nonempty = ((boxes[..., 2] - boxes[..., 0]) > 0) & ((boxes[..., 3] - boxes[..., 1]) > 0)
+    else:
+        nonempty = torch.ones(boxes.shape[:2], dtype=torch.bool, device=dev)
+    n_inst = torch.minimum(count.long() * C, count.new_tensor(K).long())         # num_inst = min(max_num_inst, prob.numel())
+    ok = (torch.arange(K, device=dev)[None, :] < n_inst[:, None]) & nonempty
+    ok_h, count_h = ok.cpu(), None                                               # the one host sync of the instance path
     results = []
+    tables = []
     for i in range(B):
-        h, w = sizes[i]
-        results.append({"instances": {"pred_boxes": xyxy[i], "scores": top[i], "pred_classes": ci[i],
-                                      "pred_masks": m[i, :, :h, :w]}})
+        sel = torch.nonzero(ok_h[i]).flatten().to(dev)
+        inst = Instances(out_sizes_inst[i])
+        inst.pred_boxes = Boxes(boxes[i][sel])
+        inst.scores = top_v[i][sel]
+        inst.pred_classes = labels[i][sel]
+        qidx = top_q[i][sel].to(torch.int32).contiguous()
+        if with_masks:
+            inst.pred_masks = ops.mask_finalize(pred_masks[i].contiguous(), qidx, s, image_sizes[i], out_sizes_inst[i], cfg.mask_thres)
+        res = {"instances": inst, "panoptic_seg": (None, None), "sem_seg": None}
+        results.append(res)
+    if task == "detection" and with_sem_pan:
+        md_logits = out["pred_logits_maskdino"].float()
+        md_masks = out["pred_masks_maskdino"]
+        mode = None if (cfg.use_bg_for_pano or cfg.bg_cls_agnostic) else "BG"
+        logits_bg = convert_grounding_to_od_logits(md_logits, C, pmap, is_thing, mode, cfg.mode_free, cfg.max_pool)
+        if not cfg.use_bg_for_pano:
+            count_h = count.tolist()
+        for i in range(B):
+            if cfg.use_bg_for_pano:
+                logits_all, masks_all = logits_bg[i], md_masks[i]
+            else:
+                k = keep_l[i, :count_h[i]]
+                logits_all = torch.cat([logits[i][k], logits_bg[i]], 0)
+                masks_all = torch.cat([pred_masks[i][k], md_masks[i].to(pred_masks.dtype)], 0)
+            if cfg.transform_eval:
+                cls_all = F.softmax(logits_all.sigmoid() / cfg.pano_temp, dim=-1)
+            else:
+                cls_all = logits_all.sigmoid()
+            sem, tab = _sem_pan(cls_all, masks_all, s, image_sizes[i], out_sizes[i], thing_vector(is_thing[i], C, dev), cfg)
+            results[i]["sem_seg"] = sem
+            tables.append(tab)
+        for i, info in enumerate(_segments_info(tables)):
+            results[i]["panoptic_seg"] = (tables[i]["pan"], info)
     return results

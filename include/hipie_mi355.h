@@ -156,6 +156,29 @@ int hipie_add_layernorm(const void* x, const void* delta, const float* gamma, co
                         void* norm_out, int64_t rows, int C, float eps, int x_dtype, int delta_dtype, int norm_dtype,
                         void* stream);
 
+/*
+ * Batched (class-aware) NMS for one batch of images, the device form of the per-image
+ *   keep_indices = torchvision.ops.batched_nms(box_cxcywh_to_xyxy(box_pred), nms_scores, idxs, 0.7)
+ * in HIPIE_IMG.inference (projects/HIPIE/hipie/hipie_img.py:626-629).
+ *   boxes (B, Q, 4) f32 normalised cxcywh; classes (B, Q) int64; order (B, Q) int32 = stable descending argsort of the
+ *   NMS scores (positions into Q); keep (B, Q) int32 out: surviving query indices in decreasing-score order, -1 padded;
+ *   count (B) int32 out.  coordinate_trick 1: torchvision's <=4000-coordinate path (every box offset by
+ *   class * (max_coordinate + 1), all pairs compared); 0: only same-class pairs on the raw boxes (its >4000 path).
+ *   IoU = inter / (area_i + area_j - inter) > iou_threshold suppresses, evaluated with single IEEE roundings (no FMA),
+ *   so keep/count are bit-exact against the CPU algorithm.  Q <= 1024 (the Q x Q bit matrix lives in LDS).
+ */
+int hipie_batched_nms(const float* boxes, const int64_t* classes, const int32_t* order, int32_t* keep, int32_t* count,
+                      int B, int Q, float iou_threshold, int coordinate_trick, void* stream);
+
+/*
+ * Instance-mask finalisation for one image:  F.interpolate(x`up`, bilinear, align_corners=False) -> sigmoid -> "> threshold"
+ * -> crop to (crop_h, crop_w)  (hipie_img.py:693-699)  -> F.interpolate(size=(out_h, out_w), mode="nearest") -> byte
+ * (segmentation_postprocess, hipie/models/ddetrs.py:1065-1070), in one pass over the stride-`up` logits.
+ *   masks (*, hm, wm) `dtype`; qidx (n) int32 rows of `masks` to process (NULL: rows 0..n-1); out (n, out_h, out_w) uint8.
+ */
+int hipie_mask_finalize(const void* masks, int dtype, const int32_t* qidx, int n, int hm, int wm, int up, int crop_h,
+                        int crop_w, int out_h, int out_w, float threshold, uint8_t* out, void* stream);
+
 /* device-side self-test helpers used by tests/ to pin the MFMA / LDS-transpose lane layouts this library assumes.
  *   which 0: D = A(32x16) . B(16x32) with v_mfma_f32_32x32x16_bf16, operands loaded with the layouts documented in
  *            csrc/mfma.h; out (32,32) f32.   which 1: ds_read_b64_tr_b16 of a (64,16) bf16 tile; out (64,4) f32 per lane.

@@ -24,8 +24,10 @@ def _worker(rank, world, port, total, q):
     for i in range(n_local):
         gi = idx[i] if i < len(idx) else -1
         k = 3
-        results.append({"instances": {"pred_boxes": torch.full((k, 4), float(gi)), "scores": torch.full((k,), float(gi) + 0.5),
-                                      "pred_classes": torch.full((k,), gi, dtype=torch.long)}})
+        from hipie_amd.structures import Boxes, Instances
+        results.append({"instances": Instances((8, 8), pred_boxes=Boxes(torch.full((k, 4), float(gi))),
+                                               scores=torch.full((k,), float(gi) + 0.5),
+                                               pred_classes=torch.full((k,), gi, dtype=torch.long))})
     block = parallel.compact_predictions(results, topk=5)
     out = parallel.all_gather_predictions(block)
     t = parallel.max_over_ranks(1.0 + r, torch.device("cpu"))

@@ -1,0 +1,144 @@
+"""GPU: the post-processing row (hipie_amd/postprocess.py + hipie_batched_nms + hipie_mask_finalize) against the golden from
+the reference's own HIPIE_IMG.inference and against the oracle (oracle/post.py) on larger random cases.
+Integer results (NMS keep lists, classes, segment tables) are compared exactly; boolean masks / label maps may differ on a
+<= 1e-4 fraction of pixels (a logit within 1 ulp of the threshold); float outputs within 1e-4 of the output scale."""
+import types
+
+import pytest
+import torch
+
+import _synth
+from oracle import post as op
+from test_post_oracle import check_against_golden, post_case
+from util import Golden
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+def fake_model(nbg, **kw):
+    from hipie_amd.config import HipieConfig
+    cfg = HipieConfig()
+    cfg.num_bg_queries = nbg
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return types.SimpleNamespace(cfg=cfg)
+
+
+def as_dict(res):
+    out = []
+    for r in res:
+        i = r["instances"]
+        out.append(dict(instances=dict(boxes=i.pred_boxes.tensor, scores=i.scores, classes=i.pred_classes, masks=i.pred_masks,
+                                       image_size=i.image_size), panoptic_seg=r["panoptic_seg"], sem_seg=r["sem_seg"]))
+    return out
+
+
+def run_product(a22, sizes, pmap, is_thing, out_hw, kw, task, nbg):
+    from hipie_amd.postprocess import inference
+    dev = "cuda"
+    out = {k: v.to(dev) for k, v in a22.items()}
+    out["image_sizes"] = sizes
+    batched = [{"task": task, "positive_map_label_to_token": pmap, "is_thing": is_thing, "height": out_hw[i][0],
+                "width": out_hw[i][1]} for i in range(len(sizes))]
+    return as_dict(inference(fake_model(nbg, **kw), out, batched))
+
+
+@pytest.mark.parametrize("cname", ["default", "evalyaml", "grounding"])
+def test_post_product_matches_reference_golden(cname):
+    g = Golden("post")
+    res = run_product(*post_case(g, cname))
+    check_against_golden(g, cname, res, tol=1e-4, mask_mismatch=1e-4)
+
+
+@pytest.mark.parametrize("B,Q,C,trick", [(3, 900, 80, None), (2, 1024, 7, None), (1, 1, 1, None), (2, 257, 1, 1), (2, 300, 5, 0)])
+def test_batched_nms_bit_exact(B, Q, C, trick):
+    from hipie_amd import ops
+    g = torch.Generator().manual_seed(Q * 7 + C)
+    centers = torch.rand(B, 12, 4, generator=g) * torch.tensor([0.8, 0.8, 0.5, 0.5]) + 0.1
+    which = torch.randint(0, 12, (B, Q), generator=g)
+    boxes = torch.gather(centers, 1, which[..., None].expand(-1, -1, 4)) + 0.03 * torch.randn(B, Q, 4, generator=g)
+    boxes[..., 2:] = boxes[..., 2:].abs().clamp_min(1e-3)
+    scores = torch.rand(B, Q, generator=g)
+    scores[:, ::17] = scores[:, 0:1]                                   # ties: the stable sort decides
+    classes = torch.randint(0, C, (B, Q), generator=g)
+    keep, count = ops.batched_nms(boxes.cuda(), scores.cuda(), classes.cuda(), 0.7, coordinate_trick=trick)
+    for b in range(B):
+        xyxy = op.box_cxcywh_to_xyxy(boxes[b])
+        if trick is None:
+            want = op.batched_nms(xyxy, scores[b], classes[b], 0.7)
+            if Q * 4 > 4000:                                           # torchvision's per-class path returns score order too
+                want = want[scores[b][want].sort(descending=True, stable=True)[1]]
+        elif trick:
+            mc = xyxy.max()
+            want = op.nms(xyxy + (classes[b].float() * (mc + 1))[:, None], scores[b], 0.7)
+        else:
+            km = torch.zeros(Q, dtype=torch.bool)
+            for c in classes[b].unique():
+                ci = torch.where(classes[b] == c)[0]
+                km[ci[op.nms(xyxy[ci], scores[b][ci], 0.7)]] = True
+            order = scores[b].sort(descending=True, stable=True)[1]
+            want = order[km[order]]
+        n = int(count[b])
+        assert n == want.numel()
+        got = keep[b, :n].cpu().long()
+        if trick is None and Q * 4 > 4000:
+            assert sorted(got.tolist()) == sorted(want.tolist())       # equal scores may be ordered differently
+        else:
+            assert torch.equal(got, want)
+        assert (keep[b, n:] == -1).all()
+
+
+def test_batched_nms_rejects_oversize():
+    from hipie_amd import ops
+    from hipie_amd._lib import HipieLibraryError
+    with pytest.raises((HipieLibraryError, RuntimeError)):
+        ops.batched_nms(torch.rand(1, 1025, 4).cuda(), torch.rand(1, 1025).cuda(), torch.zeros(1, 1025, dtype=torch.long).cuda(), 0.7)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("crop,out", [((200, 256), (200, 256)), ((250, 131), (333, 97)), ((256, 256), (64, 511))])
+def test_mask_finalize_matches_torch(dtype, crop, out):
+    import torch.nn.functional as F
+    from hipie_amd import ops
+    g = torch.Generator().manual_seed(5)
+    m = (torch.randn(13, 64, 64, generator=g) * 3).to(dtype).cuda()
+    qidx = torch.tensor([12, 0, 5, 5, 7], dtype=torch.int32).cuda()
+    got = ops.mask_finalize(m, qidx, 4, crop, out, 0.5)
+    ref = F.interpolate(m[qidx.long()][:, None].float(), size=(256, 256), mode="bilinear", align_corners=False)
+    ref = (ref.sigmoid() > 0.5)[:, :, :crop[0], :crop[1]]
+    ref = F.interpolate(ref.float(), size=out, mode="nearest").squeeze(1).byte()
+    assert got.shape == ref.shape and got.dtype == torch.uint8
+    assert (got != ref).float().mean() < 2e-4
+    full = ops.mask_finalize(m, None, 4, crop, out, 0.5)
+    assert torch.equal(full[qidx.long()], got)
+
+
+@pytest.mark.parametrize("use_bg", [True, False])
+def test_post_product_matches_oracle_large(use_bg):
+    """more queries / segments than the golden: stuff classes repeat, so the merge of stuff regions is exercised."""
+    sizes = [(384, 512), (512, 448)]
+    nbg, nfg, nmd, L, ncls = 10, 300, 120, 64, 9
+    a22 = _synth.synth_a22(sizes, nbg, nfg, nmd, L, seed=123)
+    a22["pred_logits_maskdino"] = a22["pred_logits_maskdino"] * 2.0
+    _, _, pmap = _synth.synth_token_ids(2, ncls, L, seed=74)
+    is_thing = {c + 1: (c % 3 == 0) for c in range(ncls)}
+    kw = dict(use_bg_for_pano=use_bg, bg_cls_agnostic=not use_bg, max_pool=not use_bg, object_mask_threshold=0.2,
+              overlap_threshold=0.5)
+    out_hw = [(384, 512), (300, 333)]
+    want = op.inference(a22, sizes, pmap, "detection", [is_thing] * 2, out_sizes=out_hw, num_bg=nbg, **kw)
+    got = run_product(a22, sizes, pmap, is_thing, out_hw, kw, "detection", nbg)
+    n_seg = 0
+    for w, g_ in zip(want, got):
+        wi, gi = w["instances"], g_["instances"]
+        assert torch.equal(gi["classes"].cpu(), wi["classes"])
+        assert torch.allclose(gi["scores"].cpu(), wi["scores"], atol=1e-5)
+        assert torch.allclose(gi["boxes"].cpu(), wi["boxes"], atol=1e-3)
+        assert (gi["masks"].cpu() != wi["masks"]).float().mean() < 1e-4
+        assert g_["panoptic_seg"][1] == w["panoptic_seg"][1]
+        assert (g_["panoptic_seg"][0].cpu() != w["panoptic_seg"][0]).float().mean() < 1e-4
+        assert (g_["sem_seg"].cpu() - w["sem_seg"]).abs().max() < 1e-4 * w["sem_seg"].abs().max()
+        n_seg += len(w["panoptic_seg"][1])
+        stuff_ids = [s_["category_id"] for s_ in w["panoptic_seg"][1] if not s_["isthing"]]
+        assert len(stuff_ids) == len(set(stuff_ids))
+    assert n_seg >= 4

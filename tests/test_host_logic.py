@@ -113,3 +113,35 @@ def test_r50_model_builds_with_reference_key_prefixes():
     assert "detr.detr.backbone.0.backbone.res5.2.conv3.weight" in keys
     assert m.state_dict()["detr.detr.input_proj.2.0.weight"].shape == (256, 2048, 1, 1)
     assert m.state_dict()["detr.mask_dino.pixel_decoder.adapter_1.weight"].shape == (256, 512, 1, 1)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_panoptic_merge_without_loops_matches_reference_loop(seed):
+    """the loop-free panoptic merge (cumulative-sum ids + first-occurrence stuff merging) of hipie_amd/postprocess.py is
+    plain torch, so it is checked here on the CPU against the oracle's restatement of panoptic_inference's loop."""
+    import types
+    from oracle import post as op
+    from hipie_amd import postprocess as pp
+    N, C = 60, 4
+    a22 = _synth.synth_a22([(128, 160)], 0, 1, N, 8, seed=200 + seed)
+    masks = a22["pred_masks_maskdino"][0]                                  # (N, 32, 40)
+    g = torch.Generator().manual_seed(seed)
+    cls_all = torch.softmax(torch.randn(N, C, generator=g) * 3, -1)
+    is_thing = {1: True, 2: False, 3: False, 4: (seed % 2 == 0)}
+    cfg = types.SimpleNamespace(object_mask_threshold=0.3, overlap_threshold=0.6)
+    sem, tab = pp._sem_pan(cls_all, masks, 4, (128, 160), (100, 150), pp.thing_vector(is_thing, C, "cpu"), cfg)
+    info = pp._segments_info([tab])[0]
+    up = torch.nn.functional.interpolate(masks[:, None], scale_factor=4.0, mode="bilinear", align_corners=False)
+    up = torch.nn.functional.interpolate(up[:, :, :128, :160], size=(100, 150), mode="bilinear", align_corners=False)[:, 0]
+    pan_w, info_w = op.panoptic_inference(cls_all, up, is_thing, 0.3, 0.6)
+    assert info == info_w
+    assert torch.equal(tab["pan"], pan_w)
+    assert torch.allclose(sem, op.semantic_inference(cls_all, up), atol=1e-5)
+    stuff = [s for s in info_w if not s["isthing"]]
+    assert len(info_w) >= 3 and len(stuff) >= 1
+    MERGES.append(int(tab["valid"].sum()) - len(info_w))
+    if seed == 3:
+        assert sum(MERGES) >= 1            # some stuff segment re-used an earlier id of its class
+
+
+MERGES = []
