@@ -104,7 +104,7 @@ def _sem_pan(cls_all, masks_lo, stride, crop_hw, out_hw, thing_vec, cfg):
     up = up[:, :, :crop_hw[0], :crop_hw[1]]
     if tuple(out_hw) != tuple(crop_hw):
         up = F.interpolate(up, size=tuple(out_hw), mode="bilinear", align_corners=False)
-    sig = up[:, 0].sigmoid_()                                                   # (N, oh, ow)
+    sig = up[:, 0].contiguous().sigmoid_()                                      # (N, oh, ow)
     oh, ow = sig.shape[-2:]
     sem = (cls_all.t() @ sig.view(N, -1)).view(C, oh, ow)                       # einsum("qc,qhw->chw")
     scores, labels = cls_all.max(-1)

@@ -60,7 +60,7 @@ def test_batched_nms_bit_exact(B, Q, C, trick):
     boxes = torch.gather(centers, 1, which[..., None].expand(-1, -1, 4)) + 0.03 * torch.randn(B, Q, 4, generator=g)
     boxes[..., 2:] = boxes[..., 2:].abs().clamp_min(1e-3)
     scores = torch.rand(B, Q, generator=g)
-    scores[:, ::17] = scores[:, 0:1]                                   # ties: the stable sort decides
+    scores[:, ::17] = scores[:, 0:1].clone()                                   # ties: the stable sort decides
     classes = torch.randint(0, C, (B, Q), generator=g)
     keep, count = ops.batched_nms(boxes.cuda(), scores.cuda(), classes.cuda(), 0.7, coordinate_trick=trick)
     for b in range(B):
