@@ -44,7 +44,7 @@ def synth_batch(cfg, batch, size, n_classes, L, device, seed=0):
     for b in range(batch):
         img = torch.randint(0, 256, (3, size, size), generator=g).float().to(device)      # resident in HBM before timing
         out.append({"image": img, "task": "detection", "input_ids": ids.to(device), "attention_mask": mask.to(device),
-                    "positive_map_label_to_token": pmap})
+                    "positive_map_label_to_token": pmap, "is_thing": {c: (c <= 60) for c in pmap}})
     return out
 
 
@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="capture the forward once into a hipGraph and replay it (experimental: "
                     "after the launch-count reductions the eager path is no longer host-bound, and whole-model replay "
                     "showed an unexplained GPU memory fault -- DESIGN.md section 9)")
+    ap.add_argument("--no-gemm-table", action="store_true", help="do not load the committed TunableOp table "
+                    "(hipie_amd/tuning/*.csv: the hipBLASLt solution picked per ViT-H linear shape; library plumbing)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--breakdown", action="store_true", help="after the timed region, time every hand-written kernel class "
                     "and the main stages of one extra step (stderr)")
@@ -134,6 +136,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.set_grad_enabled(False)
+
+    table = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipie_amd", "tuning", "tunableop_gfx950_vith_bs8.csv")
+    if not args.no_gemm_table and os.path.exists(table):
+        # read-only use of a committed table: known shapes get the tuned hipBLASLt solution, everything else the default
+        torch.cuda.tunable.set_filename(table)
+        torch.cuda.tunable.enable(True)
+        torch.cuda.tunable.tuning_enable(False)
+        torch.cuda.tunable.record_untuned_enable(False) if hasattr(torch.cuda.tunable, "record_untuned_enable") else None
 
     cfg = getattr(HipieConfig, args.model)()
     prec = {"fast": Precision.fast(), "parity": Precision.parity(), "default": Precision()}[args.precision]
@@ -204,6 +214,19 @@ def main():
     kern_ms, kern_n = ops.PROFILE.mean_ms("vit_attn_global")
     ops.PROFILE.disable()
 
+    # the full post-processing of the reference's eval branch (instance masks at 1024^2, semantic + panoptic maps),
+    # timed on its own: it is the row after the a22 metric surface
+    post_ms = None
+    if rank == 0:
+        out = model.forward_raw(batch)
+        inference(model, out, batch)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        inference(model, out, batch)
+        torch.cuda.synchronize()
+        post_ms = (time.perf_counter() - t1) * 1e3
+        del out
+
     if args.breakdown and rank == 0:
         ops.PROFILE.enable("all")
         torch.cuda.synchronize()
@@ -235,6 +258,7 @@ def main():
                          "frac": None if ach is None else round(ach / 2500.0, 4), "traffic": None,
                          "avg_launch_ms": None if not kern_ms else round(kern_ms, 4),
                          "flop_per_launch": flops},
+            "postprocess_full_ms": None if post_ms is None else round(post_ms, 2),
         }
         if not args.no_cpu_baseline:
             import subprocess

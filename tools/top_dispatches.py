@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""aggregate a rocprofv3 kernel_trace.csv: top kernels by total time, and the slowest single dispatches (with grid
-sizes), restricted to the last `--last-frac` of the trace (the timed steps, not the warm-up / MIOpen find)."""
+"""aggregate a rocprofv3 kernel_trace.csv: top kernels by total time, restricted to the last `frac` of the trace (the timed
+steps, not the warm-up / MIOpen find); elementwise / copy kernels are further split by launch size so that the tensor
+behind each one can be identified."""
+import collections
 import csv
 import sys
-import collections
 
 path = sys.argv[1]
 frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
@@ -13,13 +14,22 @@ t0, t1 = int(rows[0]["Start_Timestamp"]), int(rows[-1]["End_Timestamp"])
 cut = t1 - (t1 - t0) * frac
 rows = [r for r in rows if int(r["Start_Timestamp"]) >= cut]
 tot = collections.defaultdict(lambda: [0, 0])
+split = collections.defaultdict(lambda: [0, 0])
 for r in rows:
     d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     k = r["Kernel_Name"][:110]
     tot[k][0] += d
     tot[k][1] += 1
+    if "elementwise" in k or "copy" in k.lower() or "Cat" in k:
+        threads = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0) * max(1, int(r.get("Grid_Size_Y", 1) or 1))
+        key = (r["Kernel_Name"][:150], threads)
+        split[key][0] += d
+        split[key][1] += 1
 span = (int(rows[-1]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])) / 1e6
 busy = sum(v[0] for v in tot.values()) / 1e6
 print("window %.1f ms, GPU busy %.1f ms, %d dispatches" % (span, busy, len(rows)))
 for k, (d, n) in sorted(tot.items(), key=lambda x: -x[1][0])[:45]:
     print("%9.2f ms %6d x %9.1f us  %s" % (d / 1e6, n, d / n / 1e3, k))
+print("\nelementwise / copy kernels by launch size (threads):")
+for (k, th), (d, n) in sorted(split.items(), key=lambda x: -x[1][0])[:30]:
+    print("%9.2f ms %6d x %9.1f us  threads=%-10d %s" % (d / 1e6, n, d / n / 1e3, th, k))
