@@ -140,10 +140,13 @@ def main():
     table = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipie_amd", "tuning", "tunableop_gfx950_vith_bs8.csv")
     if not args.no_gemm_table and os.path.exists(table):
         # read-only use of a committed table: known shapes get the tuned hipBLASLt solution, everything else the default
-        torch.cuda.tunable.set_filename(table)
+        import shutil
+        import tempfile
+        tmp_table = os.path.join(tempfile.gettempdir(), "hipie_tunableop_%d.csv" % os.getpid())
+        shutil.copyfile(table, tmp_table)              # TunableOp may rewrite its file at exit: never the committed one
+        torch.cuda.tunable.set_filename(tmp_table)
         torch.cuda.tunable.enable(True)
         torch.cuda.tunable.tuning_enable(False)
-        torch.cuda.tunable.record_untuned_enable(False) if hasattr(torch.cuda.tunable, "record_untuned_enable") else None
 
     cfg = getattr(HipieConfig, args.model)()
     prec = {"fast": Precision.fast(), "parity": Precision.parity(), "default": Precision()}[args.precision]

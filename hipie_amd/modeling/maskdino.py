@@ -92,6 +92,7 @@ class MaskDINOEncoder(nn.Module):
         z = self.layer_1(z)
         mf = self.mask_features[0](z.to(self.mask_features[0].weight.dtype)).float()
         mf = self.mask_features[3](self.mask_features[2](self.mask_features[1](mf)))
+        mf = mf.float().contiguous()      # NCHW fp32, pixel fastest: the einsum's B-operand layout, produced once for both calls
         return mf, out[0], out          # mask_features (B,256,H/4,W/4), s8 level, [s8,s16,s32,s64]
 
 
@@ -127,6 +128,7 @@ class MaskDINODecoder(nn.Module):
         self.precision = precision
         self.pinned_topk = None
         self.last_topk = None
+        self.initial_pred_masks = False    # True: also materialise interm_outputs["pred_masks"] like the reference does
 
     def forward_prediction_heads(self, output, mask_features, pred_mask=True):
         """maskdino_decoder.py:520-529 -- the mask-logit contraction runs on hipie_mask_einsum."""
@@ -135,7 +137,7 @@ class MaskDINODecoder(nn.Module):
         masks = None
         if pred_mask:
             emb = self.mask_embed(dec)
-            masks = ops.mask_einsum(emb.float().contiguous(), mask_features.float().contiguous(), precision=self.precision.einsum)
+            masks = ops.mask_einsum(emb.float().contiguous(), mask_features, precision=self.precision.einsum)
         return cls, masks
 
     def forward(self, x, mask_features):
@@ -158,7 +160,8 @@ class MaskDINODecoder(nn.Module):
         self.last_topk = topk
         ref_un = torch.gather(coord_un, 1, topk.unsqueeze(-1).repeat(1, 1, 4))
         tgt = torch.gather(om, 1, topk.unsqueeze(-1).repeat(1, 1, self.hidden_dim))
-        interm_cls, interm_mask = self.forward_prediction_heads(tgt, mask_features)      # einsum #1 (:428)
+        # einsum #1 (:428) feeds only interm_outputs (training losses / denoising); at inference nothing consumes it
+        interm_cls, interm_mask = self.forward_prediction_heads(tgt, mask_features, pred_mask=self.initial_pred_masks)
         ref = ref_un.sigmoid()
         refs, out, hs = [ref], tgt, []
         for lid, layer in enumerate(self.decoder.layers):

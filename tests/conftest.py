@@ -24,3 +24,7 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+# MIOpen find mode (HIPIE_IMG.finalize) benchmarks every new convolution shape once: right for a long evaluation run, a
+# waste for the many tiny models the tests build
+os.environ.setdefault("HIPIE_MIOPEN_FIND", "0")

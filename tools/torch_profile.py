@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""torch.profiler view of one forward of the bench workload: device time grouped by (operator, input shapes), to find the
+source of elementwise / copy / cast kernels.  Output: gpurun_out/torch_profile.txt"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+
+import bench  # noqa: E402
+from hipie_amd.config import HipieConfig, Precision  # noqa: E402
+from hipie_amd.hipie_img import HIPIE_IMG  # noqa: E402
+
+
+def main():
+    torch.set_grad_enabled(False)
+    dev = torch.device("cuda", 0)
+    cfg = HipieConfig.vit_huge()
+    model = HIPIE_IMG(cfg, Precision.fast(), device=dev)
+    bench.randomize_degenerate_inits(model)
+    model.finalize()
+    batch = bench.synth_batch(cfg, 8, 1024, 80, 194, dev)
+    for _ in range(2):
+        model.forward_raw(batch)
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=False) as prof:
+        model.forward_raw(batch)
+        torch.cuda.synchronize()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/torch_profile.txt", "w") as f:
+        f.write(prof.key_averages(group_by_input_shape=True).table(sort_by="self_device_time_total", row_limit=90,
+                                                                   max_name_column_width=40, max_shapes_column_width=90))
+    print(open("gpurun_out/torch_profile.txt").read()[:200])
+
+
+if __name__ == "__main__":
+    main()
