@@ -52,17 +52,32 @@ template <> struct V4<f16_t> {
 };
 
 constexpr int LN_MAXV = 8;     // up to 8 x 4 elements per lane: C <= 2048
+// row maps of the call being dispatched (host-side plumbing through the dtype switch; set and cleared by the entry points)
+static thread_local const int32_t* g_delta_row = nullptr;
+static thread_local const int32_t* g_out_src = nullptr;
 
 template <typename Tx, typename Td, typename Tn>
 __global__ __launch_bounds__(256) void add_layernorm_kernel(const Tx* __restrict__ x, const Td* __restrict__ delta,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             Tx* __restrict__ res_out, Tn* __restrict__ norm_out, long rows,
-                                                            int C, float eps) {
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+                                                            int C, float eps, const int32_t* __restrict__ delta_row,
+                                                            const int32_t* __restrict__ out_src) {
+  // row maps (both optional): the wave owns OUTPUT row `orow`; it normalises x row `row = out_src[orow]` (-1: the output row
+  // is padding -> zeros, e.g. the pad tokens of window_partition) and adds delta row `delta_row[row]` (e.g. the window
+  // layout the attention wrote) -- window partition / un-partition become index arithmetic of this pass
+  const long orow = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (orow >= rows) return;
   const int lane = threadIdx.x & 63;
   const int nv = C / 256;                       // full 4-element vectors per lane (64 lanes x 4)
   const int tail = (C - nv * 256) / 4;          // remaining vectors (< 64), one per lane for lane < tail
+  const long row = out_src ? (long)out_src[orow] : orow;
+  if (row < 0) {
+    const float z[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i <= nv; ++i)
+      if ((i < nv) || (lane < tail)) V4<Tn>::st(norm_out + orow * C + i * 256 + lane * 4, z);
+    return;
+  }
+  const long drow = delta_row ? (long)delta_row[row] : row;
   float v[LN_MAXV][4];
   float sum = 0.f;
   const Tx* xr = x + row * C;
@@ -74,7 +89,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const Tx* __restrict
       V4<Tx>::ld(xr + c, v[i]);
       if (delta != nullptr) {
         float d[4];
-        V4<Td>::ld(delta + row * C + c, d);
+        V4<Td>::ld(delta + drow * C + c, d);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[i][e] += d[e];
       }
@@ -113,7 +128,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const Tx* __restrict
       o[1] = (v[i][1] - mean) * rstd * g.y + b.y;
       o[2] = (v[i][2] - mean) * rstd * g.z + b.z;
       o[3] = (v[i][3] - mean) * rstd * g.w + b.w;
-      V4<Tn>::st(norm_out + row * C + c, o);
+      V4<Tn>::st(norm_out + orow * C + c, o);
     }
   }
 }
@@ -122,7 +137,7 @@ template <typename Tx, typename Td, typename Tn>
 static int launch_ln(const void* x, const void* d, const float* g, const float* b, void* r, void* n, long rows, int C,
                      float eps, hipStream_t st) {
   hipLaunchKernelGGL((add_layernorm_kernel<Tx, Td, Tn>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const Tx*)x,
-                     (const Td*)d, g, b, (Tx*)r, (Tn*)n, rows, C, eps);
+                     (const Td*)d, g, b, (Tx*)r, (Tn*)n, rows, C, eps, g_delta_row, g_out_src);
   return check_launch("add_layernorm");
 }
 
@@ -149,6 +164,19 @@ static int ln_delta(int dd, int nd, const void* x, const void* d, const float* g
 }
 
 }  // namespace hipie
+
+extern "C" int hipie_add_layernorm_rows(const void* x, const void* delta, const float* gamma, const float* beta,
+                                        void* res_out, void* norm_out, int64_t out_rows, int C, float eps, int x_dtype,
+                                        int delta_dtype, int norm_dtype, const int32_t* delta_row, const int32_t* out_src,
+                                        void* stream) {
+  hipie::g_delta_row = delta_row;
+  hipie::g_out_src = out_src;
+  const int rc = hipie_add_layernorm(x, delta, gamma, beta, res_out, norm_out, out_rows, C, eps, x_dtype, delta_dtype,
+                                     norm_dtype, stream);
+  hipie::g_delta_row = nullptr;
+  hipie::g_out_src = nullptr;
+  return rc;
+}
 
 extern "C" int hipie_add_layernorm(const void* x, const void* delta, const float* gamma, const float* beta, void* res_out,
                                    void* norm_out, int64_t rows, int C, float eps, int x_dtype, int delta_dtype,

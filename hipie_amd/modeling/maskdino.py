@@ -76,7 +76,7 @@ class MaskDINOEncoder(nn.Module):
         self.layer_1 = NormConv2d(cd, cd, 3, padding=1, relu=True)
 
     def forward_features(self, features, masks=None):
-        f3, f4, f5 = features["res3"].float(), features["res4"].float(), features["res5"].float()
+        f3, f4, f5 = features["res3"], features["res4"], features["res5"]      # the projections cast / lay out their input
         extra = self.input_proj[3](f5)
         srcs = [self.input_proj[i](f) for i, f in enumerate((f3, f4, f5))] + [extra]
         zero = [torch.zeros(s.shape[0], s.shape[2], s.shape[3], dtype=torch.bool, device=s.device) for s in srcs]

@@ -221,9 +221,10 @@ class MSDeformAttn(nn.Module):
 
     def project_value(self, input_flatten, input_padding_mask=None):
         N, S, _ = input_flatten.shape
-        value = self.value_proj(input_flatten)
+        vp = self.value_proj                       # GEMM output stays in the weight dtype: no fp32 round trip, mask in place
+        value = F.linear(input_flatten.to(vp.weight.dtype), vp.weight, vp.bias)
         if input_padding_mask is not None:
-            value = value.masked_fill(input_padding_mask[..., None], 0.0)
+            value.masked_fill_(input_padding_mask[..., None], 0.0)
         return value.to(self.value_dtype).view(N, S, self.n_heads, self.d_model // self.n_heads)
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,

@@ -70,6 +70,27 @@ def window_unpartition(win, ws, pad_hw, hw):
     return x
 
 
+_ROW_MAPS = {}
+
+
+def window_row_maps(B, H, W, ws, device):
+    """int32 row maps between the token layout (B, H, W) and the padded window layout (B * nWin, ws, ws) of
+    window_partition: out_src[window row] = token row or -1 (pad), delta_row[token row] = window row.  Cached per geometry."""
+    key = (B, H, W, ws, str(device))
+    m = _ROW_MAPS.get(key)
+    if m is None:
+        assert B * H * W < (1 << 24)
+        tok = torch.arange(B * H * W, dtype=torch.float32).view(B, H, W, 1)
+        win, _ = window_partition(tok + 1.0, ws)                        # pad -> 0, token r -> r + 1 (exact in fp32 < 2^24)
+        out_src = (win.reshape(-1) - 1.0).to(torch.int32)
+        valid = out_src >= 0
+        delta_row = torch.empty(B * H * W, dtype=torch.int32)
+        delta_row[out_src[valid].long()] = torch.nonzero(valid).flatten().to(torch.int32)
+        m = (out_src.to(device), delta_row.to(device), win.shape[0])
+        _ROW_MAPS[key] = m
+    return m
+
+
 class PatchEmbed(nn.Module):
     """hipie/backbone/utils.py:160-186.  kernel == stride, so the conv is a GEMM over unfolded patches (a library GEMM on
     (B*h*w, 3*p*p) x (3*p*p, E) instead of a 3-input-channel convolution)."""
@@ -154,14 +175,19 @@ class Block(nn.Module):
         has not been added yet.  Returns (x, delta'): every residual add is fused with the LayerNorm that follows it
         (hipie_add_layernorm), so the stream is read and written once per half-block."""
         gd = self.precision.gemm
-        x, y = ops.add_layernorm(x, delta, self.norm1.weight, self.norm1.bias, self.norm1.eps, gd)
-        if self.window_size > 0:
-            H, W = y.shape[1], y.shape[2]
-            y, pad_hw = window_partition(y, self.window_size)
-        y = self.attn(y)
-        if self.window_size > 0:
-            y = window_unpartition(y, self.window_size, pad_hw, (H, W))
-        x, h = ops.add_layernorm(x, y.contiguous(), self.norm2.weight, self.norm2.bias, self.norm2.eps, gd)
+        ws = self.window_size
+        if ws == 0:
+            x, y = ops.add_layernorm(x, delta, self.norm1.weight, self.norm1.bias, self.norm1.eps, gd)
+            y = self.attn(y)
+            x, h = ops.add_layernorm(x, y.contiguous(), self.norm2.weight, self.norm2.bias, self.norm2.eps, gd)
+            return x, self.mlp(h)
+        # windowed block: window_partition (zero padding included) is the output row map of the first fused add+LN and
+        # window_unpartition the delta row map of the second one (utils.py:16-60) -- no partition / crop copies
+        B, H, W, C = x.shape
+        out_src, delta_row, nwin = window_row_maps(B, H, W, ws, x.device)
+        x, y = ops.add_layernorm(x, delta, self.norm1.weight, self.norm1.bias, self.norm1.eps, gd, out_src=out_src)
+        y = self.attn(y.view(nwin, ws, ws, C))
+        x, h = ops.add_layernorm(x, y.reshape(-1, C), self.norm2.weight, self.norm2.bias, self.norm2.eps, gd, delta_row=delta_row)
         return x, self.mlp(h)
 
 
@@ -189,7 +215,7 @@ class ViT(nn.Module):
     size_divisibility = 32
 
     def forward(self, x):
-        """x (B,3,H,W) fp32 normalised image -> {"res3","res4","res5"} NCHW fp32."""
+        """x (B,3,H,W) fp32 normalised image -> {"res3","res4","res5"}: logical NCHW, channels-last memory, activation dtype."""
         gd, ad = self.precision.gemm, self.precision.act
         x = self.patch_embed(x).float()
         x = (x + self._abs_pos((x.shape[1], x.shape[2]))).to(ad)
@@ -197,12 +223,15 @@ class ViT(nn.Module):
         for blk in self.blocks:
             x, delta = blk(x, delta)
         x = x + delta.to(x.dtype)
-        # fpn1: ConvTranspose2d(k=2, s=2) == one GEMM (E -> 4 * E/2) + a pixel shuffle (vit.py:341-343)
+        # fpn1: ConvTranspose2d(k=2, s=2) == one GEMM (E -> 4 * E/2, bias in the epilogue) + a pixel shuffle (vit.py:341-343).
+        # The features leave in the activation dtype and in channels-last memory (logical NCHW): the 1x1 / 3x3 projections
+        # that consume them run NHWC, so no layout or dtype copy sits between the backbone and the heads.
         B, H, W, E = x.shape
         wt = self.fpn1[0].weight                                           # (E, E/2, 2, 2)
-        y = F.linear(x.to(wt.dtype), wt.reshape(E, -1).t()).view(B, H, W, E // 2, 2, 2)
-        res3 = y.permute(0, 3, 1, 4, 2, 5).reshape(B, E // 2, 2 * H, 2 * W).float() + self.fpn1[0].bias.float().view(1, -1, 1, 1)
-        xp = x.float().permute(0, 3, 1, 2)
+        b4 = self.fpn1[0].bias.to(wt.dtype).repeat_interleave(4)
+        y = F.linear(x.to(wt.dtype), wt.reshape(E, -1).t(), b4).view(B, H, W, E // 2, 2, 2)
+        res3 = y.permute(0, 1, 4, 2, 5, 3).reshape(B, 2 * H, 2 * W, E // 2).to(ad).permute(0, 3, 1, 2)
+        xp = x.permute(0, 3, 1, 2)
         return {"res3": res3, "res4": xp, "res5": self.fpn3(xp)}
 
     def _abs_pos(self, hw):

@@ -238,17 +238,29 @@ def vit_relpos(qkv, tab_h, tab_w, grid_hw, heads):
 
 
 @_timed("add_layernorm")
-def add_layernorm(x, delta, weight, bias, eps, norm_dtype, want_res=True):
-    """s = x + delta (delta may be None); returns (s in x.dtype or None, LayerNorm(s) in norm_dtype).  x (..., C)."""
+def add_layernorm(x, delta, weight, bias, eps, norm_dtype, want_res=True, delta_row=None, out_src=None):
+    """s = x + delta (delta may be None); returns (s in x.dtype or None, LayerNorm(s) in norm_dtype).  x (..., C).
+    Row maps (int32, optional): ``out_src`` (out_rows,) = x row feeding each output row (-1: zeros) -- the normalised output
+    then has out_rows rows; ``delta_row`` (rows of x,) = row of ``delta`` that belongs to x row r."""
     lib = _lib.load()
     C = x.shape[-1]
     rows = x.numel() // C
     res = torch.empty_like(x) if (want_res and delta is not None) else None
-    out = torch.empty(x.shape, dtype=norm_dtype, device=x.device)
-    rc = lib.hipie_add_layernorm(_chk(x, "x"), None if delta is None else _chk(delta, "delta"),
-                                 _chk(weight, "weight", torch.float32), _chk(bias, "bias", torch.float32),
-                                 None if res is None else res.data_ptr(), out.data_ptr(), rows, C, float(eps),
-                                 _DT[x.dtype], _DT[x.dtype if delta is None else delta.dtype], _DT[norm_dtype], _stream())
+    if out_src is None:
+        out = torch.empty(x.shape, dtype=norm_dtype, device=x.device)
+        out_rows = rows
+    else:
+        out_rows = int(out_src.shape[0])
+        out = torch.empty(out_rows, C, dtype=norm_dtype, device=x.device)
+    args = (_chk(x, "x"), None if delta is None else _chk(delta, "delta"),
+            _chk(weight, "weight", torch.float32), _chk(bias, "bias", torch.float32),
+            None if res is None else res.data_ptr(), out.data_ptr(), out_rows, C, float(eps),
+            _DT[x.dtype], _DT[x.dtype if delta is None else delta.dtype], _DT[norm_dtype])
+    if delta_row is None and out_src is None:
+        rc = lib.hipie_add_layernorm(*args, _stream())
+    else:
+        rc = lib.hipie_add_layernorm_rows(*args, None if delta_row is None else _chk(delta_row, "delta_row", torch.int32),
+                                          None if out_src is None else _chk(out_src, "out_src", torch.int32), _stream())
     _lib.check(rc, "hipie_add_layernorm")
     return (x if delta is None else res), out
 

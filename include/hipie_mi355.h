@@ -157,6 +157,18 @@ int hipie_add_layernorm(const void* x, const void* delta, const float* gamma, co
                         void* stream);
 
 /*
+ * hipie_add_layernorm with row maps, so that window_partition / window_unpartition (hipie/backbone/utils.py:16-60) around
+ * the windowed ViT blocks (backbone/vit.py:214-225) cost no pass of their own:
+ *   for every OUTPUT row j < out_rows:  r = out_src ? out_src[j] : j;   r < 0: norm_out[j] = 0 (a pad token);  otherwise
+ *   s = x[r] + delta[delta_row ? delta_row[r] : r];  res_out[r] = s (optional);  norm_out[j] = LN(s) * gamma + beta.
+ *   out_src (out_rows) int32: token row feeding each row of the (padded, window-ordered) output, or NULL;
+ *   delta_row (rows of x) int32: where the residual branch of token r lives (the window-ordered attention output), or NULL.
+ */
+int hipie_add_layernorm_rows(const void* x, const void* delta, const float* gamma, const float* beta, void* res_out,
+                             void* norm_out, int64_t out_rows, int C, float eps, int x_dtype, int delta_dtype,
+                             int norm_dtype, const int32_t* delta_row, const int32_t* out_src, void* stream);
+
+/*
  * Batched (class-aware) NMS for one batch of images, the device form of the per-image
  *   keep_indices = torchvision.ops.batched_nms(box_cxcywh_to_xyxy(box_pred), nms_scores, idxs, 0.7)
  * in HIPIE_IMG.inference (projects/HIPIE/hipie/hipie_img.py:626-629).

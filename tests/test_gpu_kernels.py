@@ -234,6 +234,34 @@ def test_add_layernorm(C, rows):
     assert rel_err(out.float().cpu(), F.layer_norm(s, (C,), w, b, 1e-6)) < 2e-3
 
 
+@pytest.mark.parametrize("B,H,W,ws", [(2, 9, 11, 4), (1, 64, 64, 14), (2, 28, 14, 14)])
+def test_add_layernorm_window_row_maps(B, H, W, ws):
+    """hipie_add_layernorm_rows: LN written straight into the zero-padded window layout == window_partition(LN(x + d)),
+    and the residual add reading the window layout == x + window_unpartition(y) (hipie/backbone/utils.py:16-60)."""
+    import torch.nn.functional as F
+    from hipie_amd import ops
+    from hipie_amd.modeling.vit import window_partition, window_row_maps, window_unpartition
+    C = 160
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(B, H, W, C, generator=gen) * 2
+    d = torch.randn(B, H, W, C, generator=gen)
+    w = 1 + 0.1 * torch.randn(C, generator=gen)
+    b = 0.1 * torch.randn(C, generator=gen)
+    out_src, delta_row, nwin = window_row_maps(B, H, W, ws, DEV)
+    res, out = ops.add_layernorm(x.to(DEV), d.to(DEV), w.to(DEV), b.to(DEV), 1e-6, torch.float32, out_src=out_src)
+    want, pad_hw = window_partition(F.layer_norm(x + d, (C,), w, b, 1e-6), ws)
+    assert out.shape[0] == nwin * ws * ws
+    assert rel_err(res.cpu(), x + d) < 1e-6
+    assert rel_err(out.cpu().view_as(want), want) < 2e-6
+    assert (out.cpu().view_as(want)[want == 0] == 0).all()                 # pad rows are exact zeros
+    ywin = torch.randn(nwin, ws, ws, C, generator=gen)
+    res2, out2 = ops.add_layernorm(x.to(DEV), ywin.reshape(-1, C).to(DEV), w.to(DEV), b.to(DEV), 1e-6, torch.float32,
+                                   delta_row=delta_row)
+    s = x + window_unpartition(ywin, ws, pad_hw, (H, W))
+    assert rel_err(res2.cpu(), s) < 1e-6
+    assert rel_err(out2.cpu(), F.layer_norm(s, (C,), w, b, 1e-6)) < 2e-6
+
+
 @pytest.mark.parametrize("name", ["window14", "global16", "global64", "global_rect"])
 def test_vit_relpos_tables(name):
     """hipie_vit_relpos == the reference's two einsums over get_rel_pos (fp32) on the same 16-bit q and tables."""
