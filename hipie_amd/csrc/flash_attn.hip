@@ -36,6 +36,7 @@ struct FAParams {
   int B, H, Nq, Nk;
   long q_sb, q_st, q_sh, k_sb, k_st, k_sh, v_sb, v_st, v_sh, o_sb, o_st, o_sh;
   const float* bias_h; const float* bias_w; int kh, kw;
+  const void* tab_h; const void* tab_w;          // FUSEREL: rel-pos tables (2*kh-1, HD), (2*kw-1, HD) in the operand dtype
   const uint8_t* key_mask;
   float scale, clamp;
   int nqt, ntiles, swz;
@@ -47,7 +48,11 @@ constexpr float kLog2e = 1.4426950408889634f;
 // bias (tile == key row);  CLAMP: clamp scale*q.k to +-clamp.
 // One wave per SIMD (4 waves, up to 512 registers each): with QB = 2 every K / V^T fragment fetched from LDS feeds two
 // MFMAs and the two query blocks give the scheduler independent MFMA and softmax streams to overlap.
-template <typename T, int HD, int NB, int QB, int WAVES, bool BIAS, bool CLAMP, bool MASKED>
+// FUSEREL: the decomposed rel-pos bias is computed in the prologue from the tables (add_decomposed_rel_pos,
+// backbone/utils.py:96-125): bias_w[q, kx] = q . Rw[qx - kx + kw - 1] and bias_h[q, ky] = q . Rh[qy - ky + kh - 1] are
+// two small MFMA products per wave (table rows x the Q fragments already in registers), so the (B*heads, N, kh + kw) fp32
+// bias tensors are never written to or read from HBM.  Requires kw % 32 == 0 (a wave's 32 queries share one grid row).
+template <typename T, int HD, int NB, int QB, int WAVES, bool BIAS, bool CLAMP, bool MASKED, bool FUSEREL = false>
 __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || HD <= 80) ? 2 : 1) void flash_attn_kernel(const FAParams p) {
   constexpr int KT = 32 * NB;                  // keys per tile
   constexpr int KS = HD / 16;                  // k16 steps of QK^T
@@ -98,13 +103,6 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || HD <= 80) ? 2 : 1) void 
     qc[qb] = min(qi[qb], p.Nq - 1);
   }
 
-  // zero LDS once: the pad columns of the V tile feed the padded d rows of O^T (discarded, but keep them NaN-free)
-  for (int i = tid; i < 2 * BUF / 8; i += NT) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
-  if (LTRICK) {
-    __syncthreads();
-    for (int i = tid; i < 2 * KT; i += NT) smem[(i / KT) * BUF + KT * KSTR + (i % KT) * VSTR + HD] = (T)1.0f;   // never overwritten by tile stores
-  }
-
   // ---- Q fragments (B operand): lane (q = li, half hi) holds Q[q][16 ks + 8 hi + j] ----
   frag qf[QB][KS];
 #pragma unroll
@@ -113,12 +111,68 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || HD <= 80) ? 2 : 1) void 
     for (int ks = 0; ks < KS; ++ks)
       qf[qb][ks] = *reinterpret_cast<const frag*>(Qg + (long)qc[qb] * p.q_st + 16 * ks + 8 * hi);
 
+  constexpr bool BWL = BIAS && (NB <= 2) && (WAVES == 8);
+  float bw[QB][NB][16];
+  if constexpr (FUSEREL) {
+    static_assert(QB == 1 && BIAS && !BWL && !MASKED, "FUSEREL: 4-wave, full-tile bias variant only");
+    const T* TH = reinterpret_cast<const T*>(p.tab_h);
+    const T* TW = reinterpret_cast<const T*>(p.tab_w);
+    const int q0 = min(qt * (WAVES * QPW) + wave * QPW, p.Nq - 1);
+    const int qy = q0 / p.kw, qx0 = q0 - qy * p.kw;              // the wave's 32 queries: row qy, columns qx0 .. qx0 + 31
+    // G[j][q] = Rw[qx0 + j] . q for the 32 + kw - 1 table rows this wave can touch; staged through LDS because the row a
+    // lane needs (j = li + kw - 1 - kx) sits in another register / lane half of the MFMA output
+    constexpr int GROWS = 32 * (NB + 1);
+    float* stage = reinterpret_cast<float*>(smem_raw) + wave * (GROWS * 32);
+#pragma unroll
+    for (int jb = 0; jb < NB + 1; ++jb) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const int row = min(qx0 + 32 * jb + li, 2 * p.kw - 2);
+      const T* ap = TW + (long)row * HD + 8 * hi;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = Mfma32<T>::mma(*reinterpret_cast<const frag*>(ap + 16 * ks), qf[0][ks], acc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stage[(32 * jb + crow(r, hi)) * 32 + li] = acc[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kx = min(32 * blk + crow(r, hi), p.kw - 1);
+        bw[0][blk][r] = stage[(li + (p.kw - 1) - kx) * 32 + li] * kLog2e;
+      }
+    __syncthreads();               // staging (which overlaps the start of bh_all) is dead from here on
+    // H[ky][q] = Rh[qy - ky + kh - 1] . q for every key row: the per-(query, tile) scalar of the main loop
+    float* bh_all = reinterpret_cast<float*>(smem_raw + (size_t)2 * BUF * sizeof(T));      // [kh][WAVES*QPW]
+    for (int kb = 0; kb < (p.kh + 31) / 32; ++kb) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const int row = min(max(qy - (32 * kb + li) + p.kh - 1, 0), 2 * p.kh - 2);
+      const T* ap = TH + (long)row * HD + 8 * hi;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = Mfma32<T>::mma(*reinterpret_cast<const frag*>(ap + 16 * ks), qf[0][ks], acc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ky = 32 * kb + crow(r, hi);
+        if (ky < p.kh) bh_all[ky * (WAVES * QPW) + wave * QPW + li] = acc[r] * kLog2e;
+      }
+    }
+  }
+
+  // zero LDS once: the pad columns of the V tile feed the padded d rows of O^T (discarded, but keep them NaN-free)
+  for (int i = tid; i < 2 * BUF / 8; i += NT) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  if (LTRICK) {
+    __syncthreads();
+    for (int i = tid; i < 2 * KT; i += NT) smem[(i / KT) * BUF + KT * KSTR + (i % KT) * VSTR + HD] = (T)1.0f;   // never overwritten by tile stores
+  }
+
   // ---- bias_w in S^T register order, pre-multiplied by log2(e) (the softmax runs in the exp2 domain) ----
   // bias_w rows: in LDS for the 8-wave workgroup (one workgroup per CU; frees 16*NB VGPRs so two waves fit per SIMD); in
   // registers for 4-wave workgroups, whose smaller LDS footprint lets TWO independent workgroups share a CU
-  constexpr bool BWL = BIAS && (NB <= 2) && (WAVES == 8);
   constexpr int BWS = 32 * NB + 4;            // bias_w LDS row stride (floats): 16-B aligned rows, conflict-free b128 reads
-  float bw[QB][NB][16];
   // Inside the tile loop the ONLY vector-memory traffic is the prefetch of the next tile (K, V and the 4 x 32 x WAVES
   // bias_h values of that key row, which arrive transposed as (BH, kh, Nq) so they are one coalesced line): no other
   // s_waitcnt vmcnt can drain it early (vmcnt retires in order, and a loaded value carried across the loop back-edge
@@ -128,7 +182,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || HD <= 80) ? 2 : 1) void 
   uint8_t* mk_lds = reinterpret_cast<uint8_t*>(bw_lds + (BWL ? WAVES * QPW * BWS : 0));
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    if (BIAS && !BWL) {
+    if (BIAS && !BWL && !FUSEREL) {
       const float* bwp = p.bias_w + ((long)bh * p.Nq + qc[qb]) * p.kw;
 #pragma unroll
       for (int blk = 0; blk < NB; ++blk)
@@ -146,8 +200,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || HD <= 80) ? 2 : 1) void 
   if (MASKED && Mg != nullptr)
     for (int i = tid; i < p.Nk; i += NT) mk_lds[i] = Mg[i];
   // this thread's slot of the per-tile bias_h line
-  const float* bhsrc = BIAS ? p.bias_h + (long)bh * p.kh * p.Nq + min(qt * (WAVES * QPW) + tid, p.Nq - 1) : nullptr;
-  const bool bh_thread = BIAS && (tid < WAVES * QPW);
+  const float* bhsrc = (BIAS && !FUSEREL) ? p.bias_h + (long)bh * p.kh * p.Nq + min(qt * (WAVES * QPW) + tid, p.Nq - 1) : nullptr;
+  const bool bh_thread = BIAS && !FUSEREL && (tid < WAVES * QPW);
   float bhr = 0.f;
   const float c1 = p.scale * kLog2e;
   const float cl2 = p.clamp * kLog2e;
@@ -237,7 +291,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || HD <= 80) ? 2 : 1) void 
     float bh_t[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-      bh_t[qb] = BIAS ? bh_lds[(t & 1) * (WAVES * QPW) + wave * QPW + 32 * qb + li] : 0.f;
+      bh_t[qb] = BIAS ? bh_lds[(FUSEREL ? t : (t & 1)) * (WAVES * QPW) + wave * QPW + 32 * qb + li] : 0.f;
     }
 
     // ---- S^T = K . Q^T  (each K fragment feeds QB MFMAs) ----
@@ -396,19 +450,20 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || HD <= 80) ? 2 : 1) void 
 #undef FA_LOAD_REGS
 #undef FA_STORE_LDS
 
-template <typename T, int HD, int NB, int QB, int WAVES, bool BIAS, bool CLAMP, bool MASKED>
+template <typename T, int HD, int NB, int QB, int WAVES, bool BIAS, bool CLAMP, bool MASKED, bool FUSEREL = false>
 static int launch_fa(FAParams& p, hipStream_t st) {
   constexpr int KT = 32 * NB, DB = (HD + 31) / 32;
   constexpr int VSTR = (DB * 32 == 96 || DB * 32 == 32) ? DB * 32 : DB * 32 + 32;
   size_t lds = (size_t)2 * KT * ((HD + 8) + VSTR) * sizeof(T);
-  lds += (size_t)2 * WAVES * 32 * QB * sizeof(float);
+  lds += (size_t)(FUSEREL ? p.kh : 2) * WAVES * 32 * QB * sizeof(float);
+  if (FUSEREL && lds < (size_t)WAVES * 32 * (NB + 1) * 32 * sizeof(float)) lds = (size_t)WAVES * 32 * (NB + 1) * 32 * sizeof(float);
   if (BIAS && NB <= 2 && WAVES == 8) lds += (size_t)WAVES * 32 * QB * (32 * NB + 4) * sizeof(float);
   if (MASKED && p.key_mask != nullptr) lds += ((size_t)p.Nk + 15) / 16 * 16;
   if (lds > 160 * 1024) return set_err(HIPIE_EINVAL, "flash_attn: %zu bytes of LDS needed (Nk=%d) > 160 KiB", lds, p.Nk);
   p.nqt = (p.Nq + WAVES * 32 * QB - 1) / (WAVES * 32 * QB);
   p.ntiles = BIAS ? p.kh : (p.Nk + KT - 1) / KT;
   const unsigned grid = (unsigned)(p.nqt * p.B * p.H);
-  auto kern = flash_attn_kernel<T, HD, NB, QB, WAVES, BIAS, CLAMP, MASKED>;
+  auto kern = flash_attn_kernel<T, HD, NB, QB, WAVES, BIAS, CLAMP, MASKED, FUSEREL>;
   static size_t lds_set = 0;     // raise the dynamic-LDS limit once per instantiation (not a stream operation: keep it out of graph capture)
   if (lds > 64 * 1024 && lds > lds_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -421,6 +476,12 @@ static int launch_fa(FAParams& p, hipStream_t st) {
 // NBN: key blocks per tile without bias (smaller for the wide head); W: waves per workgroup for the large-Nq case
 template <typename T, int HD, int NBN, int W>
 static int dispatch_nb(FAParams& p, hipStream_t st, bool wide) {
+  if (p.tab_h != nullptr) {
+    if constexpr (HD == 64 || HD == 80) {
+      if (p.kw == 64 && p.kh >= 1 && p.kh <= 64) return launch_fa<T, HD, 2, 1, 4, true, false, false, true>(p, st);
+    }
+    return set_err(HIPIE_EINVAL, "vit_attn_fused: needs a 64-wide token grid with <= 64 rows and head_dim 64/80 (got %dx%d, hd %d)", p.kh, p.kw, HD);
+  }
   if (p.bias_h != nullptr) {
     const int nb = (p.kw + 31) / 32;
     const bool full = (p.kw % 32) == 0;
@@ -454,7 +515,7 @@ static int flash_attn_impl(FAParams p, int hd, int dtype, void* stream) {
   HIPIE_REQUIRE(p.q && p.k && p.v && p.out, "flash_attn: null pointer");
   HIPIE_REQUIRE(p.B > 0 && p.H > 0 && p.Nq > 0 && p.Nk > 0, "flash_attn: bad shape B=%d H=%d Nq=%d Nk=%d", p.B, p.H, p.Nq, p.Nk);
   HIPIE_REQUIRE((p.bias_h == nullptr) == (p.bias_w == nullptr), "flash_attn: bias_h and bias_w must be given together");
-  if (p.bias_h) HIPIE_REQUIRE(p.kh > 0 && p.kw > 0 && (long)p.kh * p.kw == p.Nk, "flash_attn: kh*kw=%d*%d != Nk=%d", p.kh, p.kw, p.Nk);
+  if (p.bias_h || p.tab_h) HIPIE_REQUIRE(p.kh > 0 && p.kw > 0 && (long)p.kh * p.kw == p.Nk, "flash_attn: kh*kw=%d*%d != Nk=%d", p.kh, p.kw, p.Nk);
   const long strides[] = {p.q_sb, p.q_st, p.q_sh, p.k_sb, p.k_st, p.k_sh, p.v_sb, p.v_st, p.v_sh, p.o_sb, p.o_st, p.o_sh};
   for (long s : strides) HIPIE_REQUIRE(s % 8 == 0, "flash_attn: strides must be multiples of 8 elements (16 bytes), got %ld", s);
   HIPIE_REQUIRE((((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v | (uintptr_t)p.out) & 15) == 0, "flash_attn: pointers must be 16-byte aligned");
@@ -503,6 +564,26 @@ extern "C" int hipie_vit_attn(const void* qkv, const float* rel_h, const float* 
   p.q_sb = p.k_sb = p.v_sb = N * 3 * C; p.q_st = p.k_st = p.v_st = 3 * C; p.q_sh = p.k_sh = p.v_sh = hd;
   p.o_sb = N * C; p.o_st = C; p.o_sh = hd;
   p.bias_h = rel_h; p.bias_w = rel_w; p.kh = gh; p.kw = gw; p.key_mask = nullptr;
+  p.scale = scale; p.clamp = 0.f;
+  return flash_attn_impl(p, hd, dtype, stream);
+}
+
+extern "C" int hipie_vit_attn_fused(const void* qkv, const void* tab_h, const void* tab_w, void* out, int B, int gh, int gw,
+                                    int heads, int hd, float scale, int dtype, void* stream) {
+  using namespace hipie;
+  HIPIE_REQUIRE(qkv && out && tab_h && tab_w, "vit_attn_fused: null pointer");
+  HIPIE_REQUIRE((((uintptr_t)tab_h | (uintptr_t)tab_w) & 15) == 0, "vit_attn_fused: tables must be 16-byte aligned");
+  const long N = (long)gh * gw, C = (long)heads * hd;
+  const size_t es = 2;
+  FAParams p{};
+  p.q = qkv;
+  p.k = (const char*)qkv + C * es;
+  p.v = (const char*)qkv + 2 * C * es;
+  p.out = out;
+  p.B = B; p.H = heads; p.Nq = (int)N; p.Nk = (int)N;
+  p.q_sb = p.k_sb = p.v_sb = N * 3 * C; p.q_st = p.k_st = p.v_st = 3 * C; p.q_sh = p.k_sh = p.v_sh = hd;
+  p.o_sb = N * C; p.o_st = C; p.o_sh = hd;
+  p.tab_h = tab_h; p.tab_w = tab_w; p.kh = gh; p.kw = gw; p.key_mask = nullptr;
   p.scale = scale; p.clamp = 0.f;
   return flash_attn_impl(p, hd, dtype, stream);
 }

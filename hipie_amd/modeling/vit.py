@@ -129,8 +129,11 @@ class Attention(nn.Module):
         qkv16 = self.qkv(x).reshape(B, H * W, 3 * C).to(self.precision.attn).contiguous()
         # decomposed rel-pos bias from the UNSCALED q (utils.py:113-123): one MFMA launch on the packed qkv tensor
         th, tw = self._rel_tables(H, W)
-        rel_h, rel_w = ops.vit_relpos(qkv16, th, tw, (H, W), nh)
-        o = ops.vit_attn(qkv16, rel_h, rel_w, (H, W), nh, self.scale)
+        if ops.vit_attn_fused_ok((H, W), hd):
+            o = ops.vit_attn_fused(qkv16, th, tw, (H, W), nh, self.scale)      # bias from the tables inside the kernel
+        else:
+            rel_h, rel_w = ops.vit_relpos(qkv16, th, tw, (H, W), nh)
+            o = ops.vit_attn(qkv16, rel_h, rel_w, (H, W), nh, self.scale)
         return self.proj(o.to(x.dtype)).view(B, H, W, C)
 
 

@@ -175,6 +175,26 @@ def vit_attn(qkv, rel_h, rel_w, grid_hw, heads, scale):
     return out
 
 
+def vit_attn_fused_ok(grid_hw, hd):
+    """the geometry hipie_vit_attn_fused covers: a 64-wide token grid (1024-pixel images), <= 64 rows, head_dim 64 / 80."""
+    return grid_hw[1] == 64 and 1 <= grid_hw[0] <= 64 and hd in (64, 80)
+
+
+@_timed("vit_attn_global")
+def vit_attn_fused(qkv, tab_h, tab_w, grid_hw, heads, scale):
+    """global ViT attention with the decomposed rel-pos bias computed in the kernel prologue from the tables:
+    qkv (B, gh*gw, 3*heads*hd) 16-bit, tab_h (2*gh-1, hd), tab_w (2*gw-1, hd) same dtype -> (B, N, heads*hd)."""
+    lib = _lib.load()
+    gh, gw = grid_hw
+    B, N, C3 = qkv.shape
+    hd = C3 // (3 * heads)
+    out = torch.empty(B, N, heads * hd, dtype=qkv.dtype, device=qkv.device)
+    rc = lib.hipie_vit_attn_fused(_chk(qkv, "qkv"), _chk(tab_h, "tab_h", qkv.dtype), _chk(tab_w, "tab_w", qkv.dtype),
+                                  out.data_ptr(), B, gh, gw, heads, hd, float(scale), _DT[qkv.dtype], _stream())
+    _lib.check(rc, "hipie_vit_attn_fused")
+    return out
+
+
 @_timed("bi_xattn")
 def bi_xattn(q, k, vv, vl, text_mask, clamp=50000.0):
     """q, vv (B,Nv,H,hd); k, vl (B,L,H,hd) 16-bit contiguous; text_mask (B,L) -> out_v (B,Nv,H*hd), out_l (B,L,H*hd)."""

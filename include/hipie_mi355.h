@@ -157,6 +157,17 @@ int hipie_add_layernorm(const void* x, const void* delta, const float* gamma, co
                         void* stream);
 
 /*
+ * hipie_vit_attn with the decomposed relative-position bias computed INSIDE the kernel from the (re-interpolated) tables
+ * (get_rel_pos + add_decomposed_rel_pos, hipie/backbone/utils.py:63-125): bias_w[q, kx] = q . Rw[qx - kx + gw - 1] and
+ * bias_h[q, ky] = q . Rh[qy - ky + gh - 1] are two MFMA products per wave in the prologue, so neither hipie_vit_relpos nor
+ * its (B*heads, N, gh + gw) fp32 outputs are needed.  tab_h (2*gh-1, hd), tab_w (2*gw-1, hd) in `dtype`, entry
+ * [q - k + size - 1].  Geometry: gw == 64, gh <= 64, hd in {64, 80} (the 1024-pixel global blocks); else HIPIE_EINVAL and the
+ * caller uses hipie_vit_relpos + hipie_vit_attn.
+ */
+int hipie_vit_attn_fused(const void* qkv, const void* tab_h, const void* tab_w, void* out, int B, int gh, int gw, int heads,
+                         int hd, float scale, int dtype, void* stream);
+
+/*
  * hipie_add_layernorm with row maps, so that window_partition / window_unpartition (hipie/backbone/utils.py:16-60) around
  * the windowed ViT blocks (backbone/vit.py:214-225) cost no pass of their own:
  *   for every OUTPUT row j < out_rows:  r = out_src ? out_src[j] : j;   r < 0: norm_out[j] = 0 (a pad token);  otherwise

@@ -162,6 +162,53 @@ def test_vit_attention(name, dt, tol_same, tol_gold):
     assert rel_err(g.like(name + "_out", out), g[name + "_out"]) < tol_gold
 
 
+@pytest.mark.parametrize("dt,tol_same,tol_gold", [(torch.float16, 1e-3, 2e-3), (torch.bfloat16, 8e-3, 2e-2)])
+def test_vit_attention_fused_relpos(dt, tol_same, tol_gold):
+    """hipie_vit_attn_fused (rel-pos bias computed in the kernel from the tables) on the real 64x64 grid: against the oracle
+    on the same 16-bit operands and tables, and against the reference golden."""
+    import torch.nn.functional as F
+    from hipie_amd import ops
+    g = Golden("vit_attn")
+    c, sd, x = vit_attn_case(g, "global64")
+    B, H, W, C = x.shape
+    heads = c["heads"]
+    hd = C // heads
+    assert ops.vit_attn_fused_ok((H, W), hd)
+    qkv = _vit_qkv(c, sd, x).to(dt)
+    q, k, v = qkv.float().reshape(B, H * W, 3, heads, hd).permute(2, 0, 3, 1, 4).reshape(3, B * heads, H * W, hd).unbind(0)
+    th, tw = sd["rel_pos_h"].to(dt), sd["rel_pos_w"].to(dt)           # (2*64-1, hd): no re-interpolation needed
+    got = ops.vit_attn_fused(qkv.to(DEV), th.to(DEV).contiguous(), tw.to(DEV).contiguous(), (H, W), heads, hd ** -0.5).float().cpu()
+    want = oo.vit_attention_core(q, k, v, th.float(), tw.float(), (H, W), hd ** -0.5)
+    want = want.view(B, heads, H * W, hd).permute(0, 2, 1, 3).reshape(B, H * W, C)
+    assert rel_err(got, want) < tol_same
+    out = F.linear(got, sd["proj.weight"], sd["proj.bias"]).view(B, H, W, C)
+    assert rel_err(g.like("global64_out", out), g["global64_out"]) < tol_gold
+
+
+@pytest.mark.parametrize("B,gh,heads,hd", [(2, 48, 8, 64), (1, 64, 16, 80), (3, 5, 3, 80)])
+def test_vit_attention_fused_equals_unfused(B, gh, heads, hd):
+    """fused prologue == hipie_vit_relpos + hipie_vit_attn on random data: batch/head swizzle on and off, fewer rows than 64."""
+    from hipie_amd import ops
+    gw = 64
+    gen = torch.Generator().manual_seed(gh * 7 + hd)
+    qkv = (torch.randn(B, gh * gw, 3 * heads * hd, generator=gen) * 0.7).bfloat16().to(DEV)
+    th = (torch.randn(2 * gh - 1, hd, generator=gen) * 0.3).bfloat16().to(DEV)
+    tw = (torch.randn(2 * gw - 1, hd, generator=gen) * 0.3).bfloat16().to(DEV)
+    rel_h, rel_w = ops.vit_relpos(qkv, th, tw, (gh, gw), heads)
+    a = ops.vit_attn(qkv, rel_h, rel_w, (gh, gw), heads, hd ** -0.5).float()
+    b = ops.vit_attn_fused(qkv, th, tw, (gh, gw), heads, hd ** -0.5).float()
+    assert rel_err(b.cpu(), a.cpu()) < 4e-3                            # both round P to bf16; the biases agree to fp32 rounding
+
+
+def test_vit_attention_fused_rejects_other_grids():
+    from hipie_amd import ops
+    from hipie_amd._lib import HipieLibraryError
+    qkv = torch.zeros(1, 14 * 14, 3 * 80, dtype=torch.bfloat16, device=DEV)
+    t = torch.zeros(27, 80, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises((HipieLibraryError, RuntimeError)):
+        ops.vit_attn_fused(qkv, t, t, (14, 14), 1, 80 ** -0.5)
+
+
 @pytest.mark.parametrize("dt,tol", [(torch.float16, 1.5e-3), (torch.bfloat16, 1e-2)])
 @pytest.mark.parametrize("name", ["L20", "L600_pad", "clamp"])
 def test_bi_xattn(name, dt, tol):
