@@ -115,6 +115,8 @@ def main():
                     "showed an unexplained GPU memory fault -- DESIGN.md section 9)")
     ap.add_argument("--no-gemm-table", action="store_true", help="do not load the committed TunableOp table "
                     "(hipie_amd/tuning/*.csv: the hipBLASLt solution picked per ViT-H linear shape; library plumbing)")
+    ap.add_argument("--timed-only", action="store_true", help="stop right after the timed region (for kernel traces: no "
+                    "extra roofline / post-processing passes at the end of the trace)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--breakdown", action="store_true", help="after the timed region, time every hand-written kernel class "
                     "and the main stages of one extra step (stderr)")
@@ -209,6 +211,11 @@ def main():
     dt = time.perf_counter() - t0
     dt = parallel.max_over_ranks(dt, dev)
 
+    if args.timed_only:
+        if rank == 0:
+            print(json.dumps({"ms_per_step": round(dt / args.steps * 1e3, 2), "images_per_sec": round(args.batch * world * args.steps / dt, 3)}))
+        return
+
     # dominant hand-written kernel, timed live with HIP events on the launch stream: the same 24 launches per step of the
     # global-attention kernel, issued eagerly (events cannot be placed inside a graph replay) right after the timed region
     ops.PROFILE.enable("vit_attn_global")
@@ -256,7 +263,7 @@ def main():
                                    % (args.model, args.size, args.size, args.batch, n_classes, L),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "precision_policy": args.precision,
                        "launch": "hipGraph replay" if graph is not None else "eager"},
-            "roofline": {"bound": "mfma", "kernel": "flash_attn_kernel<bf16,hd80,NB2,relpos> (ViT global attention, %d launches timed)" % kern_n,
+            "roofline": {"bound": "mfma", "kernel": "flash_attn_kernel<bf16,hd80,NB2,4 waves,fused rel-pos bias> (ViT global attention, %d launches timed)" % kern_n,
                          "achieved": None if ach is None else round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": None if ach is None else round(ach / 2500.0, 4), "traffic": None,
                          "avg_launch_ms": None if not kern_ms else round(kern_ms, 4),

@@ -43,6 +43,7 @@ struct FAParams {
 };
 
 constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kDefer = 8.f;                 // log2 of the largest P the deferred running max lets through
 
 // T: bf16_t | f16_t;  HD: head dim;  NB: 32-key blocks per tile;  QB: 32-query blocks per wave;  BIAS: decomposed rel-pos
 // bias (tile == key row);  CLAMP: clamp scale*q.k to +-clamp.
@@ -370,11 +371,22 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || HD <= 80) ? 2 : 1) void 
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[qb][blk][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32)) + bh_t[qb];
-      const float m_new = fmaxf(m_run[qb], mx);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;          // all keys so far masked: keep exp2() finite
-      const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_use);   // m_run = -inf -> 0
-      const float off = bh_t[qb] - m_use;
-      m_run[qb] = m_new;
+      // deferred max: the reference point m_run only moves when some row's maximum grew by more than 2^kDefer (or is
+      // still unset); otherwise P = exp2(s - m_run) <= 2^kDefer stays well inside fp32 / 16-bit range and the O rescale
+      // (and its exp2) is skipped for the whole wave -- with 32 rows per wave a plain running max moves in most tiles.
+      const bool grow = mx > m_run[qb] + kDefer;                        // m_run = -inf: true as soon as a key is valid
+      if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {
+        const float m_new = fmaxf(m_run[qb], mx);
+        const float m_ref = (m_new == -INFINITY) ? 0.f : m_new;         // all keys so far masked: keep exp2() finite
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_ref);  // m_run = -inf -> 0
+        m_run[qb] = m_new;
+        if (!LTRICK) l_run[qb] *= alpha;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) O[qb][d][r] *= alpha;
+      }
+      const float off = bh_t[qb] - ((m_run[qb] == -INFINITY) ? 0.f : m_run[qb]);
       float lsum = 0.f;
 #pragma unroll
       for (int blk = 0; blk < NB; ++blk)
@@ -384,13 +396,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || HD <= 80) ? 2 : 1) void 
           S[qb][blk][r] = pv;
           if (!LTRICK) lsum += pv;
         }
-      if (!LTRICK) l_run[qb] = l_run[qb] * alpha + lsum;
-      if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {   // wave-uniform: no row max moved in this tile -> O stays as is
-#pragma unroll
-        for (int d = 0; d < DB; ++d)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) O[qb][d][r] *= alpha;
-      }
+      if (!LTRICK) l_run[qb] += lsum;
     }
 
     // ---- O^T += V^T . P^T  (each V^T fragment feeds QB MFMAs) ----

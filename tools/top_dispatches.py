@@ -11,7 +11,14 @@ frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 t0, t1 = int(rows[0]["Start_Timestamp"]), int(rows[-1]["End_Timestamp"])
-cut = t1 - (t1 - t0) * frac
+if frac >= 1.0:
+    # frac = K >= 1: the window is the last K forwards, located by the 24 global-attention launches each one issues
+    marks = [int(r["Start_Timestamp"]) for r in rows if "flash_attn_kernel" in r["Kernel_Name"] and "Li80ELi2E" in r["Kernel_Name"]]
+    k = int(frac) * 24
+    cut = marks[-k] - 1500000 if len(marks) >= k else t0          # minus ~1.5 ms: the text encoder / patch embed before it
+    print("window = last %d forwards" % int(frac))
+else:
+    cut = t1 - (t1 - t0) * frac
 rows = [r for r in rows if int(r["Start_Timestamp"]) >= cut]
 tot = collections.defaultdict(lambda: [0, 0])
 split = collections.defaultdict(lambda: [0, 0])
