@@ -38,7 +38,7 @@ struct FAParams {
   const float* bias_h; const float* bias_w; int kh, kw;
   const void* tab_h; const void* tab_w;          // FUSEREL: rel-pos tables (2*kh-1, HD), (2*kw-1, HD) in the operand dtype
   const uint8_t* key_mask;
-  float scale, clamp;
+  float scale, clamp, defer;
   int nqt, ntiles, swz;
 };
 
@@ -72,7 +72,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || HD <= 80) ? 2 : 1) void 
   // HD = 80 pads O^T to 96 rows: row HD of the padded block is free, so a column of ones at V[:, HD] makes the PV MFMAs
   // accumulate the softmax denominator  l = sum_k P[k]  there (from the same 16-bit-rounded P as the numerator) -- the 32
   // per-tile VALU adds of the row sum disappear.
-  constexpr bool LTRICK = (HD % 32) != 0;
+  // fp16 is the parity policy's operand type: there the denominator stays an fp32 sum of the unrounded probabilities
+  constexpr bool LTRICK = (HD % 32) != 0 && sizeof(T) == 2 && !__is_same(T, f16_t);
   constexpr int L_ROW = HD % 32, L_HI = (L_ROW >> 2) & 1, L_REG = (L_ROW & 3) + 4 * (L_ROW >> 3);
   typedef typename Mfma32<T>::frag frag;
   typedef typename Mfma32<T>::half_frag hfrag;
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || HD <= 80) ? 2 : 1) void 
       // deferred max: the reference point m_run only moves when some row's maximum grew by more than 2^kDefer (or is
       // still unset); otherwise P = exp2(s - m_run) <= 2^kDefer stays well inside fp32 / 16-bit range and the O rescale
       // (and its exp2) is skipped for the whole wave -- with 32 rows per wave a plain running max moves in most tiles.
-      const bool grow = mx > m_run[qb] + kDefer;                        // m_run = -inf: true as soon as a key is valid
+      const bool grow = mx > m_run[qb] + p.defer;                        // m_run = -inf: true as soon as a key is valid
       if (__builtin_amdgcn_ballot_w64(grow) != 0ull) {
         const float m_new = fmaxf(m_run[qb], mx);
         const float m_ref = (m_new == -INFINITY) ? 0.f : m_new;         // all keys so far masked: keep exp2() finite
@@ -526,6 +527,8 @@ static int flash_attn_impl(FAParams p, int hd, int dtype, void* stream) {
   for (long s : strides) HIPIE_REQUIRE(s % 8 == 0, "flash_attn: strides must be multiples of 8 elements (16 bytes), got %ld", s);
   HIPIE_REQUIRE((((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v | (uintptr_t)p.out) & 15) == 0, "flash_attn: pointers must be 16-byte aligned");
   p.swz = ((p.B * p.H) % 8 == 0) ? 1 : 0;
+  p.defer = (dtype == HIPIE_F16) ? 0.f : kDefer;      // fp16 = parity policy: classic running max
+  { const char* d = getenv("HIPIE_FA_DEFER"); if (d) p.defer = (float)atof(d); }
   // 8 waves (256 queries) per workgroup halve the K/V traffic per query but keep all waves of a CU in lockstep
   bool wide = false;       // measured: two independent 4-wave workgroups per CU (1.09 ms) beat one 8-wave workgroup (1.16 ms)
   const char* e = getenv("HIPIE_FA_WAVES");

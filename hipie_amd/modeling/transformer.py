@@ -11,6 +11,7 @@ Inference only.  Residual streams, LayerNorm/GroupNorm, softmax and all geometry
 policy's ``head`` dtype (fp32 by default, like the reference's custom_fwd(cast_inputs=float32)).
 """
 import copy
+import os
 import math
 
 import torch

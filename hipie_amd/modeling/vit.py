@@ -6,6 +6,7 @@ parameter names, so reference checkpoints load unchanged.  The attention core ru
 policy's 16-bit types.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
