@@ -88,6 +88,9 @@ class HIPIE_IMG(nn.Module):
             # MIOpen "find": benchmark the applicable solvers once per convolution configuration instead of the
             # immediate-mode heuristic (the shapes are static over an evaluation run); -7 ms per bs-8 ViT-H step
             torch.backends.cudnn.benchmark = True
+        for m in self.modules():                       # per-geometry caches that fold (now final) parameters
+            if hasattr(m, "_own_cache"):
+                m._own_cache.clear()
         bb = self.detr.detr.backbone[0].backbone
         if hasattr(bb, "cast_weights"):
             bb.cast_weights()

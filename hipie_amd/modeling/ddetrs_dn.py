@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from .maskdino import MaskDINOHead
-from .transformer import (MLP, FeatureResizer, NestedTensor, PConv2d, _get_clones, agg_lang_feat, inverse_sigmoid,
+from .transformer import (MLP, FeatureResizer, NestedTensor, PConv2d, _get_clones, agg_lang_feat, geo_cached, inverse_sigmoid,
                           nested_tensor_from_images)
 
 
@@ -73,14 +73,17 @@ class DDETRSegmUniDN(nn.Module):
             srcs.append(self.detr.input_proj[l](src))
             masks.append(mask)
             poses.append(pos[l])
+        gk = samples.geo_key
         for l in range(len(features), self.detr.num_feature_levels):
             src = self.detr.input_proj[l](features[-1].tensors if l == len(features) else srcs[-1])
-            mask = F.interpolate(masks[0][None].float(), size=src.shape[-2:]).to(torch.bool)[0]     # level-0 mask (:841)
+            hw = tuple(src.shape[-2:])
+            mask = geo_cached(gk, ("level_mask0", hw),
+                              lambda: F.interpolate(masks[0][None].float(), size=hw).to(torch.bool)[0])   # level-0 mask (:841)
             srcs.append(src)
             masks.append(mask)
-            poses.append(self.detr.backbone[1](mask).to(src.dtype))
+            poses.append(geo_cached(gk, ("pos0", hw, src.dtype), lambda: self.detr.backbone[1](mask).to(src.dtype)))
         hs, memory, init_reference, inter_references, _, _, language_dict_features, spatial_shapes = \
-            self.detr.transformer(srcs, masks, poses, language_dict_features, task=task)
+            self.detr.transformer(srcs, masks, poses, language_dict_features, task=task, geo_key=gk)
 
         features_maskdino = {k: v.tensors for k, v in zip(self.feature_keys, features)}
         lang = lang_feat_pool if task in ("grounding", "sot") else language_dict_features["hidden"]

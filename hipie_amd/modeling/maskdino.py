@@ -6,12 +6,14 @@ transformer_decoder/maskdino_decoder.py (MaskDINODecoder, eval path), transforme
 (TransformerDecoder) and meta_arch/maskdino_head.py (MaskDINOHead) with the reference's parameter names.
 The branch is called with mask=None (ddetrs_dn.py:885): all-False padding masks, valid_ratio 1.
 """
+import collections
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from .transformer import (MLP, DeformableTransformerDecoderLayer, DeformableTransformerEncoderLayer, FeatureResizer,
+from .transformer import (MLP, DeformableTransformerDecoderLayer, DeformableTransformerEncoderLayer, FeatureResizer, geo_cached,
                           PConv2d, PGroupNorm, PLayerNorm, PLinear, PositionEmbeddingSine, _get_clones, encoder_reference_points,
                           gen_encoder_output_proposals, get_sine_pos_embed, inverse_sigmoid, level_tensors)
 
@@ -47,12 +49,17 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
     def forward(self, srcs, pos_embeds):
         shapes_list = [tuple(int(v) for v in s.shape[-2:]) for s in srcs]
         src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
-        pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[i].view(1, 1, -1) for i, p in enumerate(pos_embeds)], 1)
-        pos = pos.to(src.dtype)
         B = src.shape[0]
+        # all-valid masks: the geometry is (batch, level shapes) alone
+        gk = ("md_enc", B, tuple(shapes_list), str(src.device), src.dtype)
+        if not hasattr(self, "_own_cache"):
+            self._own_cache = collections.OrderedDict()
+        pos = geo_cached(gk, "pos_flat", lambda: torch.cat(
+            [p.flatten(2).transpose(1, 2) + self.level_embed[i].view(1, 1, -1) for i, p in enumerate(pos_embeds)], 1).to(src.dtype),
+            store=self._own_cache)
         spatial_shapes, level_start_index = level_tensors(shapes_list, src.device)
-        valid_ratios = torch.ones(B, len(srcs), 2, device=src.device)
-        refs = encoder_reference_points(shapes_list, valid_ratios, src.device)
+        refs = geo_cached(gk, "enc_refs", lambda: encoder_reference_points(
+            shapes_list, torch.ones(B, len(srcs), 2, device=src.device), src.device))
         for layer in self.encoder.layers:
             src = layer(src, pos, refs, spatial_shapes, level_start_index, None)
         return src, shapes_list
@@ -79,8 +86,8 @@ class MaskDINOEncoder(nn.Module):
         f3, f4, f5 = features["res3"], features["res4"], features["res5"]      # the projections cast / lay out their input
         extra = self.input_proj[3](f5)
         srcs = [self.input_proj[i](f) for i, f in enumerate((f3, f4, f5))] + [extra]
-        zero = [torch.zeros(s.shape[0], s.shape[2], s.shape[3], dtype=torch.bool, device=s.device) for s in srcs]
-        pos = [self.pe_layer(z) for z in zero]
+        pos = [geo_cached(("md_pe", tuple(s.shape[0:1]) + tuple(s.shape[2:]), str(s.device)), "pos", lambda s=s: self.pe_layer(
+            torch.zeros(s.shape[0], s.shape[2], s.shape[3], dtype=torch.bool, device=s.device))) for s in srcs]
         y, shapes = self.transformer(srcs, pos)
         B = y.shape[0]
         out, st = [], 0
@@ -146,10 +153,11 @@ class MaskDINODecoder(nn.Module):
         shapes_list = [tuple(int(v) for v in t.shape[-2:]) for t in xs]
         src = torch.cat([t.flatten(2).transpose(1, 2) for t in xs], 1)
         B = src.shape[0]
-        mask = torch.zeros(B, src.shape[1], dtype=torch.bool, device=src.device)
+        gk = ("md_dec", B, tuple(shapes_list), str(src.device))
+        mask = geo_cached(gk, "mask_flat", lambda: torch.zeros(B, src.shape[1], dtype=torch.bool, device=src.device))
         spatial_shapes, level_start_index = level_tensors(shapes_list, src.device)
-        vr2 = torch.ones(B, 1, nl, 4, device=src.device)
-        om, prop = gen_encoder_output_proposals(src, mask, shapes_list)
+        vr2 = geo_cached(gk, "vr2", lambda: torch.ones(B, 1, nl, 4, device=src.device))
+        om, prop = gen_encoder_output_proposals(src, mask, shapes_list, gk)
         om = self.enc_output_norm(self.enc_output(om))
         cls_un = self.class_embed(om)
         coord_un = self._bbox_embed(om) + prop

@@ -10,6 +10,7 @@ Mirrors, with the reference's parameter names:
 Inference only.  Residual streams, LayerNorm/GroupNorm, softmax and all geometry stay fp32; linears/convs run in the
 policy's ``head`` dtype (fp32 by default, like the reference's custom_fwd(cast_inputs=float32)).
 """
+import collections
 import copy
 import os
 import math
@@ -133,9 +134,33 @@ class FeatureResizer(nn.Module):
 
 
 # --------------------------------------------------------------------------- backbone wrappers + sine position
+_GEO_CACHE = collections.OrderedDict()
+
+
+def geo_cached(geo_key, what, build, store=None):
+    """Everything that depends only on the padding masks -- level masks, sine position embeddings, valid ratios, encoder
+    reference points, two-stage proposals -- is a function of the batch geometry (image sizes + padded canvas).  An
+    evaluation run repeats a handful of geometries, so these are computed once per geometry and reused (read-only)
+    instead of re-issuing a few hundred tiny cumsum / sin / cos / sum / cat kernels per forward.  geo_key None: no caching.
+    ``store``: a module-owned OrderedDict for values that also depend on that module's (frozen) parameters."""
+    if geo_key is None:
+        return build()
+    cache = _GEO_CACHE if store is None else store
+    key = (geo_key, what)
+    v = cache.get(key)
+    if v is None:
+        v = build()
+        cache[key] = v
+        if len(cache) > (512 if store is None else 32):
+            cache.popitem(last=False)
+    else:
+        cache.move_to_end(key)
+    return v
+
+
 class NestedTensor(object):
-    def __init__(self, tensors, mask):
-        self.tensors, self.mask = tensors, mask
+    def __init__(self, tensors, mask, geo_key=None):
+        self.tensors, self.mask, self.geo_key = tensors, mask, geo_key
 
     def decompose(self):
         return self.tensors, self.mask
@@ -147,12 +172,18 @@ def nested_tensor_from_images(images, size_divisibility=32):
     W = max(int(im.shape[2]) for im in images)
     H = (H + size_divisibility - 1) // size_divisibility * size_divisibility
     W = (W + size_divisibility - 1) // size_divisibility * size_divisibility
-    t = torch.zeros(len(images), 3, H, W, dtype=images[0].dtype, device=images[0].device)
-    m = torch.ones(len(images), H, W, dtype=torch.bool, device=images[0].device)
+    dev = images[0].device
+    t = torch.zeros(len(images), 3, H, W, dtype=images[0].dtype, device=dev)
+    geo_key = (tuple((int(im.shape[1]), int(im.shape[2])) for im in images), (H, W), str(dev))
+
+    def build_mask():
+        m = torch.ones(len(images), H, W, dtype=torch.bool, device=dev)
+        for i, im in enumerate(images):
+            m[i, :im.shape[1], :im.shape[2]] = False
+        return m
     for i, im in enumerate(images):
         t[i, :, :im.shape[1], :im.shape[2]].copy_(im)
-        m[i, :im.shape[1], :im.shape[2]] = False
-    return NestedTensor(t, m)
+    return NestedTensor(t, geo_cached(geo_key, "pixel_mask", build_mask), geo_key)
 
 
 class PositionEmbeddingSine(nn.Module):
@@ -188,9 +219,12 @@ class MaskedBackbone(nn.Module):
     def forward(self, tensor_list):
         xs = self.backbone(tensor_list.tensors)
         out = {}
+        gk = tensor_list.geo_key
         for name, x in xs.items():
-            mask = F.interpolate(tensor_list.mask[None].float(), size=x.shape[-2:]).to(torch.bool)[0]
-            out[name] = NestedTensor(x, mask)
+            hw = tuple(x.shape[-2:])
+            mask = geo_cached(gk, ("level_mask", hw),
+                              lambda: F.interpolate(tensor_list.mask[None].float(), size=hw).to(torch.bool)[0])
+            out[name] = NestedTensor(x, mask, gk)
         return out
 
 
@@ -203,7 +237,8 @@ class Joiner(nn.Sequential):
     def forward(self, tensor_list):
         xs = self[0](tensor_list)
         out = [x for _, x in sorted(xs.items())]
-        pos = [self[1](x.mask).to(x.tensors.dtype) for x in out]
+        pos = [geo_cached(x.geo_key, ("pos", tuple(x.mask.shape), x.tensors.dtype, self[1].offset),
+                          lambda x=x: self[1](x.mask).to(x.tensors.dtype)) for x in out]
         return out, pos
 
 
@@ -351,9 +386,10 @@ class DeformableTransformerEncoderVL(nn.Module):
         self.layers = _get_clones(encoder_layer, num_layers)
         self.lang_layers = nn.ModuleList([nn.Identity() for _ in range(num_layers)])
 
-    def forward(self, src, shapes_list, spatial_shapes, level_start_index, valid_ratios, pos, padding_mask, lang, task=None):
+    def forward(self, src, shapes_list, spatial_shapes, level_start_index, valid_ratios, pos, padding_mask, lang, task=None,
+                geo_key=None):
         output = {"visual": src, "lang": lang}
-        refs = encoder_reference_points(shapes_list, valid_ratios, src.device)
+        refs = geo_cached(geo_key, "enc_refs", lambda: encoder_reference_points(shapes_list, valid_ratios, src.device))
         for vl_layer, layer in zip(self.vl_layers, self.layers):
             if not isinstance(vl_layer, nn.Identity):
                 output = vl_layer(output, task=task)
@@ -446,16 +482,23 @@ class DeformableTransformerDecoder(nn.Module):
         return torch.stack(inter), torch.stack(inter_refs)
 
 
-def gen_encoder_output_proposals(memory, memory_padding_mask, shapes_list):
-    """deformable_transformer_dino.py:138-166 / maskdino/utils/utils.py:33-71 (without the enc_output projection)."""
-    N_ = memory.shape[0]
+def gen_encoder_output_proposals(memory, memory_padding_mask, shapes_list, geo_key=None):
+    """deformable_transformer_dino.py:138-166 / maskdino/utils/utils.py:33-71 (without the enc_output projection).
+    The proposals and the keep mask depend only on the geometry (cached); the memory masking is one masked_fill."""
+    keep, prop = geo_cached(geo_key, ("proposals", tuple(shapes_list)),
+                            lambda: _proposal_geometry(memory_padding_mask, shapes_list, memory.shape[0], memory.device))
+    return memory.masked_fill(~keep, 0.0), prop
+
+
+def _proposal_geometry(memory_padding_mask, shapes_list, N_, device):
+    memory = None
     proposals, _cur = [], 0
     for lvl, (H_, W_) in enumerate(shapes_list):
         m = memory_padding_mask[:, _cur:_cur + H_ * W_].view(N_, H_, W_, 1)
         valid_H = torch.sum(~m[:, :, 0, 0], 1)
         valid_W = torch.sum(~m[:, 0, :, 0], 1)
-        gy, gx = torch.meshgrid(torch.linspace(0, H_ - 1, H_, dtype=torch.float32, device=memory.device),
-                                torch.linspace(0, W_ - 1, W_, dtype=torch.float32, device=memory.device), indexing="ij")
+        gy, gx = torch.meshgrid(torch.linspace(0, H_ - 1, H_, dtype=torch.float32, device=device),
+                                torch.linspace(0, W_ - 1, W_, dtype=torch.float32, device=device), indexing="ij")
         grid = torch.cat([gx.unsqueeze(-1), gy.unsqueeze(-1)], -1)
         scale = torch.cat([valid_W.unsqueeze(-1), valid_H.unsqueeze(-1)], 1).view(N_, 1, 1, 2)
         grid = (grid.unsqueeze(0).expand(N_, -1, -1, -1) + 0.5) / scale
@@ -466,8 +509,8 @@ def gen_encoder_output_proposals(memory, memory_padding_mask, shapes_list):
     valid = ((prop > 0.01) & (prop < 0.99)).all(-1, keepdim=True)
     prop = torch.log(prop / (1 - prop))
     prop = prop.masked_fill(memory_padding_mask.unsqueeze(-1), float("inf")).masked_fill(~valid, float("inf"))
-    mem = memory.masked_fill(memory_padding_mask.unsqueeze(-1), 0.0).masked_fill(~valid, 0.0)
-    return mem, prop
+    keep = (~memory_padding_mask.unsqueeze(-1)) & valid
+    return keep, prop
 
 
 def get_valid_ratio(mask):
@@ -508,20 +551,25 @@ class DeformableTransformerVLDINO(nn.Module):
         self.pinned_topk = None          # test hook: indices for the discontinuous top-k (SURVEY 7 hard part (c))
         self.last_topk = None
 
-    def forward(self, srcs, masks, pos_embeds, language_dict_features, task=None):
+    def forward(self, srcs, masks, pos_embeds, language_dict_features, task=None, geo_key=None):
         shapes_list = [tuple(int(v) for v in s.shape[-2:]) for s in srcs]
         src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
-        mask = torch.cat([m.flatten(1) for m in masks], 1)
-        pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[i].view(1, 1, -1) for i, p in enumerate(pos_embeds)], 1)
-        pos = pos.to(src.dtype)                      # one cast here instead of one per encoder layer (src + pos promotes)
+        gk = None if geo_key is None else (geo_key, tuple(shapes_list), src.dtype)
+        mask = geo_cached(gk, "mask_flat", lambda: torch.cat([m.flatten(1) for m in masks], 1))
+        # position + level embedding, one cast (src + pos would promote per layer); constant per geometry at inference
+        if not hasattr(self, "_own_cache"):
+            self._own_cache = collections.OrderedDict()
+        pos = geo_cached(gk, "pos_flat", lambda: torch.cat(
+            [p.flatten(2).transpose(1, 2) + self.level_embed[i].view(1, 1, -1) for i, p in enumerate(pos_embeds)], 1).to(src.dtype),
+            store=self._own_cache)
         spatial_shapes, level_start_index = level_tensors(shapes_list, src.device)
-        valid_ratios = torch.stack([get_valid_ratio(m) for m in masks], 1)
+        valid_ratios = geo_cached(gk, "valid_ratios", lambda: torch.stack([get_valid_ratio(m) for m in masks], 1))
 
         enc = self.encoder(src, shapes_list, spatial_shapes, level_start_index, valid_ratios, pos, mask,
-                           language_dict_features, task=task)
+                           language_dict_features, task=task, geo_key=gk)
         memory, language_dict_features = enc["visual"], enc["lang"]
         bs = memory.shape[0]
-        om, prop = gen_encoder_output_proposals(memory, mask, shapes_list)
+        om, prop = gen_encoder_output_proposals(memory, mask, shapes_list, gk)
         om = self.enc_output_norm(self.enc_output(om))
         nd = self.decoder.num_layers
         enc_cls = self.decoder.class_embed[nd](om, None)
