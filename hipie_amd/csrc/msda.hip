@@ -8,16 +8,21 @@
 //
 // Mapping (D == 32 fast path): 8 lanes own one (b,q,m); each lane owns 4 consecutive channels, so a corner fetch of one
 // head is ONE 128-byte coalesced segment (8 lanes x 16 B) and a wave covers 8 heads = the full 1 KiB pixel line when
-// M == 8.  All L*P*4 = 64 corner fetches of a lane are independent -> the compiler keeps them in flight together
-// (latency hiding by ILP; the kernel is gather/L2-bound, never MFMA work).  Control flow is branch-free: out-of-range
-// samples / corners are clamped to a legal address and zeroed by select, exactly reproducing the zero padding of
-// ms_deform_attn_im2col_bilinear (ms_deform_im2col_cuda.cuh:33-84).
+// M == 8.  Two phases per (query, head): the location / bilinear / softmax arithmetic of the L*P points is split over the 8
+// lanes and published through LDS as (4 corner offsets, 4 weights) records; then all 8 lanes run a pure gather + FMA loop
+// over the records (it used to be repeated by every lane, which made the kernel VALU-bound: 0.9 -> 0.47 ms per bs-8
+// encoder call).  Control flow is branch-free: out-of-range samples / corners are clamped to a legal address and get a zero
+// weight, exactly reproducing the zero padding of ms_deform_attn_im2col_bilinear (ms_deform_im2col_cuda.cuh:33-84).
+// Tried and dropped: staging per-tile sampling windows of all levels in LDS (bit-identical results, 1.03 ms vs 0.47 ms) --
+// the gather is served well by L1/L2; occupancy and the per-point arithmetic are what matter.
 //
 // The FUSED variant additionally computes the sampling locations and the softmax over the L*P logits in registers
 // (ops/modules/ms_deform_attn.py:99-114) so the (B,Lq,M,L,P,2) location tensor never exists in HBM.
 //
 // Roofline: HBM/L2 bound.  Algorithmic bytes per call (f32): S*M*D*4 (value) + Lq*M*L*P*(2+1)*4 (loc, weights) +
 // Lq*M*D*4 (out) per image = 78 MB at Nv = 21760.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace hipie {
@@ -58,14 +63,100 @@ template <> struct Vec4<f16_t> {
 
 constexpr int kMaxLP = 32;  // L*P supported by the fused softmax (reference geometry: 4*4 = 16)
 
+// ---- shared by the D == 32 kernels: the per-point record (4 corner offsets + 4 weights) --------------------------------
+// The location / bilinear / softmax arithmetic of one sampling point is ~70 VALU instructions; the 8 lanes that share a
+// (query, head) used to repeat all of it (the kernel was VALU-bound at ~1800 instructions per lane, not gather-bound).  Now
+// each lane does it for LP/8 of the points (phase 1), publishes a record of 4 clamped corner offsets (elements, relative to
+// the head's slice of the image) and 4 weights (bilinear x attention weight, zero for padded corners) through LDS, and all
+// 8 lanes then run the pure gather + FMA loop over the records (phase 2).
+
+struct PointRec {
+  int o[4];
+  float w[4];
+};
+
+// sampling point at normalised (x, y) of an H x W level whose first pixel is `lbase` pixels into the image; `row` elements
+// per pixel; aw = attention weight.  Zero padding exactly as ms_deform_attn_im2col_bilinear (ms_deform_im2col_cuda.cuh:33-84).
+__device__ __forceinline__ PointRec point_record(float x, float y, int H, int W, long lbase, long row, float aw) {
+  const float h_im = y * (float)H - 0.5f;
+  const float w_im = x * (float)W - 0.5f;
+  const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
+  const float hf = floorf(h_im), wf = floorf(w_im);
+  const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+  const int h0 = inside ? (int)hf : 0, w0 = inside ? (int)wf : 0;
+  const int h1 = h0 + 1, w1 = w0 + 1;
+  const bool okh0 = inside && h0 >= 0, okh1 = inside && h1 <= H - 1;
+  const bool okw0 = w0 >= 0, okw1 = w1 <= W - 1;
+  const int ch0 = max(h0, 0), ch1 = min(h1, H - 1), cw0 = max(w0, 0), cw1 = min(w1, W - 1);
+  PointRec r;
+  r.o[0] = (int)((lbase + (long)ch0 * W + cw0) * row);
+  r.o[1] = (int)((lbase + (long)ch0 * W + cw1) * row);
+  r.o[2] = (int)((lbase + (long)ch1 * W + cw0) * row);
+  r.o[3] = (int)((lbase + (long)ch1 * W + cw1) * row);
+  r.w[0] = (okh0 && okw0) ? hh * hw * aw : 0.f;
+  r.w[1] = (okh0 && okw1) ? hh * lw * aw : 0.f;
+  r.w[2] = (okh1 && okw0) ? lh * hw * aw : 0.f;
+  r.w[3] = (okh1 && okw1) ? lh * lw * aw : 0.f;
+  return r;
+}
+
+// max / sum over the 8 lanes of a (query, head) group
+__device__ __forceinline__ float group_max8(float v) {
+  v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 4));
+  return v;
+}
+__device__ __forceinline__ float group_sum8(float v) {
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+  return v;
+}
+
+// phase 1 for one (batch*query row bq, head m): lane `sub` handles points sub, sub + 8, ...; records go to rec[point * 8 ..]
+template <typename A, bool FUSED>
+__device__ __forceinline__ void publish_records(float* rec, int sub, const A* lp, const A* wp, const float* refrow,
+                                                int ref_dim, const int64_t* shapes, const int64_t* lstart, int L, int P,
+                                                long row) {
+  const int LP = L * P;
+  float wmax = 0.f, winv = 1.f;
+  if (FUSED) {
+    float mx = -INFINITY;
+    for (int i = sub; i < LP; i += 8) mx = fmaxf(mx, elem<A>::to_f32(wp[i]));
+    wmax = group_max8(mx);
+    float sm = 0.f;
+    for (int i = sub; i < LP; i += 8) sm += expf(elem<A>::to_f32(wp[i]) - wmax);
+    winv = 1.f / group_sum8(sm);
+  }
+  for (int i = sub; i < LP; i += 8) {
+    const int l = i / P;
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    float x = elem<A>::to_f32(lp[2 * i]), y = elem<A>::to_f32(lp[2 * i + 1]), aw;
+    if (FUSED) {
+      const float* r = refrow + l * ref_dim;
+      if (ref_dim == 2) {                              // ref + off / (W_l, H_l)
+        x = r[0] + x / (float)W;
+        y = r[1] + y / (float)H;
+      } else {                                         // ref_xy + off / P * ref_wh * 0.5
+        x = r[0] + x / (float)P * r[2] * 0.5f;
+        y = r[1] + y / (float)P * r[3] * 0.5f;
+      }
+      aw = expf(elem<A>::to_f32(wp[i]) - wmax) * winv;
+    } else {
+      aw = elem<A>::to_f32(wp[i]);
+    }
+    const PointRec pr = point_record(x, y, H, W, lstart[l], row, aw);
+    *reinterpret_cast<int4*>(rec + i * 8) = make_int4(pr.o[0], pr.o[1], pr.o[2], pr.o[3]);
+    *reinterpret_cast<float4*>(rec + i * 8 + 4) = make_float4(pr.w[0], pr.w[1], pr.w[2], pr.w[3]);
+  }
+}
+
 // D == 32: 8 lanes per (b,q,m), 4 channels per lane.
-template <typename T, typename A, bool FUSED>
+template <typename T, typename A, bool FUSED, int U>
 __global__ __launch_bounds__(256) void msda_d32_kernel(const T* __restrict__ value, const int64_t* __restrict__ shapes,
                                                        const int64_t* __restrict__ lstart,
                                                        const A* __restrict__ loc_or_off, const A* __restrict__ w_or_logit,
                                                        const float* __restrict__ ref, T* __restrict__ out, int S, int M,
                                                        int L, int Lq, int P, int ref_dim, long total_groups,
                                                        long off_stride, long w_stride) {
+  extern __shared__ __attribute__((aligned(16))) float recs[];   // 32 groups x (LP * 8 + 4) words
   // XCD-aware block order: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md); give every XCD one CONTIGUOUS range of
   // (image, query) groups so that neighbouring queries -- which sample neighbouring value pixels -- share that XCD's L2
   // instead of all eight L2s streaming the whole value tensor.  Placement only affects speed.
@@ -74,80 +165,37 @@ __global__ __launch_bounds__(256) void msda_d32_kernel(const T* __restrict__ val
   const long xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   const long blk = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
   const long g = blk * 32 + (threadIdx.x >> 3);
-  if (g >= total_groups) return;
+  const bool live = g < total_groups;
+  const long gc = live ? g : total_groups - 1;         // dead groups recompute the last one (the shuffles need every lane)
   const int sub = threadIdx.x & 7;
-  const int m = (int)(g % M);
-  const long bq = g / M;
+  const int m = (int)(gc % M);
+  const long bq = gc / M;
   const int b = (int)(bq / Lq);
   const int LP = L * P;
+  const long row = (long)M * 32;                       // elements per pixel
+  float* rec = recs + (threadIdx.x >> 3) * (LP * 8 + 4);      // +4 words: the 8 groups of a wave land on disjoint banks
   // row = one (batch, query); offsets / logits of head m inside the row (dense rows when the strides are M*L*P*2 / M*L*P)
-  const A* lp = loc_or_off + bq * off_stride + (long)m * (LP * 2);
-  const A* wp = w_or_logit + bq * w_stride + (long)m * LP;
-
-  float wmax = 0.f, winv = 1.f;
-  if (FUSED) {
-    wmax = -INFINITY;
-    for (int i = 0; i < LP; ++i) wmax = fmaxf(wmax, elem<A>::to_f32(wp[i]));
-    float s = 0.f;
-    for (int i = 0; i < LP; ++i) s += expf(elem<A>::to_f32(wp[i]) - wmax);
-    winv = 1.f / s;
-  }
+  publish_records<A, FUSED>(rec, sub, loc_or_off + bq * off_stride + (long)m * (LP * 2), w_or_logit + bq * w_stride + (long)m * LP,
+                            FUSED ? ref + bq * L * ref_dim : nullptr, ref_dim, shapes, lstart, L, P, row);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();                      // the 8 lanes of a group live in one wave: no block barrier needed
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  const long row = (long)M * 32;                       // elements per pixel
   const T* vb = value + (long)b * S * row + m * 32 + sub * 4;
-  for (int l = 0; l < L; ++l) {
-    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
-    const T* vl = vb + (long)lstart[l] * row;
-    float rx = 0.f, ry = 0.f, rw = 0.f, rh = 0.f;
-    if (FUSED) {
-      const float* r = ref + (bq * L + l) * ref_dim;
-      rx = r[0]; ry = r[1];
-      if (ref_dim == 4) { rw = r[2]; rh = r[3]; }
-    }
-#pragma unroll 4
-    for (int p = 0; p < P; ++p) {
-      const int i = l * P + p;
-      float x = elem<A>::to_f32(lp[2 * i]), y = elem<A>::to_f32(lp[2 * i + 1]), w;
-      if (FUSED) {
-        if (ref_dim == 2) {                            // ref + off / (W_l, H_l)
-          x = rx + x / (float)W;
-          y = ry + y / (float)H;
-        } else {                                       // ref_xy + off / P * ref_wh * 0.5
-          x = rx + x / (float)P * rw * 0.5f;
-          y = ry + y / (float)P * rh * 0.5f;
-        }
-        w = expf(elem<A>::to_f32(wp[i]) - wmax) * winv;
-      } else {
-        w = elem<A>::to_f32(wp[i]);
-      }
-      const float h_im = y * (float)H - 0.5f;
-      const float w_im = x * (float)W - 0.5f;
-      const bool inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)H) && (w_im < (float)W);
-      const float hf = floorf(h_im), wf = floorf(w_im);
-      const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-      const int h0 = inside ? (int)hf : 0, w0 = inside ? (int)wf : 0;
-      const int h1 = h0 + 1, w1 = w0 + 1;
-      const bool okh0 = inside && h0 >= 0, okh1 = inside && h1 <= H - 1;
-      const bool okw0 = w0 >= 0, okw1 = w1 <= W - 1;
-      const int ch0 = max(h0, 0), ch1 = min(h1, H - 1), cw0 = max(w0, 0), cw1 = min(w1, W - 1);
-      float v1[4], v2[4], v3[4], v4[4];
-      Vec4<T>::load(vl + ((long)ch0 * W + cw0) * row, v1);
-      Vec4<T>::load(vl + ((long)ch0 * W + cw1) * row, v2);
-      Vec4<T>::load(vl + ((long)ch1 * W + cw0) * row, v3);
-      Vec4<T>::load(vl + ((long)ch1 * W + cw1) * row, v4);
-      const float w1c = (okh0 && okw0) ? hh * hw : 0.f, w2c = (okh0 && okw1) ? hh * lw : 0.f;
-      const float w3c = (okh1 && okw0) ? lh * hw : 0.f, w4c = (okh1 && okw1) ? lh * lw : 0.f;
+#pragma unroll U
+  for (int i = 0; i < LP; ++i) {
+    const int4 o = *reinterpret_cast<const int4*>(rec + i * 8);
+    const float4 w = *reinterpret_cast<const float4*>(rec + i * 8 + 4);
+    float v1[4], v2[4], v3[4], v4[4];
+    Vec4<T>::load(vb + o.x, v1);
+    Vec4<T>::load(vb + o.y, v2);
+    Vec4<T>::load(vb + o.z, v3);
+    Vec4<T>::load(vb + o.w, v4);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float a1 = (okh0 && okw0) ? v1[c] : 0.f, a2 = (okh0 && okw1) ? v2[c] : 0.f;
-        const float a3 = (okh1 && okw0) ? v3[c] : 0.f, a4 = (okh1 && okw1) ? v4[c] : 0.f;
-        const float val = w1c * a1 + w2c * a2 + w3c * a3 + w4c * a4;
-        acc[c] += val * w;
-      }
-    }
+    for (int c = 0; c < 4; ++c) acc[c] = fmaf(w.w, v4[c], fmaf(w.z, v3[c], fmaf(w.y, v2[c], fmaf(w.x, v1[c], acc[c]))));
   }
-  Vec4<T>::store(out + g * 32 + sub * 4, acc);
+  if (live) Vec4<T>::store(out + g * 32 + sub * 4, acc);
 }
 
 // any D: one thread per output element (b,q,m,c), the reference's own decomposition.
@@ -223,7 +271,9 @@ static int launch_msda(const void* value, const int64_t* shapes, const int64_t* 
   if (groups == 0) return HIPIE_OK;
   if (D == 32) {
     const long blocks = (groups + 31) / 32;
-    hipLaunchKernelGGL((msda_d32_kernel<T, A, FUSED>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)value, shapes,
+    const size_t lds = (size_t)32 * (L * P * 8 + 4) * sizeof(float);
+    // unroll 2 of the record loop: 0.467 ms vs 0.480 (1, 4, 8) on the bs-8 encoder geometry (tools/bench_msda.py)
+    hipLaunchKernelGGL((msda_d32_kernel<T, A, FUSED, 2>), dim3((unsigned)blocks), dim3(256), lds, st, (const T*)value, shapes,
                        lstart, (const A*)a, (const A*)w, ref, (T*)out, S, M, L, Lq, P, ref_dim, groups, off_stride, w_stride);
   } else {
     const long n = groups * D;
@@ -245,6 +295,7 @@ static int dispatch_aux(int aux_dtype, const void* value, const int64_t* shapes,
     default: return set_err(HIPIE_EINVAL, "msda: unsupported aux dtype %d", aux_dtype);
   }
 }
+
 
 template <bool FUSED>
 static int dispatch_msda(const void* value, const int64_t* shapes, const int64_t* lstart, const void* a, const void* w,

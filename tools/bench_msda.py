@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""micro-benchmark of the deformable-attention sampling kernels on the encoder geometry of the bench workload
+(B = 8, pyramid 128/64/32/16, 8 heads x 32, 4 levels x 4 points, bf16 value, bf16 strided offsets/logits)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from hipie_amd import ops  # noqa: E402
+from hipie_amd.modeling.transformer import encoder_reference_points  # noqa: E402
+
+
+def main():
+    dev = "cuda"
+    B, M, D, L, P = 8, 8, 32, 4, 4
+    shapes = [(128, 128), (64, 64), (32, 32), (16, 16)]
+    S = sum(h * w for h, w in shapes)
+    g = torch.Generator().manual_seed(0)
+    value = torch.randn(B, S, M, D, generator=g).bfloat16().to(dev)
+    proj = torch.randn(B, S, M * L * P * 3, generator=g)
+    proj[..., :M * L * P * 2] *= float(os.environ.get("SIGMA", "1.5"))
+    proj = proj.bfloat16().to(dev)
+    off = proj[..., :M * L * P * 2].unflatten(-1, (M, L, P, 2))
+    lg = proj[..., M * L * P * 2:].unflatten(-1, (M, L * P))
+    ref = encoder_reference_points(shapes, torch.ones(B, L, 2), "cpu").to(dev)
+    ss = torch.tensor(shapes, device=dev)
+    ls = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+
+    def bench(fn, n=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e3
+    alg = B * (S * M * D * 2 * 2 + S * M * L * P * 3 * 2 + S * L * 2 * 4)         # value in + out, offsets + logits, refs
+    t = bench(lambda: ops.msda_fused(value, ss, ls, ref, off, lg))
+    print("msda_fused: %.3f ms  %.2f TB/s algorithmic" % (t, alg / t / 1e9))
+
+
+if __name__ == "__main__":
+    main()
