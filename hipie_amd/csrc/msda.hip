@@ -301,8 +301,9 @@ template <bool FUSED>
 static int dispatch_msda(const void* value, const int64_t* shapes, const int64_t* lstart, const void* a, const void* w,
                          const float* ref, void* out, int B, int S, int M, int D, int L, int Lq, int P, int ref_dim,
                          int dtype, int aux_dtype, long off_stride, long w_stride, void* stream) {
-  HIPIE_REQUIRE(value && shapes && lstart && a && w && out, "msda: null pointer");
   HIPIE_REQUIRE(B >= 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq >= 0 && P > 0, "msda: bad shape B=%d S=%d M=%d D=%d L=%d Lq=%d P=%d", B, S, M, D, L, Lq, P);
+  if (B == 0 || Lq == 0) return HIPIE_OK;              // no queries: nothing to write (pointers of empty tensors may be null)
+  HIPIE_REQUIRE(value && shapes && lstart && a && w && out, "msda: null pointer");
   HIPIE_REQUIRE((long)B * S * M * D < (1L << 40), "msda: tensor too large");
   HIPIE_REQUIRE(off_stride >= (long)M * L * P * 2 && w_stride >= (long)M * L * P, "msda: row strides too small");
   if (FUSED) {

@@ -156,14 +156,15 @@ using namespace hipie;
 
 extern "C" int hipie_batched_nms(const float* boxes, const int64_t* classes, const int32_t* order, int32_t* keep,
                                  int32_t* count, int B, int Q, float iou_threshold, int coordinate_trick, void* stream) {
-  HIPIE_REQUIRE(boxes && classes && order && keep && count, "batched_nms: null pointer");
   HIPIE_REQUIRE(B >= 0 && Q >= 0, "batched_nms: negative size");
   HIPIE_REQUIRE(Q <= NMS_MAXQ, "batched_nms: Q=%d > %d (suppression matrix must fit the 160 KB LDS)", Q, NMS_MAXQ);
   if (B == 0) return HIPIE_OK;
+  HIPIE_REQUIRE(count, "batched_nms: null pointer");
   if (Q == 0) {
     (void)hipMemsetAsync(count, 0, sizeof(int32_t) * B, (hipStream_t)stream);
     return check_launch("batched_nms(memset)");
   }
+  HIPIE_REQUIRE(boxes && classes && order && keep, "batched_nms: null pointer");
   const int W = (Q + 63) >> 6;
   const size_t smem = sizeof(float) * (4 * NMS_MAXQ + NMS_MAXQ) + sizeof(int) * NMS_MAXQ + sizeof(float) * 16 +
                       sizeof(unsigned long long) * (size_t)Q * W;
@@ -182,8 +183,9 @@ extern "C" int hipie_batched_nms(const float* boxes, const int64_t* classes, con
 extern "C" int hipie_mask_finalize(const void* masks, int dtype, const int32_t* qidx, int n, int hm, int wm, int up,
                                    int crop_h, int crop_w, int out_h, int out_w, float threshold, uint8_t* out,
                                    void* stream) {
-  HIPIE_REQUIRE(masks && out, "mask_finalize: null pointer");
   HIPIE_REQUIRE(n >= 0 && hm > 0 && wm > 0 && up > 0, "mask_finalize: bad geometry");
+  if (n == 0) return HIPIE_OK;
+  HIPIE_REQUIRE(masks && out, "mask_finalize: null pointer");
   HIPIE_REQUIRE(crop_h > 0 && crop_w > 0 && crop_h <= hm * up && crop_w <= wm * up, "mask_finalize: crop outside the mask");
   HIPIE_REQUIRE(out_h > 0 && out_w > 0 && n <= 65535, "mask_finalize: bad output size");
   if (n == 0) return HIPIE_OK;

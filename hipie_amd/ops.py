@@ -115,6 +115,8 @@ def msda_fused(value, spatial_shapes, level_start_index, ref, offsets, logits):
     _, Lq, _, L, P, _ = offsets.shape
     if offsets.dtype != logits.dtype or offsets.dtype not in _DT:
         raise RuntimeError("msda_fused: offsets/logits must share a dtype in f32/f16/bf16")
+    if B == 0 or Lq == 0:
+        return torch.empty(B, Lq, M * D, dtype=value.dtype, device=value.device)
     off_stride, lg_stride = offsets.stride(1), logits.stride(1)
     if offsets.stride(0) != Lq * off_stride or logits.stride(0) != Lq * lg_stride or \
             offsets[0, 0].stride() != (L * P * 2, P * 2, 2, 1) or logits[0, 0].stride() != (L * P, 1):

@@ -90,3 +90,39 @@ def test_stage_vit_backbone():
         out = m(x)
         for k in ("res3", "res4", "res5"):
             assert rel_err(g.like(k, out[k].float().cpu()), g[k]) < tol, (k, prec)
+
+
+def test_stage_bert_short_and_chunked():
+    """product BertEncoder (<= 512 tokens and the > 512 chunking path, bert_model.py:32-153) on the GPU vs the golden made by
+    the reference's BertEncoder + transformers.BertModel."""
+    from hipie_amd.config import HipieConfig
+    from hipie_amd.modeling.text import BertEncoder
+    g = Golden("bert")
+    cfg = HipieConfig.from_dict(g.meta["cfg"])
+    m = BertEncoder(cfg)
+    m.load_state_dict(_synth.synth_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}, seed=51))
+    m = m.cuda().eval()
+    for tag in ("short", "long"):
+        out = m({"input_ids": g[tag + "_ids"].cuda(), "attention_mask": g[tag + "_mask"].cuda()}, sep=1012)["hidden"]
+        assert rel_err(g.like(tag + "_hidden", out.float().cpu()), g[tag + "_hidden"]) < 2e-4
+
+
+def test_e2e_batch_items_are_independent():
+    """size-independent property: with equal image sizes the a22 rows of an image do not depend on its batch neighbours
+    (exercises every batch / head / XCD index map of the kernels); pinned top-k so the comparison is continuous."""
+    from hipie_amd.config import Precision
+    g, model = build(Precision.parity())
+    imgs = _synth.synth_images([(192, 256), (192, 256), (192, 256)], seed=99)
+    ids, mask, pmap = _synth.synth_token_ids(3, 9, 64, seed=74)
+
+    def batch(idx):
+        return [{"image": imgs[i], "task": "detection", "input_ids": ids[0], "attention_mask": mask[0],
+                 "positive_map_label_to_token": pmap} for i in idx]
+    full = model.forward_raw(batch([0, 1, 2]))
+    fg, md = model.last_topk()
+    for i in (0, 2):
+        model.pin_topk(fg[i:i + 1].cpu(), md[i:i + 1].cpu())
+        one = model.forward_raw(batch([i]))
+        for k in KEYS:
+            assert rel_err(one[k].float().cpu(), full[k][i:i + 1].float().cpu()) < 1e-3, (k, i)
+    model.pin_topk(None, None)

@@ -354,3 +354,60 @@ def test_msda_fused_full_scale_strided_aux():
     c = ops.msda_fused((2 * value.float()).bfloat16(), ss, ls, ref, off, lg)                     # linearity in value
     assert rel_err(c.float().cpu(), 2 * a.float().cpu()) < 1e-2
     assert torch.isfinite(a.float()).all()
+
+
+def test_mask_einsum_full_size_against_library_gemm():
+    """BASELINE-size contraction (300 queries x 256 channels x 256^2 pixels, batch 2): exact-fp32 MFMA path against an fp32
+    library GEMM on the same device, and linearity of the bf16x3 path."""
+    from hipie_amd import ops
+    gen = torch.Generator().manual_seed(8)
+    emb = torch.randn(2, 300, 256, generator=gen).to(DEV)
+    feat = torch.randn(2, 256, 256, 256, generator=gen).to(DEV)
+    want = torch.bmm(emb, feat.flatten(2)).view(2, 300, 256, 256)
+    got = ops.mask_einsum(emb, feat, precision=0)
+    assert rel_err(got.cpu(), want.cpu()) < 2e-6
+    a = ops.mask_einsum(emb, feat, precision=1)
+    assert rel_err(a.cpu(), want.cpu()) < 3e-5
+    b = ops.mask_einsum(3.0 * emb, feat, precision=1)
+    assert rel_err(b.cpu(), 3.0 * a.cpu()) < 3e-5
+
+
+def test_vit_attention_full_grid_against_materialised_scores():
+    """the real global-attention geometry (64x64 tokens, 16 heads x 80) against the reference's own formulation with the
+    (N x N) score tensor materialised in fp32 on the device (backbone/vit.py:72-80 + utils.py:96-125), fused and unfused."""
+    from hipie_amd import ops
+    gen = torch.Generator().manual_seed(21)
+    B, gh, gw, heads, hd = 1, 64, 64, 16, 80
+    N, C = gh * gw, heads * hd
+    qkv = (torch.randn(B, N, 3 * C, generator=gen) * 0.8).half().to(DEV)
+    th = (torch.randn(2 * gh - 1, hd, generator=gen) * 0.2).half().to(DEV)
+    tw = (torch.randn(2 * gw - 1, hd, generator=gen) * 0.2).half().to(DEV)
+    q, k, v = qkv.float().view(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4).unbind(0)        # (B, heads, N, hd)
+    idx_h = torch.arange(gh, device=DEV)[:, None] - torch.arange(gh, device=DEV)[None, :] + gh - 1
+    idx_w = torch.arange(gw, device=DEV)[:, None] - torch.arange(gw, device=DEV)[None, :] + gw - 1
+    Rh, Rw = th.float()[idx_h], tw.float()[idx_w]                                          # (gh, gh, hd), (gw, gw, hd)
+    rq = q.reshape(B, heads, gh, gw, hd)
+    rel_h = torch.einsum("bmhwc,hkc->bmhwk", rq, Rh)
+    rel_w = torch.einsum("bmhwc,wkc->bmhwk", rq, Rw)
+    attn = (q * hd ** -0.5) @ k.transpose(-2, -1)
+    attn = (attn.view(B, heads, gh, gw, gh, gw) + rel_h[..., :, None] + rel_w[..., None, :]).view(B, heads, N, N)
+    want = (attn.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B, N, C)
+    fused = ops.vit_attn_fused(qkv, th, tw, (gh, gw), heads, hd ** -0.5).float()
+    assert rel_err(fused.cpu(), want.cpu()) < 1e-3
+    bh, bw = ops.vit_relpos(qkv, th, tw, (gh, gw), heads)
+    unfused = ops.vit_attn(qkv, bh, bw, (gh, gw), heads, hd ** -0.5).float()
+    assert rel_err(unfused.cpu(), want.cpu()) < 1e-3
+
+
+def test_empty_inputs_are_handled():
+    from hipie_amd import ops
+    keep, count = ops.batched_nms(torch.zeros(2, 0, 4, device=DEV), torch.zeros(2, 0, device=DEV),
+                                  torch.zeros(2, 0, dtype=torch.long, device=DEV), 0.7)
+    assert keep.shape == (2, 0) and count.tolist() == [0, 0]
+    m = ops.mask_finalize(torch.zeros(4, 8, 8, device=DEV), torch.zeros(0, dtype=torch.int32, device=DEV), 4, (32, 32), (32, 32), 0.5)
+    assert m.shape == (0, 32, 32)
+    shapes = torch.tensor([(4, 4)], device=DEV)
+    out = ops.msda_fused(torch.zeros(1, 16, 8, 32, device=DEV), shapes, torch.zeros(1, dtype=torch.long, device=DEV),
+                         torch.zeros(1, 0, 1, 2, device=DEV), torch.zeros(1, 0, 8, 1, 4, 2, device=DEV),
+                         torch.zeros(1, 0, 8, 4, device=DEV))
+    assert out.shape == (1, 0, 256)
