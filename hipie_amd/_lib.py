@@ -32,6 +32,7 @@ SIGNATURES = {
     "hipie_add_layernorm_rows": [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_i, c_i, c_i, c_p, c_p, c_p],
     "hipie_batched_nms": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p],
     "hipie_mask_finalize": [c_p, c_i, c_p] + [c_i] * 8 + [c_f, c_p, c_p],
+    "hipie_sem_pan": [c_p] * 8 + [c_i] * 11 + [c_p],
     "hipie_selftest": [c_i, c_p, c_p, c_p, c_p],
 }
 

@@ -319,6 +319,39 @@ def mask_finalize(masks, qidx, up, crop_hw, out_hw, threshold):
     return out
 
 
+def sem_pan_ok(n_queries, n_classes):
+    return 0 < n_classes <= 160 and 0 < n_queries <= 8192
+
+
+@_timed("sem_pan")
+def sem_pan(masks_lo, cls_all, pscore, up, crop_hw, out_hw, precision=0):
+    """fused semantic + panoptic maps of one image.  masks_lo (N,hm,wm) f32 stride-`up` logits, cls_all (N,C) f32 class
+    probabilities, pscore (N) f32 (score of kept queries, <= 0 otherwise) ->
+    sem (C,oh,ow) f32, pan_idx (oh,ow) int32 (-1: no kept query), pan_own (oh,ow) bool, area (N) int32."""
+    lib = _lib.load()
+    N, C = cls_all.shape
+    _, hm, wm = masks_lo.shape
+    dev = masks_lo.device
+    npad = (N + 15) // 16 * 16
+    cp = 32 if C <= 32 else 96 if C <= 96 else 160
+    cls_t = torch.zeros(cp, npad, dtype=torch.float32, device=dev)
+    cls_t[:C, :N] = cls_all.t()
+    hi = cls_t.to(torch.bfloat16)
+    lo = (cls_t - hi.float()).to(torch.bfloat16) if precision == 0 else None
+    ps = torch.full((npad,), -1.0, dtype=torch.float32, device=dev)
+    ps[:N] = pscore
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    sem = torch.empty(C, oh, ow, dtype=torch.float32, device=dev)
+    pan_idx = torch.empty(oh, ow, dtype=torch.int32, device=dev)
+    pan_own = torch.empty(oh, ow, dtype=torch.uint8, device=dev)
+    area = torch.zeros(npad, dtype=torch.int32, device=dev)
+    rc = lib.hipie_sem_pan(_chk(masks_lo, "masks", torch.float32), hi.data_ptr(), None if lo is None else lo.data_ptr(),
+                           ps.data_ptr(), sem.data_ptr(), pan_idx.data_ptr(), pan_own.data_ptr(), area.data_ptr(),
+                           N, npad, C, hm, wm, int(up), int(crop_hw[0]), int(crop_hw[1]), oh, ow, int(precision), _stream())
+    _lib.check(rc, "hipie_sem_pan")
+    return sem, pan_idx, pan_own.bool(), area[:N]
+
+
 def selftest(which, a, b=None):
     lib = _lib.load()
     out = torch.empty(32 * 32 if which == 0 else 256, dtype=torch.float32, device=a.device)

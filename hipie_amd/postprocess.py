@@ -95,27 +95,40 @@ def _cxcywh_to_xyxy(b):
 
 
 # ------------------------------------------------------------------------------------------------ panoptic / semantic
-def _sem_pan(cls_all, masks_lo, stride, crop_hw, out_hw, thing_vec, cfg):
+def _sem_pan(cls_all, masks_lo, stride, crop_hw, out_hw, thing_vec, cfg, precision=0):
     """semantic_inference + the tensor part of panoptic_inference for one image.
     cls_all (N, C) class probabilities, masks_lo (N, hm, wm) stride-`stride` logits.  Returns sem_seg (C, oh, ow) and a
-    dict of device tensors describing the panoptic result (label map + per-segment table)."""
+    dict of device tensors describing the panoptic result (label map + per-segment table).
+    On the device the N x H x W sigmoid tensor is never built (hipie_sem_pan); the torch formulation below it is the same
+    arithmetic for CPU tensors (host-logic tests) and for shapes the kernel does not cover."""
     N, C = cls_all.shape
-    up = F.interpolate(masks_lo[:, None].float(), scale_factor=float(stride), mode="bilinear", align_corners=False)
-    up = up[:, :, :crop_hw[0], :crop_hw[1]]
-    if tuple(out_hw) != tuple(crop_hw):
-        up = F.interpolate(up, size=tuple(out_hw), mode="bilinear", align_corners=False)
-    sig = up[:, 0].contiguous().sigmoid_()                                      # (N, oh, ow)
-    oh, ow = sig.shape[-2:]
-    sem = (cls_all.t() @ sig.view(N, -1)).view(C, oh, ow)                       # einsum("qc,qhw->chw")
     scores, labels = cls_all.max(-1)
     kept = scores > cfg.object_mask_threshold
-    w = torch.where(kept, scores, scores.new_tensor(-1.0))                      # never wins the argmax unless nothing is kept
-    ids = (w.view(-1, 1, 1) * sig).argmax(0)                                    # (oh, ow) index into N
-    own = sig.gather(0, ids[None])[0] >= 0.5                                    # the winner's own mask >= 0.5
-    flat = ids.view(-1)
-    mask_area = torch.bincount(flat, minlength=N)
+    if cls_all.is_cuda and ops.sem_pan_ok(N, C):
+        sem, ids, own, orig_area = ops.sem_pan(masks_lo.float().contiguous(), cls_all.float().contiguous(),
+                                               torch.where(kept, scores, scores.new_tensor(-1.0)), stride, crop_hw, out_hw,
+                                               precision)
+        ids = ids.long()
+        some = ids >= 0
+        own = own & some
+        ids = ids.clamp_min(0)
+        flat = ids.view(-1)
+        mask_area = torch.bincount(flat[some.view(-1)], minlength=N)
+    else:
+        up = F.interpolate(masks_lo[:, None].float(), scale_factor=float(stride), mode="bilinear", align_corners=False)
+        up = up[:, :, :crop_hw[0], :crop_hw[1]]
+        if tuple(out_hw) != tuple(crop_hw):
+            up = F.interpolate(up, size=tuple(out_hw), mode="bilinear", align_corners=False)
+        sig = up[:, 0].contiguous().sigmoid_()                                      # (N, oh, ow)
+        oh, ow = sig.shape[-2:]
+        sem = (cls_all.t() @ sig.view(N, -1)).view(C, oh, ow)                       # einsum("qc,qhw->chw")
+        w = torch.where(kept, scores, scores.new_tensor(-1.0))                      # never wins the argmax unless nothing is kept
+        ids = (w.view(-1, 1, 1) * sig).argmax(0)                                    # (oh, ow) index into N
+        own = sig.gather(0, ids[None])[0] >= 0.5                                    # the winner's own mask >= 0.5
+        flat = ids.view(-1)
+        mask_area = torch.bincount(flat, minlength=N)
+        orig_area = (sig >= 0.5).view(N, -1).sum(1)
     inter_area = torch.bincount(flat[own.view(-1)], minlength=N)
-    orig_area = (sig >= 0.5).view(N, -1).sum(1)
     ratio_ok = mask_area.double() / orig_area.clamp_min(1).double() >= cfg.overlap_threshold
     valid = kept & (mask_area > 0) & (orig_area > 0) & (inter_area > 0) & ratio_ok
     isthing = thing_vec[labels]
@@ -248,7 +261,8 @@ def inference(model, out, batched_inputs, do_postprocess=True, with_masks=True, 
                 cls_all = F.softmax(logits_all.sigmoid() / cfg.pano_temp, dim=-1)
             else:
                 cls_all = logits_all.sigmoid()
-            sem, tab = _sem_pan(cls_all, masks_all, s, image_sizes[i], out_sizes[i], thing_vector(is_thing[i], C, dev), cfg)
+            sem, tab = _sem_pan(cls_all, masks_all, s, image_sizes[i], out_sizes[i], thing_vector(is_thing[i], C, dev), cfg,
+                                0 if getattr(getattr(model, "precision", None), "einsum", 0) <= 1 else 1)
             results[i]["sem_seg"] = sem
             tables.append(tab)
         for i, info in enumerate(_segments_info(tables)):

@@ -202,6 +202,23 @@ int hipie_batched_nms(const float* boxes, const int64_t* classes, const int32_t*
 int hipie_mask_finalize(const void* masks, int dtype, const int32_t* qidx, int n, int hm, int wm, int up, int crop_h,
                         int crop_w, int out_h, int out_w, float threshold, uint8_t* out, void* stream);
 
+/*
+ * Fused semantic + panoptic maps of one image -- the tensor part of the detection tail of HIPIE_IMG.inference
+ * (hipie_img.py:716-748), semantic_inference (:870-878) and panoptic_inference (:473-505):
+ *   sig[q] = sigmoid(resize(masks[q]))  with resize = bilinear x`up` -> crop (crop_h, crop_w) -> bilinear to (out_h, out_w);
+ *   sem[c] = sum_q cls[q, c] * sig[q];   pan_idx = argmax_q pscore[q] * sig[q] over pscore > 0 (first index on ties, -1 if
+ *   none);  pan_own = sig[pan_idx] >= 0.5;   area[q] += #pixels with sig[q] >= 0.5.
+ * The N x out_h x out_w sigmoid tensor never exists: each value is produced in registers as an MFMA B-operand element.
+ *   masks (N, hm, wm) f32; cls_hi / cls_lo (ceil32(C) rounded to 32/96/160, Npad) bf16: class probabilities TRANSPOSED,
+ *   zero padded, split as value = hi + lo (cls_lo unused and may be NULL for precision 1); pscore (Npad) f32 (<= 0: query
+ *   not kept; padding -1); sem (C, out_h, out_w) f32; pan_idx (out_h, out_w) int32; pan_own (out_h, out_w) uint8;
+ *   area (Npad) int32, zero-initialised by the caller.  Npad % 16 == 0, C <= 160.
+ *   precision 0: bf16 hi+lo operands, 3 MFMAs per product (~2^-16);  1: plain bf16.
+ */
+int hipie_sem_pan(const float* masks, const void* cls_hi, const void* cls_lo, const float* pscore, float* sem,
+                  int32_t* pan_idx, uint8_t* pan_own, int32_t* area, int N, int Npad, int C, int hm, int wm, int up,
+                  int crop_h, int crop_w, int out_h, int out_w, int precision, void* stream);
+
 /* device-side self-test helpers used by tests/ to pin the MFMA / LDS-transpose lane layouts this library assumes.
  *   which 0: D = A(32x16) . B(16x32) with v_mfma_f32_32x32x16_bf16, operands loaded with the layouts documented in
  *            csrc/mfma.h; out (32,32) f32.   which 1: ds_read_b64_tr_b16 of a (64,16) bf16 tile; out (64,4) f32 per lane.

@@ -142,3 +142,43 @@ def test_post_product_matches_oracle_large(use_bg):
         stuff_ids = [s_["category_id"] for s_ in w["panoptic_seg"][1] if not s_["isthing"]]
         assert len(stuff_ids) == len(set(stuff_ids))
     assert n_seg >= 4
+
+
+@pytest.mark.parametrize("N,C,crop,out,prec", [(300, 9, (200, 256), (200, 256), 0), (130, 80, (250, 131), (333, 97), 0),
+                                               (77, 150, (256, 256), (256, 256), 1), (40, 33, (64, 100), (50, 300), 1)])
+def test_sem_pan_kernel_matches_torch_formulation(N, C, crop, out, prec):
+    """hipie_sem_pan against the reference's tensor formulation (two bilinear resizes, sigmoid, einsum, argmax, areas)."""
+    import torch.nn.functional as F
+    from hipie_amd import ops
+    g = torch.Generator().manual_seed(N + C)
+    a22 = _synth.synth_a22([(256, 256)], 0, 1, N, 8, seed=N)
+    masks = a22["pred_masks_maskdino"][0].cuda()                              # (N, 64, 64) blobs
+    cls = torch.softmax(torch.randn(N, C, generator=g) * 3, -1).cuda()
+    scores = cls.max(-1)[0]
+    ps = torch.where(scores > 0.4, scores, scores.new_tensor(-1.0))
+    sem, idx, own, area = ops.sem_pan(masks, cls, ps, 4, crop, out, prec)
+    up = F.interpolate(masks[:, None], scale_factor=4.0, mode="bilinear", align_corners=False)[:, :, :crop[0], :crop[1]]
+    if crop != out:
+        up = F.interpolate(up, size=out, mode="bilinear", align_corners=False)
+    sig = up[:, 0].sigmoid()
+    want_sem = torch.einsum("qc,qhw->chw", cls, sig)
+    tol = 3e-5 if prec == 0 else 6e-3
+    assert (sem - want_sem).abs().max() < tol * want_sem.abs().max()
+    kept = ps > 0
+    w_ids = (torch.where(kept, ps, ps.new_tensor(-1.0)).view(-1, 1, 1) * sig).argmax(0)
+    if kept.any():
+        assert (idx.long() != w_ids).float().mean() < 1e-4
+        w_own = sig.gather(0, w_ids[None])[0] >= 0.5
+        assert (own != w_own).float().mean() < 1e-4
+    else:
+        assert (idx == -1).all() and not own.any()
+    w_area = (sig >= 0.5).view(N, -1).sum(1)
+    assert ((area.long() - w_area).abs() <= 2 + w_area // 2000).all()       # a logit within an ulp of 0 may flip a pixel
+
+
+def test_sem_pan_no_query_kept():
+    from hipie_amd import ops
+    masks = torch.randn(20, 16, 16).cuda()
+    cls = torch.full((20, 5), 0.2).cuda()
+    sem, idx, own, area = ops.sem_pan(masks, cls, torch.full((20,), -1.0).cuda(), 4, (64, 64), (64, 64), 0)
+    assert (idx == -1).all() and not own.any() and torch.isfinite(sem).all()
