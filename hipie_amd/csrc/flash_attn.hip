@@ -39,10 +39,17 @@ struct FAParams {
   const void* tab_h; const void* tab_w;          // FUSEREL: rel-pos tables (2*kh-1, HD), (2*kw-1, HD) in the operand dtype
   const uint8_t* key_mask;
   float scale, clamp, defer;
-  int nqt, ntiles, swz;
+  int nqt, ntiles, swz, prio;
 };
 
 constexpr float kLog2e = 1.4426950408889634f;
+
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
 constexpr float kDefer = 8.f;                 // log2 of the largest P the deferred running max lets through
 
 // T: bf16_t | f16_t;  HD: head dim;  NB: 32-key blocks per tile;  QB: 32-query blocks per wave;  BIAS: decomposed rel-pos
@@ -297,6 +304,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || HD <= 80) ? 2 : 1) void 
     }
 
     // ---- S^T = K . Q^T  (each K fragment feeds QB MFMAs) ----
+    if (p.prio) __builtin_amdgcn_s_setprio(1);     // MFMA clusters at raised priority: the co-resident workgroup's VALU yields
     f32x16 S[QB][NB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb)
@@ -324,6 +332,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || HD <= 80) ? 2 : 1) void 
       }
     }
 
+    if (p.prio) __builtin_amdgcn_s_setprio(0);
     unsigned long long vw[NW];
     if (MASKED) {
       // validity words: bit i of word w <=> key (64 w + i) of this tile is attended to
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || HD <= 80) ? 2 : 1) void 
 #pragma unroll
       for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, S[qb][blk][r]);
+        for (int r = 0; r < 16; r += 2) mx = max3(mx, S[qb][blk][r], S[qb][blk][r + 1]);
       mx = fmaxf(mx, __shfl_xor(mx, 32)) + bh_t[qb];
       // deferred max: the reference point m_run only moves when some row's maximum grew by more than 2^kDefer (or is
       // still unset); otherwise P = exp2(s - m_run) <= 2^kDefer stays well inside fp32 / 16-bit range and the O rescale
@@ -401,6 +410,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || HD <= 80) ? 2 : 1) void 
     }
 
     // ---- O^T += V^T . P^T  (each V^T fragment feeds QB MFMAs) ----
+    if (p.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
 #pragma unroll
@@ -425,6 +435,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || HD <= 80) ? 2 : 1) void 
       }
     }
 
+    if (p.prio) __builtin_amdgcn_s_setprio(0);
     if (t + 1 < nt) FA_STORE_LDS((t + 1) & 1);
     __syncthreads();
     if (t + 2 < nt) FA_LOAD_REGS(t + 2);
@@ -529,6 +540,7 @@ static int flash_attn_impl(FAParams p, int hd, int dtype, void* stream) {
   p.swz = ((p.B * p.H) % 8 == 0) ? 1 : 0;
   p.defer = (dtype == HIPIE_F16) ? 0.f : kDefer;      // fp16 = parity policy: classic running max
   { const char* d = getenv("HIPIE_FA_DEFER"); if (d) p.defer = (float)atof(d); }
+  { static int prio = -1; if (prio < 0) { const char* e = getenv("HIPIE_FA_PRIO"); prio = e ? atoi(e) : 1; } p.prio = prio; }   // +1.5 % (tools/bench_attn.py)
   // 8 waves (256 queries) per workgroup halve the K/V traffic per query but keep all waves of a CU in lockstep
   bool wide = false;       // measured: two independent 4-wave workgroups per CU (1.09 ms) beat one 8-wave workgroup (1.16 ms)
   const char* e = getenv("HIPIE_FA_WAVES");

@@ -34,7 +34,29 @@ def run(B=8, g=64, heads=16, hd=80, dt=torch.bfloat16, iters=20):
     return ms, fl / ms / 1e9, err
 
 
+def run_fused(B=8, g=64, heads=16, hd=80, dt=torch.bfloat16, iters=30):
+    N, C = g * g, heads * hd
+    gen = torch.Generator().manual_seed(0)
+    qkv = (torch.randn(B, N, 3 * C, generator=gen)).to(dt).cuda()
+    th = (torch.randn(2 * g - 1, hd, generator=gen) * 0.3).to(dt).cuda()
+    tw = (torch.randn(2 * g - 1, hd, generator=gen) * 0.3).to(dt).cuda()
+    ops.vit_attn_fused(qkv, th, tw, (g, g), heads, hd ** -0.5)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        ops.vit_attn_fused(qkv, th, tw, (g, g), heads, hd ** -0.5)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / iters
+    return ms, 4.0 * N * N * C * B / ms / 1e9
+
+
 if __name__ == "__main__":
+    if os.environ.get("FUSED_ONLY") == "1":
+        ms, tf = run_fused()
+        print("fused (prio=%s)  %.4f ms  %.1f TFLOP/s" % (os.environ.get("HIPIE_FA_PRIO", "0"), ms, tf), flush=True)
+        sys.exit(0)
     for waves in ("8", "4"):
         os.environ["HIPIE_FA_WAVES"] = waves
         ms, tf, err = run()
