@@ -262,7 +262,9 @@ def main():
             "config": {"workload": "BASELINE.json configs[2]: %s, %dx%d, batch %d per GPU, %d class prompts (L=%d), detection"
                                    % (args.model, args.size, args.size, args.batch, n_classes, L),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "precision_policy": args.precision,
-                       "launch": "hipGraph replay" if graph is not None else "eager"},
+                       "launch": "hipGraph replay" if graph is not None else "eager",
+                       "constants": "weight- and geometry-only tensors (rel-pos tables, position embeddings, valid ratios) are "
+                                    "built once; nothing that depends on image or text content is cached"},
             "roofline": {"bound": "mfma", "kernel": "flash_attn_kernel<bf16,hd80,NB2,4 waves,fused rel-pos bias> (ViT global attention, %d launches timed)" % kern_n,
                          "achieved": None if ach is None else round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": None if ach is None else round(ach / 2500.0, 4), "traffic": None,
