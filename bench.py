@@ -26,8 +26,14 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 
-def synth_batch(cfg, batch, size, n_classes, L, device, seed=0):
+def synth_batch(cfg, batch, size, n_classes, L, device, seed=0, task="detection"):
     g = torch.Generator().manual_seed(seed)
+    if task == "grounding":                     # one referring expression of ~10 tokens (BASELINE configs[2], second call)
+        n = 10
+        ids = torch.tensor([101] + torch.randint(1996, 29000, (n,), generator=g).tolist() + [102])
+        mask = torch.ones_like(ids)
+        return [{"image": torch.randint(0, 256, (3, size, size), generator=g).float().to(device), "task": "grounding",
+                 "input_ids": ids.to(device), "attention_mask": mask.to(device)} for _ in range(batch)]
     ids = torch.zeros(L, dtype=torch.long)
     mask = torch.zeros(L, dtype=torch.long)
     row, pmap = [101], {}
@@ -107,7 +113,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--model", default="vit_huge", choices=["vit_huge", "vit_large", "vit_base"])
+    ap.add_argument("--model", default="vit_huge", choices=["vit_huge", "vit_large", "vit_base", "r50"],
+                    help="r50 = BASELINE configs[1] (use --batch 4); no ViT attention kernel there: roofline fields are null")
+    ap.add_argument("--task", default="detection", choices=["detection", "grounding"],
+                    help="grounding = the referring-expression call of BASELINE configs[2] (one ~12-token expression)")
     ap.add_argument("--precision", default="fast", choices=["fast", "parity", "default"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="capture the forward once into a hipGraph and replay it (experimental: "
@@ -157,7 +166,7 @@ def main():
     randomize_degenerate_inits(model)
     model.finalize()
     L, n_classes = 194, 80
-    batch = synth_batch(cfg, args.batch, args.size, n_classes, L, dev, seed=rank)
+    batch = synth_batch(cfg, args.batch, args.size, n_classes, L, dev, seed=rank, task=args.task)
 
     def local_step():
         out = model.forward_raw(batch)
