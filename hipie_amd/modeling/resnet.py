@@ -33,8 +33,21 @@ class NormConv(nn.Conv2d):
         super().__init__(cin, cout, k, stride=stride, padding=padding, bias=False)
         self.norm = FrozenBatchNorm2d(cout)
 
+    folded = None      # (weight * bn_scale, bn_shift) in the policy dtype, built by ResNet50.cast_weights()
+
     def forward(self, x):
+        if self.folded is not None:            # frozen BN is an affine map per output channel: one conv + bias pass
+            return self._conv_forward(x, self.folded[0], self.folded[1])
         return self.norm(self._conv_forward(x, self.weight, None))
+
+    def fold(self, dtype):
+        n = self.norm
+        scale = n.weight.float() * (n.running_var.float() + n.eps).rsqrt()
+        shift = n.bias.float() - n.running_mean.float() * scale
+        w = (self.weight.float() * scale.view(-1, 1, 1, 1)).to(dtype)
+        if dtype != torch.float32:
+            w = w.contiguous(memory_format=torch.channels_last)
+        self.folded = (w, shift.to(dtype))
 
 
 class BasicStem(nn.Module):
@@ -91,12 +104,12 @@ class ResNet50(nn.Module):
         return out
 
     def cast_weights(self):
+        """after the weights are loaded: fold every FrozenBatchNorm2d into its convolution (weights are frozen at inference)
+        and put the folded weights in the policy dtype (channels-last for the 16-bit policies)."""
         gd = self.precision.gemm
         for m in self.modules():
-            if isinstance(m, nn.Conv2d):
-                m.weight.data = m.weight.data.to(gd)
-                if gd != torch.float32:
-                    m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+            if isinstance(m, NormConv):
+                m.fold(gd)
         return self
 
     def output_shape(self):

@@ -96,7 +96,11 @@ def test_resnet50_state_dict_and_cpu_forward_match_reference():
     ours = {k: list(v.shape) for k, v in m.state_dict().items()}
     assert ours == g.meta["manifest"]
     m.load_state_dict(_synth.synth_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}, seed=81))
-    out = m(_synth.synth_tensor("r50_in", g.meta["x_shape"], seed=82) * 2)
+    x = _synth.synth_tensor("r50_in", g.meta["x_shape"], seed=82) * 2
+    out = m(x)
+    for k in ("res3", "res4", "res5"):
+        assert rel_err(g.like(k, out[k]), g[k]) < 5e-5
+    out = m.cast_weights()(x)                  # FrozenBN folded into the convolutions (what finalize() runs with)
     for k in ("res3", "res4", "res5"):
         assert rel_err(g.like(k, out[k]), g[k]) < 5e-5
 
