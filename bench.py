@@ -258,6 +258,10 @@ def main():
         ops.PROFILE.disable()
 
     if rank == 0:
+        traffic = None                  # HBM bytes per launch of the roofline kernel from the committed PMC passes (same shape only)
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_attention.json")
+        if os.path.exists(pmc) and args.model == "vit_huge" and args.batch == 8 and args.size == 1024:
+            traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
         images = args.batch * world * args.steps
         N = (args.size // 16) ** 2
         flops = 4.0 * N * N * cfg.vit_embed_dim * args.batch          # QK^T + PV of one global block, all heads, this batch
@@ -276,7 +280,8 @@ def main():
                                     "built once; nothing that depends on image or text content is cached"},
             "roofline": {"bound": "mfma", "kernel": "flash_attn_kernel<bf16,hd80,NB2,4 waves,fused rel-pos bias> (ViT global attention, %d launches timed)" % kern_n,
                          "achieved": None if ach is None else round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": None if ach is None else round(ach / 2500.0, 4), "traffic": None,
+                         "frac": None if ach is None else round(ach / 2500.0, 4), "traffic": traffic,
+                         "traffic_note": "bytes per launch, rocprofv3 PMC FETCH_SIZE (x2, guide correction) + WRITE_SIZE, separate passes: profiles/r01_pmc_attention.md",
                          "avg_launch_ms": None if not kern_ms else round(kern_ms, 4),
                          "flop_per_launch": flops},
             "postprocess_full_ms": None if post_ms is None else round(post_ms, 2),
