@@ -313,22 +313,27 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || HD <= 80) ? 2 : 1) void 
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[qb][blk][r] = 0.f;
     {
+      // all K fragments of a chunk of k-steps are requested from LDS first and the MFMAs follow behind a scheduling
+      // barrier: left to itself the compiler sinks every ds_read_b128 next to its MFMA (one register quad, lgkmcnt(0) before
+      // each MFMA), which turns the QK^T phase into a chain of exposed LDS latencies
       const T* kbase = Ks + li * KSTR + 8 * hi;
-      frag kcur[NB], knxt[NB];
+      constexpr int KCH = (KS * NB <= 12) ? KS : 4;
 #pragma unroll
-      for (int blk = 0; blk < NB; ++blk) kcur[blk] = *reinterpret_cast<const frag*>(kbase + 32 * blk * KSTR);
+      for (int k0 = 0; k0 < KS; k0 += KCH) {
+        frag kf[NB][KCH];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        if (ks + 1 < KS) {
+        for (int kk = 0; kk < KCH; ++kk)
 #pragma unroll
-          for (int blk = 0; blk < NB; ++blk) knxt[blk] = *reinterpret_cast<const frag*>(kbase + 32 * blk * KSTR + 16 * (ks + 1));
-        }
+          for (int blk = 0; blk < NB; ++blk)
+            if (k0 + kk < KS) kf[blk][kk] = *reinterpret_cast<const frag*>(kbase + 32 * blk * KSTR + 16 * (k0 + kk));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int blk = 0; blk < NB; ++blk)
+        for (int kk = 0; kk < KCH; ++kk)
 #pragma unroll
-          for (int qb = 0; qb < QB; ++qb) S[qb][blk] = Mfma32<T>::mma(kcur[blk], qf[qb][ks], S[qb][blk]);
+          for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
-        for (int blk = 0; blk < NB; ++blk) kcur[blk] = knxt[blk];
+            for (int qb = 0; qb < QB; ++qb)
+              if (k0 + kk < KS) S[qb][blk] = Mfma32<T>::mma(kf[blk][kk], qf[qb][k0 + kk], S[qb][blk]);
       }
     }
 
