@@ -287,7 +287,7 @@ def main():
                          "flop_per_launch": flops},
             "postprocess_full_ms": None if post_ms is None else round(post_ms, 2),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1 and args.model != "r50":   # rank 0 at N = 1 only (bounded ~20 s CPU sample)
             import subprocess
             try:                        # separate process, hard time bound: the baseline must never break the measured line
                 env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
