@@ -46,6 +46,7 @@ class DDETRSegmUniDN(nn.Module):
         self.mask_head = MaskHeadSmallConv(d, d)
         self.resizer = FeatureResizer(cfg.lang_dim, d)  # DYNAMIC_LABEL_ENC (training-only use; kept for the state_dict)
         self.mask_dino = MaskDINOHead(cfg, detr.backbone.num_channels, precision)
+        self.mask_logit_dtype = precision.act      # mask logits leave in the activation dtype (fp32 in the parity policy)
         self.feature_keys = ["res3", "res4", "res5"]
         self.mask_dino_cls_embed = _get_clones(self.detr.class_embed[0], cfg.md_dec_layers + 2)
         self.cfg = cfg
@@ -120,5 +121,6 @@ class DDETRSegmUniDN(nn.Module):
             st += h * w
         mask_feats = self.mask_head(enc, fpns=None)                           # (bs, 8, H/8, W/8)
         logits = ops.dynamic_mask(mask_feats.float().contiguous(), reference_points.float().contiguous(),
-                                  mask_head_params.float().contiguous(), nq, stride=8, up=self.up_rate)
+                                  mask_head_params.float().contiguous(), nq, stride=8, up=self.up_rate,
+                                  out_dtype=self.mask_logit_dtype)
         return logits.view(bs, nq, 1, logits.shape[-2], logits.shape[-1])

@@ -144,7 +144,8 @@ class MaskDINODecoder(nn.Module):
         masks = None
         if pred_mask:
             emb = self.mask_embed(dec)
-            masks = ops.mask_einsum(emb.float().contiguous(), mask_features, precision=self.precision.einsum)
+            masks = ops.mask_einsum(emb.float().contiguous(), mask_features, precision=self.precision.einsum,
+                                    out_dtype=self.precision.act)
         return cls, masks
 
     def forward(self, x, mask_features):
