@@ -135,7 +135,9 @@ class MaskDINODecoder(nn.Module):
         self.precision = precision
         self.pinned_topk = None
         self.last_topk = None
-        self.initial_pred_masks = False    # True: also materialise interm_outputs["pred_masks"] like the reference does
+        # the reference's eval path also evaluates the mask contraction for the two-stage proposals (interm_outputs, consumed
+        # only by the training losses); kept on so the path does the same work -- set False to drop that 0.46 ms launch
+        self.initial_pred_masks = True
 
     def forward_prediction_heads(self, output, mask_features, pred_mask=True):
         """maskdino_decoder.py:520-529 -- the mask-logit contraction runs on hipie_mask_einsum."""
@@ -169,7 +171,7 @@ class MaskDINODecoder(nn.Module):
         self.last_topk = topk
         ref_un = torch.gather(coord_un, 1, topk.unsqueeze(-1).repeat(1, 1, 4))
         tgt = torch.gather(om, 1, topk.unsqueeze(-1).repeat(1, 1, self.hidden_dim))
-        # einsum #1 (:428) feeds only interm_outputs (training losses / denoising); at inference nothing consumes it
+        # einsum #1 (:428): interm_outputs
         interm_cls, interm_mask = self.forward_prediction_heads(tgt, mask_features, pred_mask=self.initial_pred_masks)
         ref = ref_un.sigmoid()
         refs, out, hs = [ref], tgt, []
