@@ -20,6 +20,7 @@ __device__ __forceinline__ bool iou_gt(const float* a, const float* b, float aa,
   const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
   const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
   const float w = fmaxf(__fsub_rn(right, left), 0.f), h = fmaxf(__fsub_rn(bottom, top), 0.f);
+  if (w <= 0.f || h <= 0.f) return false;       // disjoint (the vast majority of pairs): 0 / union > thr is false; skips the division
   const float inter = __fmul_rn(w, h);
   const float uni = __fsub_rn(__fadd_rn(aa, ab), inter);
   return __fdiv_rn(inter, uni) > thr;
