@@ -251,7 +251,7 @@ def main():
         ops.PROFILE.enable("all")
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        step()
+        local_step()                     # no collective here: only rank 0 runs the breakdown
         torch.cuda.synchronize()
         print("BREAKDOWN step %.1f ms" % ((time.perf_counter() - t1) * 1e3), file=sys.stderr)
         for tag, (mean, n, tot) in sorted(ops.PROFILE.summary().items()):
