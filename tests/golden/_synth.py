@@ -206,3 +206,21 @@ def synth_a22(sizes, n_bg, n_fg, n_md, L, seed=0, stride=4):
         "pred_masks_maskdino": smooth(n_md)[:, :, 0],
     }
     return out
+
+
+PROMPT_CATEGORIES = [{"name": "person"}, {"name": "traffic light"}, {"name": "hot dog", "isthing": 1},
+                     {"name": "potted_plant"}, {"name": "tv (monitor)"}, {"name": "wine glass"},
+                     {"name": "hair drier"}, {"name": "sky-other", "isthing": 0}, {"name": "teddy bear"},
+                     {"name": "zyxwv"}]
+PROMPT_VOCAB = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", ".", "-", "person", "traffic", "light", "hot", "dog",
+                "potted", "plant", "tv", "wine", "glass", "hair", "dr", "##ier", "sky", "other", "teddy", "bear"]
+
+
+def prompt_tokenizer(tmpdir):
+    """a BertTokenizerFast over a tiny deterministic vocab (the real bert-base-uncased vocab is not available offline)."""
+    import os
+    from transformers import BertTokenizerFast
+    path = os.path.join(str(tmpdir), "vocab.txt")
+    with open(path, "w") as f:
+        f.write("\n".join(PROMPT_VOCAB) + "\n")
+    return BertTokenizerFast(vocab_file=path, do_lower_case=True)

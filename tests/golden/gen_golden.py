@@ -526,7 +526,32 @@ def gen_post():
     save("post", meta, _full=tuple(k for k in arrays if k.endswith(("masks", "panoptic"))), **arrays)
 
 
-ALL = dict(post=gen_post, resnet50=gen_resnet50, msda=gen_msda, vit_attn=gen_vit_attn, vit_backbone=gen_vit_backbone, bi_attn=gen_bi_attn, bert=gen_bert,
+def gen_prompts():
+    """create_queries_and_maps / create_positive_dict / clean_name of the reference's mapper
+    (data/coco_dataset_mapper_uni.py:54-90, 732-736, 1024-1058).  That module cannot be imported (its package pulls in the
+    dataset registry), so exactly those three function definitions are extracted from the reference file with ``ast`` and
+    executed here, at generation time only; the fixture stores inputs and outputs."""
+    import ast
+    import re
+    import tempfile
+    from collections import defaultdict
+    src = open(ref_shim.REF_HIPIE + "/data/coco_dataset_mapper_uni.py").read()
+    tree = ast.parse(src)
+    want = {"create_queries_and_maps", "create_positive_dict", "clean_name"}
+    mod = ast.Module(body=[n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want], type_ignores=[])
+    ns = {"re": re, "defaultdict": defaultdict}
+    exec(compile(mod, "ref_mapper_functions", "exec"), ns)
+    meta = {"categories": _synth.PROMPT_CATEGORIES, "vocab": _synth.PROMPT_VOCAB}
+    with tempfile.TemporaryDirectory() as d:
+        tok = _synth.prompt_tokenizer(d)
+        for things_only in (False, True):
+            q, pm = ns["create_queries_and_maps"](_synth.PROMPT_CATEGORIES, tok, things_only=things_only)
+            meta["caption_%d" % things_only] = q
+            meta["pmap_%d" % things_only] = {str(k): v for k, v in pm.items()}
+    save("prompts", meta, dummy=np.zeros(1))
+
+
+ALL = dict(prompts=gen_prompts, post=gen_post, resnet50=gen_resnet50, msda=gen_msda, vit_attn=gen_vit_attn, vit_backbone=gen_vit_backbone, bi_attn=gen_bi_attn, bert=gen_bert,
            dynamic_mask=gen_dynamic_mask, e2e=gen_e2e, stages=gen_stages, e2e_r50=gen_e2e_r50)
 
 if __name__ == "__main__":

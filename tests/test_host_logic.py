@@ -175,3 +175,19 @@ def test_config_from_yacs_key_mapping():
     c = HipieConfig.from_yacs(cfg, md)
     assert c.backbone == "r50" and c.backbone_channels == [512, 1024, 2048]
     assert (c.md_num_queries, c.md_dec_layers, c.md_enc_layers) == (300, 9, 6)
+
+
+def test_prompt_construction_matches_reference(tmp_path):
+    """caption + positive_map_label_to_token (hipie_amd/prompts.py) against the outputs of the reference mapper's own
+    functions on the same categories and tokenizer (tests/golden/gen_golden.py prompts)."""
+    from hipie_amd import prompts
+    g = Golden("prompts")
+    assert g.meta["categories"] == _synth.PROMPT_CATEGORIES and g.meta["vocab"] == _synth.PROMPT_VOCAB
+    tok = _synth.prompt_tokenizer(tmp_path)
+    for things_only in (False, True):
+        caption, pmap = prompts.create_queries_and_maps(_synth.PROMPT_CATEGORIES, tok, things_only=things_only)
+        assert caption == g.meta["caption_%d" % things_only]
+        assert {str(k): v for k, v in pmap.items()} == g.meta["pmap_%d" % things_only]
+    item = prompts.detection_inputs(torch.zeros(3, 32, 32), _synth.PROMPT_CATEGORIES, tok)
+    assert item["task"] == "detection" and item["input_ids"].shape == item["attention_mask"].shape
+    assert item["is_thing"][8] is False and item["positive_map_label_to_token"][2] == [3, 4]
