@@ -39,7 +39,7 @@ def synth_batch(cfg, batch, size, n_classes, L, device, seed=0, task="detection"
     row, pmap = [101], {}
     for c in range(n_classes):
         k = int(torch.randint(1, 4, (1,), generator=g))
-        if len(row) + k + 2 > L:
+        if len(row) + k + 2 > min(L, 194):          # the caption itself is the 80-class one; a longer L is padding
             break
         pmap[c + 1] = list(range(len(row), len(row) + k))
         row += torch.randint(1996, 29000, (k,), generator=g).tolist() + [1012]
@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--model", default="vit_huge", choices=["vit_huge", "vit_large", "vit_base", "r50"],
                     help="r50 = BASELINE configs[1] (use --batch 4); no ViT attention kernel there: roofline fields are null")
+    ap.add_argument("--text-len", type=int, default=194, help="token length of the class prompt: 194 = the 80-class caption "
+                    "as is (PAD_MAX off); 4096 = the shipped eval setting that pads every caption to 4096 tokens (SURVEY 8d)")
     ap.add_argument("--task", default="detection", choices=["detection", "grounding"],
                     help="grounding = the referring-expression call of BASELINE configs[2] (one ~12-token expression)")
     ap.add_argument("--precision", default="fast", choices=["fast", "parity", "default"])
@@ -165,7 +167,7 @@ def main():
     model = HIPIE_IMG(cfg, prec, device=dev)
     randomize_degenerate_inits(model)
     model.finalize()
-    L, n_classes = 194, 80
+    L, n_classes = args.text_len, 80
     batch = synth_batch(cfg, args.batch, args.size, n_classes, L, dev, seed=rank, task=args.task)
 
     def local_step():
