@@ -290,10 +290,23 @@ __global__ __launch_bounds__(WAVES * 64, ((WAVES == 8 || HD <= 80) && QB == 1) ?
       for (int r = 0; r < 16; ++r) O[qb][d][r] = 0.f;
   }
 
-  const int nt = p.ntiles;
+  int nt = p.ntiles;
   // MASKED is instantiated only where some key can be invalid: padded key rows (BIAS, kw % 32 != 0), a ragged last tile
   // or a key mask.  The full-tile instantiation contains no validity code at all.
-  __syncthreads();                 // LDS zero fill done
+  __syncthreads();                 // LDS zero fill / mask staging done
+  if (MASKED && !BIAS && Mg != nullptr) {
+    // key tiles after the last attended key contribute exp(-inf) = 0: skip them.  (The shipped eval setting pads every
+    // caption to 4096 tokens, of which ~200 are real: the image->text attention then walks 7 tiles instead of 128.)
+    int* s_last = reinterpret_cast<int*>(mk_lds + ((size_t)p.Nk + 15) / 16 * 16);
+    if (tid == 0) *s_last = -1;
+    __syncthreads();
+    int last = -1;
+    for (int i = tid; i < p.Nk; i += NT)
+      if (mk_lds[i] != 0) last = i;
+    if (last >= 0) atomicMax(s_last, last);
+    __syncthreads();
+    nt = max(1, min(nt, (*s_last + KT) / KT));
+  }
   FA_LOAD_REGS(0);
   FA_STORE_LDS(0);
   __syncthreads();
@@ -489,7 +502,7 @@ static int launch_fa(FAParams& p, hipStream_t st) {
   lds += (size_t)(FUSEREL ? p.kh : 2) * WAVES * 32 * QB * sizeof(float);
   if (FUSEREL && lds < (size_t)WAVES * 32 * (NB + 1) * 32 * sizeof(float)) lds = (size_t)WAVES * 32 * (NB + 1) * 32 * sizeof(float);
   if (BIAS && NB <= 2 && WAVES == 8) lds += (size_t)WAVES * 32 * QB * (32 * NB + 4) * sizeof(float);
-  if (MASKED && p.key_mask != nullptr) lds += ((size_t)p.Nk + 15) / 16 * 16;
+  if (MASKED && p.key_mask != nullptr) lds += ((size_t)p.Nk + 15) / 16 * 16 + 16;     // mask bytes + the last-valid-key word
   if (lds > 160 * 1024) return set_err(HIPIE_EINVAL, "flash_attn: %zu bytes of LDS needed (Nk=%d) > 160 KiB", lds, p.Nk);
   p.nqt = (p.Nq + WAVES * 32 * QB - 1) / (WAVES * 32 * QB);
   p.ntiles = BIAS ? p.kh : (p.Nk + KT - 1) / KT;
