@@ -191,3 +191,46 @@ def test_prompt_construction_matches_reference(tmp_path):
     item = prompts.detection_inputs(torch.zeros(3, 32, 32), _synth.PROMPT_CATEGORIES, tok)
     assert item["task"] == "detection" and item["input_ids"].shape == item["attention_mask"].shape
     assert item["is_thing"][8] is False and item["positive_map_label_to_token"][2] == [3, 4]
+
+
+@pytest.mark.parametrize("max_pool", [False, True])
+@pytest.mark.parametrize("mode", [None, "FG", "BG"])
+def test_token_to_class_pooling_matches_reference_loop(mode, max_pool):
+    """convert_grounding_to_od_logits as one GEMM / one padded gather (hipie_amd/postprocess.py) against the oracle's
+    restatement of the reference's per-class loop (hipie_img.py:1025-1052), per-image thing maps included."""
+    from oracle import post as op
+    from hipie_amd import postprocess as pp
+    g = torch.Generator().manual_seed(4)
+    logits = torch.randn(3, 17, 64, generator=g)
+    _, _, pmap = _synth.synth_token_ids(2, 9, 64, seed=74)
+    things = [{c: (c % 2 == 0) for c in pmap}, {c: True for c in pmap}, {}]
+    got = pp.convert_grounding_to_od_logits(logits, len(pmap), pmap, things, mode, False, max_pool)
+    for b in range(3):
+        want = op.convert_grounding_to_od_logits(logits[b:b + 1], len(pmap), pmap, is_thing=things[b], mode=mode,
+                                                 max_pool=max_pool)[0]
+        assert torch.allclose(got[b], want, atol=1e-6)
+
+
+def test_geometry_cache_keys_and_eviction():
+    from hipie_amd.modeling import transformer as T
+    calls = []
+
+    def build(tag):
+        calls.append(tag)
+        return torch.tensor([len(calls)])
+    a = T.geo_cached(("k", 1), "x", lambda: build("a"))
+    b = T.geo_cached(("k", 1), "x", lambda: build("b"))           # hit
+    c = T.geo_cached(("k", 2), "x", lambda: build("c"))           # other geometry
+    d = T.geo_cached(None, "x", lambda: build("d"))               # no key: never cached
+    assert calls == ["a", "c", "d"] and a is b and c is not a and d is not a
+    own = T.collections.OrderedDict()
+    for i in range(40):
+        T.geo_cached(("own", i), "y", lambda: build("o"), store=own)
+    assert len(own) <= 33 and ("own", 39) in [k[0] for k in own]
+    imgs = [torch.zeros(3, 40, 50), torch.zeros(3, 33, 64)]
+    nt1 = T.nested_tensor_from_images(imgs)
+    nt2 = T.nested_tensor_from_images([torch.ones(3, 40, 50), torch.ones(3, 33, 64)])
+    assert nt1.mask is nt2.mask and nt1.geo_key == nt2.geo_key and tuple(nt1.tensors.shape) == (2, 3, 64, 64)
+    assert bool(nt1.mask[0, 39, 49]) is False and bool(nt1.mask[0, 40, 0]) is True and bool(nt1.mask[1, 0, 63]) is False
+    nt3 = T.nested_tensor_from_images([torch.zeros(3, 40, 51), torch.zeros(3, 33, 64)])
+    assert nt3.geo_key != nt1.geo_key and nt3.mask is not nt1.mask
