@@ -43,3 +43,18 @@ def test_ops_refuse_cpu_tensors():
     v = torch.zeros(1, 4, 2, 2)
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
         ops.ms_deform_attn_forward(v, torch.tensor([[2, 2]]), torch.tensor([0]), torch.zeros(1, 1, 2, 1, 1, 2), torch.zeros(1, 1, 2, 1, 1))
+
+
+def test_new_entry_points_validate_on_the_host():
+    lib = _lib.load()
+    p = ctypes.c_void_p(256)
+    assert lib.hipie_batched_nms(p, p, p, p, p, 1, 2000, 0.7, 1, None) == -22 and b"Q=2000" in lib.hipie_last_error()
+    assert lib.hipie_sem_pan(p, p, p, p, p, p, p, p, 10, 16, 200, 8, 8, 4, 32, 32, 32, 32, 0, None) == -22
+    assert b"C=200" in lib.hipie_last_error()
+    assert lib.hipie_sem_pan(p, p, p, p, p, p, p, p, 10, 10, 5, 8, 8, 4, 32, 32, 32, 32, 0, None) == -22      # Npad % 16
+    assert lib.hipie_vit_attn_fused(p, p, p, p, 1, 14, 14, 1, 80, 0.1, 2, None) == -22 and b"64-wide" in lib.hipie_last_error()
+    assert lib.hipie_mask_finalize(p, 0, None, 1, 8, 8, 4, 40, 32, 32, 32, 0.5, p, None) == -22              # crop outside the mask
+    assert lib.hipie_add_layernorm_rows(p, None, p, p, None, p, 4, 6, 1e-6, 0, 0, 0, None, None, None) == -22  # C % 4
+    # empty work is a no-op even with null data pointers
+    assert lib.hipie_batched_nms(None, None, None, None, None, 0, 0, 0.7, 1, None) == 0
+    assert lib.hipie_mask_finalize(None, 0, None, 0, 8, 8, 4, 32, 32, 32, 32, 0.5, None, None) == 0
