@@ -551,7 +551,22 @@ def gen_prompts():
     save("prompts", meta, dummy=np.zeros(1))
 
 
-ALL = dict(prompts=gen_prompts, post=gen_post, resnet50=gen_resnet50, msda=gen_msda, vit_attn=gen_vit_attn, vit_backbone=gen_vit_backbone, bi_attn=gen_bi_attn, bert=gen_bert,
+def gen_manifest_full():
+    """state_dict names and shapes of the reference's full-size model (ViT-H backbone, the shipped head sizes): what a released
+    checkpoint contains.  Built on the CPU from the reference's own classes (809.7 M parameters, ~30 s); only the
+    name -> shape table is stored."""
+    full = dict(TINY, vit_embed_dim=1280, vit_depth=32, vit_heads=16, vit_window_blocks=[0, 1, 3, 4, 6, 7, 9, 10],
+                dim_feedforward=2048, enc_layers=6, dec_layers=6, num_queries=900, num_bg_queries=10, md_num_queries=300,
+                md_dec_layers=9, md_enc_layers=6, md_dim_feedforward=2048, md_enc_dim_feedforward=2048, bert_layers=12)
+    model, bert = build_ref_model(full), build_ref_bert(full)
+    man = {"detr." + k: list(v.shape) for k, v in model.state_dict().items()}
+    man.update({"text_encoder.body." + k: list(v.shape) for k, v in bert.state_dict().items()})
+    with open(os.path.join(HERE, "manifest_vit_huge.json"), "w") as f:
+        json.dump(man, f, indent=0, sort_keys=True)
+    print("wrote manifest_vit_huge.json  %d entries" % len(man))
+
+
+ALL = dict(manifest_full=gen_manifest_full, prompts=gen_prompts, post=gen_post, resnet50=gen_resnet50, msda=gen_msda, vit_attn=gen_vit_attn, vit_backbone=gen_vit_backbone, bi_attn=gen_bi_attn, bert=gen_bert,
            dynamic_mask=gen_dynamic_mask, e2e=gen_e2e, stages=gen_stages, e2e_r50=gen_e2e_r50)
 
 if __name__ == "__main__":

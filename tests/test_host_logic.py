@@ -234,3 +234,21 @@ def test_geometry_cache_keys_and_eviction():
     assert bool(nt1.mask[0, 39, 49]) is False and bool(nt1.mask[0, 40, 0]) is True and bool(nt1.mask[1, 0, 63]) is False
     nt3 = T.nested_tensor_from_images([torch.zeros(3, 40, 51), torch.zeros(3, 33, 64)])
     assert nt3.geo_key != nt1.geo_key and nt3.mask is not nt1.mask
+
+
+def test_full_size_state_dict_matches_the_reference_checkpoint_layout():
+    """the shipped configuration (ViT-H, 6+6 layers, 900+10 queries, MaskDINO 300 queries / 9 layers, BERT-base): every one of
+    the 1624 state_dict entries of the reference's model (tests/golden/manifest_vit_huge.json, generated from the reference's
+    own classes) exists here with the same shape, and nothing else -- a released checkpoint loads with strict=True."""
+    import json
+    import os
+    from hipie_amd.config import HipieConfig, Precision
+    from hipie_amd.hipie_img import HIPIE_IMG
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "manifest_vit_huge.json")))
+    with torch.device("meta"):                       # shapes only: no 3 GB allocation
+        m = HIPIE_IMG(HipieConfig.vit_huge(), Precision.parity(), device="cpu")
+    ours = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert len(ref) == 1624
+    assert sorted(ours) == sorted(ref)
+    assert all(ours[k] == ref[k] for k in ref)
+    assert sum(int(torch.tensor(v).prod()) for v in ours.values()) == 809749203
