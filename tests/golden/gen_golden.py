@@ -564,6 +564,13 @@ def gen_manifest_full():
     with open(os.path.join(HERE, "manifest_vit_huge.json"), "w") as f:
         json.dump(man, f, indent=0, sort_keys=True)
     print("wrote manifest_vit_huge.json  %d entries" % len(man))
+    r50 = dict(full, backbone="r50")
+    model = build_ref_model(r50)
+    man = {"detr." + k: list(v.shape) for k, v in model.state_dict().items()}
+    man.update({"text_encoder.body." + k: list(v.shape) for k, v in bert.state_dict().items()})
+    with open(os.path.join(HERE, "manifest_r50.json"), "w") as f:
+        json.dump(man, f, indent=0, sort_keys=True)
+    print("wrote manifest_r50.json  %d entries" % len(man))
 
 
 ALL = dict(manifest_full=gen_manifest_full, prompts=gen_prompts, post=gen_post, resnet50=gen_resnet50, msda=gen_msda, vit_attn=gen_vit_attn, vit_backbone=gen_vit_backbone, bi_attn=gen_bi_attn, bert=gen_bert,

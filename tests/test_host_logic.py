@@ -252,3 +252,9 @@ def test_full_size_state_dict_matches_the_reference_checkpoint_layout():
     assert sorted(ours) == sorted(ref)
     assert all(ours[k] == ref[k] for k in ref)
     assert sum(int(torch.tensor(v).prod()) for v in ours.values()) == 809749203
+    # and the ResNet-50 configuration of BASELINE configs[0]/[1] (1436 entries)
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "manifest_r50.json")))
+    with torch.device("meta"):
+        m = HIPIE_IMG(HipieConfig.r50(), Precision.parity(), device="cpu")
+    ours = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert len(ref) == 1436 and ours == ref
