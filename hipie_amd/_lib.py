@@ -24,6 +24,7 @@ SIGNATURES = {
     "hipie_flash_attn": [c_p, c_p, c_p, c_p] + [c_i] * 5 + [c_l] * 12 + [c_p, c_p, c_i, c_i, c_p, c_f, c_f, c_i, c_p],
     "hipie_vit_attn": [c_p, c_p, c_p, c_p] + [c_i] * 5 + [c_f, c_i, c_p],
     "hipie_vit_attn_fused": [c_p, c_p, c_p, c_p] + [c_i] * 5 + [c_f, c_i, c_p],
+    "hipie_vit_attn_rel": [c_p, c_p, c_p, c_p] + [c_i] * 7 + [c_p],
     "hipie_bi_xattn": [c_p, c_p, c_p, c_p, c_p, c_p, c_p] + [c_i] * 5 + [c_f, c_i, c_p],
     "hipie_mask_einsum": [c_p, c_p, c_p] + [c_i] * 6 + [c_p],
     "hipie_dynamic_mask": [c_p, c_p, c_p, c_p] + [c_i] * 7 + [c_p],

@@ -197,6 +197,32 @@ def vit_attn_fused(qkv, tab_h, tab_w, grid_hw, heads, scale):
     return out
 
 
+LOG2E = 1.4426950408889634
+ATTN_FAST = 1            # include/hipie_mi355.h: HIPIE_ATTN_FAST
+
+
+def vit_attn_rel_ok(grid_hw, hd):
+    """the geometry hipie_vit_attn_rel covers: head_dim 64 / 80, token grids up to 96 wide (84 rows when wider than 64)."""
+    gh, gw = grid_hw
+    return hd in (64, 80) and 1 <= gw <= 96 and 1 <= gh <= (160 if gw <= 64 else 84)
+
+
+@_timed(lambda qkv, tab_h, tab_w, grid_hw, heads, fast=False: "vit_attn_global" if grid_hw[0] * grid_hw[1] > 256 else "vit_attn_window")
+def vit_attn_rel(qkv, tab_h, tab_w, grid_hw, heads, fast=False):
+    """ViT attention (global or windowed) with the decomposed rel-pos bias computed in the kernel.  Operand contract of
+    hipie_vit_attn_rel: qkv (B, gh*gw, 3*heads*hd) 16-bit whose q rows are PRE-SCALED by scale*log2(e); tab_h (2*gh-1, hd),
+    tab_w (2*gw-1, hd) = the (re-interpolated) rel-pos tables DIVIDED by scale, same dtype -> (B, N, heads*hd)."""
+    lib = _lib.load()
+    gh, gw = grid_hw
+    B, N, C3 = qkv.shape
+    hd = C3 // (3 * heads)
+    out = torch.empty(B, N, heads * hd, dtype=qkv.dtype, device=qkv.device)
+    rc = lib.hipie_vit_attn_rel(_chk(qkv, "qkv"), _chk(tab_h, "tab_h", qkv.dtype), _chk(tab_w, "tab_w", qkv.dtype),
+                                out.data_ptr(), B, gh, gw, heads, hd, _DT[qkv.dtype], ATTN_FAST if fast else 0, _stream())
+    _lib.check(rc, "hipie_vit_attn_rel")
+    return out
+
+
 @_timed("bi_xattn")
 def bi_xattn(q, k, vv, vl, text_mask, clamp=50000.0):
     """q, vv (B,Nv,H,hd); k, vl (B,L,H,hd) 16-bit contiguous; text_mask (B,L) -> out_v (B,Nv,H*hd), out_l (B,L,H*hd)."""

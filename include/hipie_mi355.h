@@ -21,12 +21,18 @@
 extern "C" {
 #endif
 
-#define HIPIE_ABI_VERSION 1
+#define HIPIE_ABI_VERSION 2
 
 /* element types of activations */
 #define HIPIE_F32 0
 #define HIPIE_F16 1
 #define HIPIE_BF16 2
+
+/* flags of the attention entry points that take a `flags` argument */
+#define HIPIE_ATTN_FAST 1    /* deferred running max (rescale only when a row maximum grows by > 2^8) and, where the head dim
+                                leaves a padded MFMA row, softmax denominators from a ones column of V (same 16-bit-rounded
+                                probabilities as the numerator).  Without it: classic running max, fp32 sums of the
+                                unrounded probabilities (the parity policy). */
 
 /* error codes */
 #define HIPIE_OK 0
@@ -166,6 +172,21 @@ int hipie_add_layernorm(const void* x, const void* delta, const float* gamma, co
  */
 int hipie_vit_attn_fused(const void* qkv, const void* tab_h, const void* tab_w, void* out, int B, int gh, int gw, int heads,
                          int hd, float scale, int dtype, void* stream);
+
+/*
+ * ViT attention of one block with the decomposed relative-position bias computed inside the kernel -- global blocks (one
+ * key tile = one key row of the gh x gw token grid) and the 14 x 14 windowed blocks (B = batch * windows; two key rows per
+ * tile) alike.  Replaces: Attention.forward between the qkv and proj Linears (backbone/vit.py:69-80) including
+ * get_rel_pos + add_decomposed_rel_pos (backbone/utils.py:63-125).
+ * Operand contract (the two constants are folded into the weights once by the host, hipie_amd/modeling/vit.py):
+ *   qkv   (B, gh*gw, 3, heads, hd) 16-bit with the q rows PRE-SCALED:  q' = scale * log2(e) * q
+ *   tab_h (2*gh-1, hd), tab_w (2*gw-1, hd) 16-bit = rel_pos_h / rel_pos_w after the reference's linear re-interpolation to
+ *         2*size-1 rows, DIVIDED by scale (entry [q - k + size - 1])
+ *   so that q'.k + q'.tab_h' + q'.tab_w' is the attention logit in the exp2 domain.
+ *   out   (B, gh*gw, heads*hd) 16-bit.   hd in {64, 80};  gw <= 96;  gh <= 84 when gw > 64 (LDS);  flags: HIPIE_ATTN_FAST.
+ */
+int hipie_vit_attn_rel(const void* qkv, const void* tab_h, const void* tab_w, void* out, int B, int gh, int gw, int heads,
+                       int hd, int dtype, int flags, void* stream);
 
 /*
  * hipie_add_layernorm with row maps, so that window_partition / window_unpartition (hipie/backbone/utils.py:16-60) around

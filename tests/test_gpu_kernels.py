@@ -185,6 +185,79 @@ def test_vit_attention_fused_relpos(dt, tol_same, tol_gold):
     assert rel_err(g.like("global64_out", out), g["global64_out"]) < tol_gold
 
 
+def _fold_rel(qkv32, tab_h32, tab_w32, heads, hd, dt):
+    """operands of hipie_vit_attn_rel from fp32 qkv / (re-interpolated) tables: q rows * scale*log2(e), tables / scale, rounded
+    ONCE to the 16-bit type; plus the fp32 (q, k, v, tables) those 16-bit operands stand for (what the oracle is fed)."""
+    from hipie_amd import ops
+    scale = hd ** -0.5
+    c1 = scale * ops.LOG2E
+    C = heads * hd
+    f = qkv32.clone()
+    f[..., :C] *= c1
+    f = f.to(dt)
+    th, tw = (tab_h32 / scale).to(dt).contiguous(), (tab_w32 / scale).to(dt).contiguous()
+    B, N = f.shape[:2]
+    q, k, v = f.float().reshape(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4).reshape(3, B * heads, N, hd).unbind(0)
+    return f, th, tw, q / c1, k, v, th.float() * scale, tw.float() * scale
+
+
+@pytest.mark.parametrize("dt,fast,tol_same,tol_gold", [(torch.float16, False, 1e-3, 2e-3), (torch.float16, True, 1.5e-3, 2e-3),
+                                                        (torch.bfloat16, True, 8e-3, 2e-2)])
+@pytest.mark.parametrize("name", ["window14", "global16", "global64", "global_rect"])
+def test_vit_attention_rel(name, dt, fast, tol_same, tol_gold):
+    """hipie_vit_attn_rel (bias computed in the kernel, pre-scaled q, two key rows per tile for the 14x14 windows) on the
+    reference-generated cases: windowed 14x14, a 16x16 grid with interpolated tables, the real 64x64 grid, a 12x20 grid
+    whose 32-query blocks wrap grid rows.  vs the oracle on the same 16-bit operands, and vs the reference golden."""
+    import torch.nn.functional as F
+    from hipie_amd import ops
+    from hipie_amd.modeling.vit import resize_rel_pos
+    g = Golden("vit_attn")
+    c, sd, x = vit_attn_case(g, name)
+    B, H, W, C = x.shape
+    heads = c["heads"]
+    hd = C // heads
+    assert ops.vit_attn_rel_ok((H, W), hd)
+    f, th, tw, q, k, v, th32, tw32 = _fold_rel(_vit_qkv(c, sd, x), resize_rel_pos(H, sd["rel_pos_h"]), resize_rel_pos(W, sd["rel_pos_w"]),
+                                               heads, hd, dt)
+    got = ops.vit_attn_rel(f.to(DEV), th.to(DEV), tw.to(DEV), (H, W), heads, fast=fast).float().cpu()
+    want = oo.vit_attention_core(q, k, v, th32, tw32, (H, W), hd ** -0.5)
+    want = want.view(B, heads, H * W, hd).permute(0, 2, 1, 3).reshape(B, H * W, C)
+    assert rel_err(got, want) < tol_same
+    out = F.linear(got, sd["proj.weight"], sd["proj.bias"]).view(B, H, W, C)
+    assert rel_err(g.like(name + "_out", out), g[name + "_out"]) < tol_gold
+
+
+@pytest.mark.parametrize("B,gh,gw,heads,hd,dt,fast", [
+    (1, 64, 64, 16, 80, torch.float16, False),        # the ViT-H global block at 1024^2 (BASELINE configs[2,3])
+    (1, 64, 64, 16, 80, torch.bfloat16, True),
+    (1, 84, 84, 4, 80, torch.float16, True),          # 1344^2 (BASELINE configs[4]): 84-wide grid, 3 key blocks, 8-wave workgroups
+    (2, 40, 64, 8, 64, torch.float16, True),          # ViT-B/L head dim, fewer rows than columns, batch/head swizzle on
+    (3, 14, 14, 5, 80, torch.float16, False),         # windows: 7-wave workgroups, odd batch*heads (no swizzle)
+    (2, 7, 14, 2, 80, torch.float16, True),           # odd number of key rows with two rows per tile (ragged last tile)
+    (1, 33, 50, 3, 64, torch.float16, False)])
+def test_vit_attention_rel_against_materialised_scores(B, gh, gw, heads, hd, dt, fast):
+    """the reference's own formulation with the (N x N) score tensor materialised in fp32 on the device
+    (backbone/vit.py:72-80 + utils.py:96-125) on random operands, at the full-size geometries."""
+    from hipie_amd import ops
+    gen = torch.Generator().manual_seed(21 + gh + gw)
+    N, C = gh * gw, heads * hd
+    scale = hd ** -0.5
+    f, th, tw, q, k, v, th32, tw32 = _fold_rel(torch.randn(B, N, 3 * C, generator=gen) * 0.8, torch.randn(2 * gh - 1, hd, generator=gen) * 0.2,
+                                               torch.randn(2 * gw - 1, hd, generator=gen) * 0.2, heads, hd, dt)
+    q, k, v = (t.to(DEV).view(B, heads, N, hd) for t in (q, k, v))
+    idx_h = torch.arange(gh, device=DEV)[:, None] - torch.arange(gh, device=DEV)[None, :] + gh - 1
+    idx_w = torch.arange(gw, device=DEV)[:, None] - torch.arange(gw, device=DEV)[None, :] + gw - 1
+    Rh, Rw = th32.to(DEV)[idx_h], tw32.to(DEV)[idx_w]
+    rq = q.reshape(B, heads, gh, gw, hd)
+    rel_h = torch.einsum("bmhwc,hkc->bmhwk", rq, Rh)
+    rel_w = torch.einsum("bmhwc,wkc->bmhwk", rq, Rw)
+    attn = (q * scale) @ k.transpose(-2, -1)
+    attn = (attn.view(B, heads, gh, gw, gh, gw) + rel_h[..., :, None] + rel_w[..., None, :]).view(B, heads, N, N)
+    want = (attn.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B, N, C)
+    got = ops.vit_attn_rel(f.to(DEV), th.to(DEV), tw.to(DEV), (gh, gw), heads, fast=fast).float()
+    assert rel_err(got.cpu(), want.cpu()) < (8e-3 if dt == torch.bfloat16 else 1.5e-3 if fast else 1e-3)
+
+
 @pytest.mark.parametrize("B,gh,heads,hd", [(2, 48, 8, 64), (1, 64, 16, 80), (3, 5, 3, 80)])
 def test_vit_attention_fused_equals_unfused(B, gh, heads, hd):
     """fused prologue == hipie_vit_relpos + hipie_vit_attn on random data: batch/head swizzle on and off, fewer rows than 64."""
