@@ -119,7 +119,7 @@ def main():
                     "as is (PAD_MAX off); 4096 = the shipped eval setting that pads every caption to 4096 tokens (SURVEY 8d)")
     ap.add_argument("--task", default="detection", choices=["detection", "grounding"],
                     help="grounding = the referring-expression call of BASELINE configs[2] (one ~12-token expression)")
-    ap.add_argument("--precision", default="fast", choices=["fast", "parity", "default"])
+    ap.add_argument("--precision", default="fast", choices=["fast", "parity", "bf16", "default"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="capture the forward once into a hipGraph and replay it (experimental: "
                     "after the launch-count reductions the eager path is no longer host-bound, and whole-model replay "
@@ -162,7 +162,7 @@ def main():
         torch.cuda.tunable.tuning_enable(False)
 
     cfg = getattr(HipieConfig, args.model)()
-    prec = {"fast": Precision.fast(), "parity": Precision.parity(), "default": Precision()}[args.precision]
+    prec = {"fast": Precision.fast(), "parity": Precision.parity(), "bf16": Precision.bf16(), "default": Precision()}[args.precision]
     torch.manual_seed(0)
     model = HIPIE_IMG(cfg, prec, device=dev)
     randomize_degenerate_inits(model)
@@ -273,7 +273,7 @@ def main():
             "metric": "images/sec @1024x1024 ViT-H bs=8 (single-image inference hot path: box, class and mask logits)",
             "value": round(images / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fast": "bf16", "parity": "f32+f16attn", "default": "bf16+f32head"}[args.precision],
+            "dtype": {"fast": "f16", "parity": "f32+f16attn", "bf16": "bf16", "default": "bf16+f32head"}[args.precision],
             "data": "synthetic (uint8-valued random images resident in HBM, synthetic BERT token ids, random-init weights)",
             "config": {"workload": "BASELINE.json configs[2]: %s, %dx%d, batch %d per GPU, %d class prompts (L=%d), detection"
                                    % (args.model, args.size, args.size, args.batch, n_classes, L),

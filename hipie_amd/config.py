@@ -19,8 +19,12 @@ class Precision:
     head      dtype of the linears/convs after the backbone (the reference runs them in fp32)
     value     dtype of the MSDeformAttn value tensor (fp32 as the reference, or 16-bit to halve the gather traffic)
     einsum    hipie_mask_einsum precision (0 exact fp32 MFMA, 1 bf16x3, 2 bf16)
-    act       storage dtype of the residual streams / activations between kernels (fp32, or bf16 to halve the
-              elementwise traffic and drop the cast kernels; statistics of LayerNorm / softmax stay fp32 either way)
+    act       storage dtype of the activations between kernels: backbone features, the encoder streams, mask logits (fp32, or
+              16 bit to halve the elementwise traffic and drop the cast kernels; statistics of LayerNorm / softmax stay fp32)
+    resid     dtype of the ViT residual stream (64 additions deep: fp32 keeps the 16-bit policies inside the tolerance at
+              +1.5 % of the step; bf16 only in the bf16 policy)
+    attn_fast attention kernels: deferred running max + row sums from the matrix pipe (HIPIE_ATTN_FAST); False = classic
+              running max and fp32 sums of the unrounded probabilities
     """
     gemm: torch.dtype = torch.bfloat16
     attn: torch.dtype = torch.bfloat16
@@ -28,15 +32,25 @@ class Precision:
     value: torch.dtype = torch.float32
     einsum: int = 1
     act: torch.dtype = torch.float32
+    resid: torch.dtype = torch.float32
+    attn_fast: bool = True
+    name: str = "default"
 
     @staticmethod
     def parity():
         """closest to the reference's fp32 eval arithmetic: only the attention operands are 16 bit (fp16)."""
-        return Precision(torch.float32, torch.float16, torch.float32, torch.float32, 0, torch.float32)
+        return Precision(torch.float32, torch.float16, torch.float32, torch.float32, 0, torch.float32, torch.float32, False, "parity")
 
     @staticmethod
     def fast():
-        return Precision(torch.bfloat16, torch.bfloat16, torch.bfloat16, torch.bfloat16, 1, torch.bfloat16)
+        """the timed policy: fp16 operands everywhere (same MFMA rate as bf16, 3 more mantissa bits), fp32 accumulation,
+        fp32 ViT residual stream; inside the north star's 1e-3-class tolerance end to end (tests/test_gpu_e2e.py)."""
+        return Precision(torch.float16, torch.float16, torch.float16, torch.float16, 1, torch.float16, torch.float32, True, "fast")
+
+    @staticmethod
+    def bf16():
+        """bf16 operands and streams everywhere (round 1's timed policy): widest range, 8 mantissa bits."""
+        return Precision(torch.bfloat16, torch.bfloat16, torch.bfloat16, torch.bfloat16, 1, torch.bfloat16, torch.bfloat16, True, "bf16")
 
 
 @dataclass
@@ -83,6 +97,9 @@ class HipieConfig:
     pixel_std: List[float] = field(default_factory=lambda: [58.395, 57.120, 57.375])
     log_scale: float = 0.0
     prior_prob: float = 0.01
+    max_query_len: int = 256                    # MODEL.LANGUAGE_BACKBONE.MAX_QUERY_LEN (hipie/config.py:84; 4096 / 8192 in the eval yamls)
+    pad_max: bool = True                        # MODEL.LANGUAGE_BACKBONE.PAD_MAX (hipie/config.py:88): padding="max_length" else "longest"
+    clip_enabled: bool = False                  # MODEL.CLIP.ENABLED: MaskCLIP score fusion -- not built: construction raises
     # post-processing (hipie_img.py:60-135: values of hipie/config.py:190-257; the eval yamls override the last three)
     ota: bool = True
     mask_thres: float = 0.5
@@ -135,6 +152,22 @@ class HipieConfig:
         """reference CfgNode (after add_hipie_config + yaml merge) -> HipieConfig."""
         m = cfg.MODEL
         c = HipieConfig()
+        # the eval path built here is the one every shipped eval yaml selects; any other switch position would silently
+        # compute something else, so it is refused (hipie/config.py:12-217 for the keys)
+        required = [("MODEL.PARALLEL_DET", m.PARALLEL_DET, False), ("MODEL.DECOUPLE_TGT", m.DECOUPLE_TGT, True),
+                    ("MODEL.STILL_TGT_FOR_BOTH", m.STILL_TGT_FOR_BOTH, True), ("MODEL.USE_IOU_BRANCH", m.USE_IOU_BRANCH, True),
+                    ("MODEL.STILL_CLS_FOR_ENCODER", m.STILL_CLS_FOR_ENCODER, True), ("MODEL.LANG_GUIDE_DET", m.LANG_GUIDE_DET, True),
+                    ("MODEL.DDETRS.USE_DINO", m.DDETRS.USE_DINO, True), ("MODEL.DDETRS.TWO_STAGE", m.DDETRS.TWO_STAGE, True),
+                    ("MODEL.DDETRS.MIXED_SELECTION", m.DDETRS.MIXED_SELECTION, True),
+                    ("MODEL.DDETRS.LOOK_FORWARD_TWICE", m.DDETRS.LOOK_FORWARD_TWICE, True),
+                    ("MODEL.DDETRS.BG_QUERY_FROM_LANG", m.DDETRS.BG_QUERY_FROM_LANG, False),
+                    ("MODEL.DDETRS.NEW_MASK_HEAD", m.DDETRS.NEW_MASK_HEAD, False), ("MODEL.DDETRS.USE_RAFT", m.DDETRS.USE_RAFT, False),
+                    ("MODEL.DDETRS.USE_REL_COORD", m.DDETRS.USE_REL_COORD, True), ("MODEL.CLIP.ENABLED_TRAIN", m.CLIP.ENABLED_TRAIN, False)]
+        bad = ["%s=%r (supported: %r)" % (k, v, want) for k, v, want in required if bool(v) != want]
+        if bad:
+            raise NotImplementedError("hipie_amd builds the shipped eval configuration only; unsupported: " + "; ".join(bad))
+        c.max_query_len, c.pad_max = int(m.LANGUAGE_BACKBONE.MAX_QUERY_LEN), bool(m.LANGUAGE_BACKBONE.PAD_MAX)
+        c.clip_enabled = bool(m.CLIP.ENABLED)
         if m.BACKBONE.NAME == "D2ViT":
             geo = {"ViT-Base": (768, 12, 12), "ViT-Large": (1024, 24, 16), "ViT-huge": (1280, 32, 16)}[m.VIT.NAME]
             c.backbone, (c.vit_embed_dim, c.vit_depth, c.vit_heads) = "vit", geo

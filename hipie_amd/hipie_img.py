@@ -58,6 +58,10 @@ class HIPIE_IMG(nn.Module):
     def __init__(self, cfg: HipieConfig, precision: Precision = None, device="cuda"):
         super().__init__()
         _lib.load()       # fail loudly at construction when the HIP library is missing -- there is no fallback path
+        if cfg.clip_enabled:
+            raise NotImplementedError(
+                "MODEL.CLIP.ENABLED: the MaskCLIP score fusion (hipie/open_vocab/clip.py:243-383, SURVEY 8f-2) is not part of "
+                "this build -- run with MODEL.CLIP.ENABLED False (the scores then differ from the shipped eval setting)")
         self.cfg = cfg
         self.precision = precision or Precision()
         self.device = torch.device(device)
@@ -80,10 +84,19 @@ class HIPIE_IMG(nn.Module):
         self.register_buffer("pixel_mean", torch.tensor(cfg.pixel_mean).view(3, 1, 1), persistent=False)
         self.register_buffer("pixel_std", torch.tensor(cfg.pixel_std).view(3, 1, 1), persistent=False)
         self.eval()
+        # Weight-derived state (policy-dtype casts, BN folds, fused projection weights, per-geometry constants) is built by
+        # finalize().  It runs lazily on the first forward and again after every load_state_dict, so the order
+        # build -> DetectionCheckpointer.load -> forward of train_net.py:269-271 never sees folds of the random init.
+        self._final = False
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module._invalidate())
+
+    def _invalidate(self):
+        self._final = False
 
     def finalize(self):
         """after loading weights: move to the device and put GEMM weights in the policy dtypes."""
         self.to(self.device)
+        self._final = True
         if self.device.type == "cuda" and os.environ.get("HIPIE_MIOPEN_FIND", "1") != "0":
             # MIOpen "find": benchmark the applicable solvers once per convolution configuration instead of the
             # immediate-mode heuristic (the shapes are static over an evaluation run); -7 ms per bs-8 ViT-H step
@@ -118,8 +131,10 @@ class HIPIE_IMG(nn.Module):
             if self.tokenizer is None:
                 raise RuntimeError("no tokenizer assets (projects/HIPIE/bert-base-uncased): pass input_ids/attention_mask")
             captions = [x["expressions"] for x in batched_inputs]
-            tok = self.tokenizer.batch_encode_plus(captions, padding="longest", return_special_tokens_mask=True,
-                                                   return_tensors="pt", truncation=True).to(self.device)
+            tok = self.tokenizer.batch_encode_plus(captions, max_length=self.cfg.max_query_len,
+                                                   padding="max_length" if self.cfg.pad_max else "longest",
+                                                   return_special_tokens_mask=True, return_tensors="pt",
+                                                   truncation=True).to(self.device)                 # hipie_img.py:904-909
             ids, mask = tok.input_ids, tok.attention_mask
             sep = self.tokenizer(".").input_ids[1]
         return self.text_encoder[0]({"input_ids": ids, "attention_mask": mask}, sep=sep)
@@ -130,6 +145,8 @@ class HIPIE_IMG(nn.Module):
         tasks = set(x["task"] for x in batched_inputs)
         assert len(tasks) == 1
         task = tasks.pop()
+        if not self._final:
+            self.finalize()
         images = self.preprocess_image(batched_inputs)
         lang = self.forward_text(batched_inputs)
         outputs, _ = self.detr.coco_inference(images, None, None, train=False, language_dict_features=lang, task=task)
@@ -140,7 +157,7 @@ class HIPIE_IMG(nn.Module):
     def forward(self, batched_inputs, do_postprocess=True):
         from .postprocess import inference
         out = self.forward_raw(batched_inputs)
-        return inference(self, out, batched_inputs)
+        return inference(self, out, batched_inputs, do_postprocess=do_postprocess)
 
     # ---- test / bench hooks ---------------------------------------------------------------------------------
     def pin_topk(self, topk_fg=None, topk_md=None):

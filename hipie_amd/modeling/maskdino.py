@@ -127,7 +127,7 @@ class MaskDINODecoder(nn.Module):
         self.resizer = FeatureResizer(768, d)                # dynamic_label_enc (training only; kept for the state_dict)
         self.mask_embed = MLP(d, d, cfg.md_mask_dim, 3)
         self.decoder_norm = PLayerNorm(d)
-        layer = DeformableTransformerDecoderLayer(d, cfg.md_dim_feedforward, 4, 8, 4, precision.value)
+        layer = DeformableTransformerDecoderLayer(d, cfg.md_dim_feedforward, 4, 8, 4, precision.value, precision.attn)
         self.decoder = TransformerDecoder(layer, self.num_layers, self.decoder_norm, d)
         self._bbox_embed = MLP(d, d, 4, 3)
         self.bbox_embed = nn.ModuleList([self._bbox_embed for _ in range(self.num_layers)])

@@ -282,7 +282,7 @@ class MSDeformAttn(nn.Module):
 
     def _fused_proj(self):
         so, aw = self.sampling_offsets, self.attention_weights
-        key = (so.weight.data_ptr(), aw.weight.data_ptr(), so.weight.dtype)
+        key = tuple((p.data_ptr(), p._version, p.dtype) for p in (so.weight, aw.weight, so.bias, aw.bias))
         if getattr(self, "_fp_key", None) != key:
             self._fp = (torch.cat([so.weight, aw.weight], 0).contiguous(), torch.cat([so.bias, aw.bias], 0).contiguous())
             self._fp_key = key
@@ -398,37 +398,37 @@ class DeformableTransformerEncoderVL(nn.Module):
 
 
 class MultiheadAttention(nn.Module):
-    """nn.MultiheadAttention parameters (in_proj_weight/in_proj_bias/out_proj), q = k = x_qk, v = x_v, batch-first."""
+    """nn.MultiheadAttention parameters (in_proj_weight/in_proj_bias/out_proj), q = k = x_qk, v = x_v, batch-first
+    (deformable_transformer_dino.py:435-436, dino_decoder.py:246-248).  The softmax(QK^T)V core runs on hipie_flash_attn
+    (head dim 32, 16-bit operands, fp32 softmax / accumulation) -- no library / Triton attention on the path."""
 
-    def __init__(self, d_model, n_heads):
+    def __init__(self, d_model, n_heads, attn_dtype=torch.float16):
         super().__init__()
         self.in_proj_weight = nn.Parameter(torch.empty(3 * d_model, d_model))
         self.in_proj_bias = nn.Parameter(torch.zeros(3 * d_model))
         self.out_proj = PLinear(d_model, d_model)
         self.n_heads = n_heads
+        self.attn_dtype = attn_dtype
         nn.init.xavier_uniform_(self.in_proj_weight)
 
     def forward(self, x_qk, x_v):
         B, N, C = x_qk.shape
         w, b = self.in_proj_weight, self.in_proj_bias
-        qk = F.linear(x_qk.to(w.dtype), w[:2 * C], b[:2 * C]).float()
-        v = F.linear(x_v.to(w.dtype), w[2 * C:], b[2 * C:]).float()
         hd = C // self.n_heads
-
-        def sp(t):
-            return t.view(B, N, self.n_heads, hd).transpose(1, 2)
-        o = F.scaled_dot_product_attention(sp(qk[..., :C]), sp(qk[..., C:]), sp(v))
-        return self.out_proj(o.transpose(1, 2).reshape(B, N, C))
+        qk = F.linear(x_qk.to(w.dtype), w[:2 * C], b[:2 * C]).to(self.attn_dtype).view(B, N, 2, self.n_heads, hd)
+        v = F.linear(x_v.to(w.dtype), w[2 * C:], b[2 * C:]).to(self.attn_dtype).view(B, N, self.n_heads, hd)
+        o = ops.flash_attn(qk[:, :, 0], qk[:, :, 1], v, hd ** -0.5)              # strided q / k views of one GEMM output
+        return self.out_proj(o)
 
 
 class DeformableTransformerDecoderLayer(nn.Module):
     """deformable_transformer_dino.py:397-450 == maskdino/transformer_decoder/dino_decoder.py:171-270 (batch-first here)."""
 
-    def __init__(self, d_model, d_ffn, n_levels, n_heads, n_points, value_dtype):
+    def __init__(self, d_model, d_ffn, n_levels, n_heads, n_points, value_dtype, attn_dtype=torch.float16):
         super().__init__()
         self.cross_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points, value_dtype)
         self.norm1 = PLayerNorm(d_model)
-        self.self_attn = MultiheadAttention(d_model, n_heads)
+        self.self_attn = MultiheadAttention(d_model, n_heads, attn_dtype)
         self.norm2 = PLayerNorm(d_model)
         self.linear1, self.linear2 = PLinear(d_model, d_ffn), PLinear(d_ffn, d_model)
         self.norm3 = PLayerNorm(d_model)
@@ -537,7 +537,7 @@ class DeformableTransformerVLDINO(nn.Module):
                                                       cfg.enc_n_points, precision.value)
         self.encoder = DeformableTransformerEncoderVL(VLFuse(cfg, precision), enc_layer, cfg.enc_layers, cfg.num_vl_layers)
         dec_layer = DeformableTransformerDecoderLayer(d, cfg.dim_feedforward, cfg.num_feature_levels, cfg.nheads,
-                                                      cfg.dec_n_points, precision.value)
+                                                      cfg.dec_n_points, precision.value, precision.attn)
         self.decoder = DeformableTransformerDecoder(d, dec_layer, cfg.dec_layers)
         self.level_embed = nn.Parameter(torch.randn(cfg.num_feature_levels, d))
         self.tgt_embed = nn.Embedding(cfg.num_queries, d)

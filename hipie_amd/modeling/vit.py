@@ -1,9 +1,9 @@
 """ViT backbone with windowed / global attention and decomposed relative position bias.
 
 Mirror of hipie/backbone/vit.py (ViT, Block, Attention, D2ViT) and hipie/backbone/utils.py with the reference's
-parameter names, so reference checkpoints load unchanged.  The attention core runs on the hand-written HIP kernel
-(hipie_vit_attn); the linears are library GEMMs.  The residual stream stays fp32, the GEMM/attention operands use the
-policy's 16-bit types.
+parameter names, so reference checkpoints load unchanged.  The attention core runs on the hand-written HIP kernels
+(hipie_vit_attn_rel); the linears are library GEMMs.  The residual stream is kept in ``precision.resid`` (fp32 in the
+parity and fast policies), the GEMM / attention operands use the policy's 16-bit types.
 """
 import math
 import os
@@ -127,21 +127,47 @@ class Attention(nn.Module):
         B, H, W, C = x.shape
         nh = self.num_heads
         hd = C // nh
-        qkv16 = self.qkv(x).reshape(B, H * W, 3 * C).to(self.precision.attn).contiguous()
-        # decomposed rel-pos bias from the UNSCALED q (utils.py:113-123): one MFMA launch on the packed qkv tensor
-        th, tw = self._rel_tables(H, W)
-        if ops.vit_attn_fused_ok((H, W), hd):
-            o = ops.vit_attn_fused(qkv16, th, tw, (H, W), nh, self.scale)      # bias from the tables inside the kernel
-        else:
+        if ops.vit_attn_rel_ok((H, W), hd):
+            # hipie_vit_attn_rel: rel-pos bias computed in the kernel; its operand contract (q rows * scale*log2(e), tables /
+            # scale) is met by folding the two constants into a copy of the qkv weights / the tables once (_folded)
+            w, b, th, tw = self._folded(H, W)
+            qkv16 = F.linear(x.to(w.dtype), w, b).reshape(B, H * W, 3 * C).to(self.precision.attn).contiguous()
+            o = ops.vit_attn_rel(qkv16, th, tw, (H, W), nh, fast=self.precision.attn_fast)
+        else:       # token grids wider than 96: bias tables through HBM (hipie_vit_relpos + hipie_vit_attn)
+            qkv16 = self.qkv(x).reshape(B, H * W, 3 * C).to(self.precision.attn).contiguous()
+            th, tw = self._rel_tables(H, W)
             rel_h, rel_w = ops.vit_relpos(qkv16, th, tw, (H, W), nh)
             o = ops.vit_attn(qkv16, rel_h, rel_w, (H, W), nh, self.scale)
         return self.proj(o.to(x.dtype)).view(B, H, W, C)
+
+    def _versions(self):
+        ps = (self.qkv.weight, self.qkv.bias, self.rel_pos_h, self.rel_pos_w)
+        return tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in ps)
+
+    def _folded(self, H, W):
+        """(qkv weight, bias) with the q rows multiplied by scale*log2(e) and the two rel-pos tables (re-interpolated to
+        2*size-1 rows, get_rel_pos utils.py:63-86) divided by scale, rounded ONCE to the GEMM / attention dtypes.  Cached per
+        token grid; the key carries the parameters' version counters, so load_state_dict / .to() invalidate it."""
+        key = (H, W, self.precision.attn, self._versions())
+        if getattr(self, "_fold_key", None) != key:
+            C = self.qkv.weight.shape[1]
+            c1 = self.scale * ops.LOG2E
+            w = self.qkv.weight.detach().float().clone()
+            b = self.qkv.bias.detach().float().clone()
+            w[:C] *= c1
+            b[:C] *= c1
+            gd = self.qkv.weight.dtype
+            th = (resize_rel_pos(H, self.rel_pos_h.detach().float()) / self.scale).to(self.precision.attn).contiguous()
+            tw = (resize_rel_pos(W, self.rel_pos_w.detach().float()) / self.scale).to(self.precision.attn).contiguous()
+            self._fold = (w.to(gd).contiguous(), b.to(gd).contiguous(), th, tw)
+            self._fold_key = key
+        return self._fold
 
 
     def _rel_tables(self, H, W):
         """rel_pos_h / rel_pos_w linearly re-interpolated to 2*size-1 rows when needed (get_rel_pos, utils.py:63-86), in the
         attention operand dtype, cached per token grid.  Entry [hq - hk + H - 1] is Rh[hq, hk] (:88-93)."""
-        key = (H, W, self.rel_pos_h.data_ptr(), self.rel_pos_h.device, self.precision.attn)
+        key = (H, W, self.precision.attn, self._versions())
         if getattr(self, "_rel_key", None) != key:
             self._rel_cache = (resize_rel_pos(H, self.rel_pos_h.float()).to(self.precision.attn).contiguous(),
                                resize_rel_pos(W, self.rel_pos_w.float()).to(self.precision.attn).contiguous())
@@ -220,13 +246,13 @@ class ViT(nn.Module):
 
     def forward(self, x):
         """x (B,3,H,W) fp32 normalised image -> {"res3","res4","res5"}: logical NCHW, channels-last memory, activation dtype."""
-        gd, ad = self.precision.gemm, self.precision.act
+        gd, ad, rd = self.precision.gemm, self.precision.act, self.precision.resid
         x = self.patch_embed(x).float()
-        x = (x + self._abs_pos((x.shape[1], x.shape[2]))).to(ad)
+        x = (x + self._abs_pos((x.shape[1], x.shape[2]))).to(rd)
         x, delta = x.contiguous(), None
         for blk in self.blocks:
             x, delta = blk(x, delta)
-        x = x + delta.to(x.dtype)
+        x = (x + delta.to(x.dtype)).to(ad)
         # fpn1: ConvTranspose2d(k=2, s=2) == one GEMM (E -> 4 * E/2, bias in the epilogue) + a pixel shuffle (vit.py:341-343).
         # The features leave in the activation dtype and in channels-last memory (logical NCHW): the 1x1 / 3x3 projections
         # that consume them run NHWC, so no layout or dtype copy sits between the backbone and the heads.
@@ -240,7 +266,7 @@ class ViT(nn.Module):
 
     def _abs_pos(self, hw):
         """bicubic-resized absolute position table, cached per token grid (weights are frozen at inference)."""
-        key = (hw, self.pos_embed.data_ptr(), self.pos_embed.device)
+        key = (hw, self.pos_embed.data_ptr(), self.pos_embed._version, str(self.pos_embed.device))
         if getattr(self, "_abs_pos_key", None) != key:
             self._abs_pos_cache = get_abs_pos(self.pos_embed.float(), True, hw)
             self._abs_pos_key = key

@@ -134,6 +134,7 @@ def msda_fused(value, spatial_shapes, level_start_index, ref, offsets, logits):
     return out
 
 
+@_timed("flash_attn")
 def flash_attn(q, k, v, scale, bias_h=None, bias_w=None, key_mask=None, clamp=0.0):
     """q (B,Nq,H,hd), k,v (B,Nk,H,hd) 16-bit (may be strided views with hd contiguous) -> (B,Nq,H*hd).
     bias_h (B*H,kh,Nq) / bias_w (B*H,Nq,kw) f32 decomposed rel-pos bias; key_mask (B,Nk) uint8/bool."""

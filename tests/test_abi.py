@@ -22,7 +22,7 @@ def test_library_loads_and_exports_all():
     lib = _lib.load()
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.hipie_version() == 1
+    assert lib.hipie_version() == 2
     assert lib.hipie_last_error() == b""
 
 
@@ -53,6 +53,8 @@ def test_new_entry_points_validate_on_the_host():
     assert b"C=200" in lib.hipie_last_error()
     assert lib.hipie_sem_pan(p, p, p, p, p, p, p, p, 10, 10, 5, 8, 8, 4, 32, 32, 32, 32, 0, None) == -22      # Npad % 16
     assert lib.hipie_vit_attn_fused(p, p, p, p, 1, 14, 14, 1, 80, 0.1, 2, None) == -22 and b"64-wide" in lib.hipie_last_error()
+    assert lib.hipie_vit_attn_rel(p, p, p, p, 1, 14, 200, 1, 80, 2, 0, None) == -22 and b"wider than 96" in lib.hipie_last_error()
+    assert lib.hipie_vit_attn_rel(p, p, p, p, 1, 14, 14, 1, 48, 2, 0, None) == -22 and b"head_dim" in lib.hipie_last_error()
     assert lib.hipie_mask_finalize(p, 0, None, 1, 8, 8, 4, 40, 32, 32, 32, 0.5, p, None) == -22              # crop outside the mask
     assert lib.hipie_add_layernorm_rows(p, None, p, p, None, p, 4, 6, 1e-6, 0, 0, 0, None, None, None) == -22  # C % 4
     # empty work is a no-op even with null data pointers

@@ -258,3 +258,129 @@ def test_full_size_state_dict_matches_the_reference_checkpoint_layout():
         m = HIPIE_IMG(HipieConfig.r50(), Precision.parity(), device="cpu")
     ours = {k: list(v.shape) for k, v in m.state_dict().items()}
     assert len(ref) == 1436 and ours == ref
+
+
+# ------------------------------------------------------------------------------------------------ registry boundary (b1)
+def _fake_detectron2(monkeypatch):
+    """the slice of detectron2 that hipie_amd.d2_registry touches, as in-memory modules (no detectron2 on any box here)."""
+    import sys
+    import types
+
+    class Registry(object):
+        def __init__(self, name):
+            self._name, self._obj_map = name, {}
+
+        def register(self, obj):
+            assert obj.__name__ not in self._obj_map
+            self._obj_map[obj.__name__] = obj
+            return obj
+
+        def get(self, name):
+            return self._obj_map[name]
+
+        def __contains__(self, name):
+            return name in self._obj_map
+
+    mods = {n: types.ModuleType(n) for n in ("detectron2", "detectron2.modeling", "detectron2.utils", "detectron2.utils.registry")}
+    mods["detectron2.utils.registry"].Registry = Registry
+    for r in ("BACKBONE_REGISTRY", "META_ARCH_REGISTRY", "SEM_SEG_HEADS_REGISTRY"):
+        setattr(mods["detectron2.modeling"], r, Registry(r))
+    for n, m in mods.items():
+        monkeypatch.setitem(sys.modules, n, m)
+    monkeypatch.delitem(sys.modules, "MultiScaleDeformableAttention", raising=False)
+    return mods["detectron2.modeling"]
+
+
+def _yacs_like(d):
+    import types
+    return types.SimpleNamespace(**{k: _yacs_like(v) if isinstance(v, dict) else v for k, v in d.items()})
+
+
+def _eval_cfg(**over):
+    """the keys HipieConfig.from_yacs reads, at the values of configs/eval/image_joint_r50_pan_maskdino_ade_test.yaml
+    (hipie/config.py for the rest), shrunk where size does not matter for the test."""
+    model = dict(
+        DEVICE="cpu", PARALLEL_DET=False, DECOUPLE_TGT=True, STILL_TGT_FOR_BOTH=True, USE_IOU_BRANCH=True, STILL_CLS_FOR_ENCODER=True,
+        LANG_GUIDE_DET=True, OTA=True, MODE_FREE_MATCHING_INFERENCE=False, PANO_TRANSFORM_EVAL=True, PANO_TEMPERATURE=0.06,
+        OVERLAP_THRESHOLD=0.8, OBJECT_MASK_THRESHOLD=0.25, PIXEL_MEAN=[123.675, 116.28, 103.53], PIXEL_STD=[58.395, 57.12, 57.375],
+        BACKBONE=dict(NAME="build_resnet_backbone"), VIT=dict(NAME="ViT-Base"),
+        DDETRS=dict(HIDDEN_DIM=256, NHEADS=8, DIM_FEEDFORWARD=64, ENC_LAYERS=1, DEC_LAYERS=1, NUM_FEATURE_LEVELS=4, ENC_N_POINTS=4,
+                    DEC_N_POINTS=4, TWO_STAGE_NUM_PROPOSALS=20, TWO_STAGE_NUM_BG_PROPOSALS=2, NUM_VL_LAYERS=1, VL_HIDDEN_DIM=2048,
+                    MASK_STRIDE=4, CTRL_LAYERS=3, MASK_THRES=0.5, USE_DINO=True, TWO_STAGE=True, MIXED_SELECTION=True,
+                    LOOK_FORWARD_TWICE=True, BG_QUERY_FROM_LANG=False, NEW_MASK_HEAD=False, USE_RAFT=False, USE_REL_COORD=True),
+        LANGUAGE_BACKBONE=dict(LANG_DIM=768, MAX_QUERY_LEN=8192, PAD_MAX=True), DYHEAD=dict(LOG_SCALE=0.0, PRIOR_PROB=0.01),
+        CLIP=dict(ENABLED=False, ENABLED_TRAIN=False), MASKDINO=dict(CONFIG_PATH="unused"))
+    cfg = dict(MODEL=model, TEST=dict(USE_BG_FOR_PANO_ON=True, BG_CLS_AGNOSTIC=False, MAX_POOL=False))
+    for path, v in over.items():
+        node = cfg
+        keys = path.split(".")
+        for k in keys[:-1]:
+            node = node[k]
+        node[keys[-1]] = v
+    return _yacs_like(cfg)
+
+
+def _md_cfg(cfg):
+    return _yacs_like(dict(MODEL=dict(MaskDINO=dict(NUM_OBJECT_QUERIES=12, DEC_LAYERS=1, DIM_FEEDFORWARD=64),
+                                      SEM_SEG_HEAD=dict(TRANSFORMER_ENC_LAYERS=1, DIM_FEEDFORWARD=64, MASK_DIM=256, CONVS_DIM=256))))
+
+
+def test_d2_registry_registers_and_builds_from_a_yacs_cfg(monkeypatch):
+    """register() against a (fake) detectron2 puts the five classes under the reference's names; HIPIE_IMG(cfg)
+    builds from a yacs-like CfgNode without touching weights (finalize is lazy: train_net.py loads the checkpoint AFTER
+    build_model), honours MAX_QUERY_LEN / PAD_MAX, and refuses switch positions the build does not implement."""
+    import sys
+    import pytest
+    from hipie_amd import d2_registry
+    from hipie_amd.config import Precision
+    modeling = _fake_detectron2(monkeypatch)
+    out = d2_registry.register(Precision.parity(), md_cfg_loader=_md_cfg)
+    assert "HIPIE_IMG" in modeling.META_ARCH_REGISTRY and "D2ViT" in modeling.BACKBONE_REGISTRY
+    assert "MaskDINOHead" in modeling.SEM_SEG_HEADS_REGISTRY and "MaskDINOEncoder" in modeling.SEM_SEG_HEADS_REGISTRY
+    assert "MaskDINODecoder" in out["TRANSFORMER_DECODER_REGISTRY"]
+    assert "MultiScaleDeformableAttention" in sys.modules                       # the op shim of SURVEY 8b2
+    d2_registry.register(Precision.parity(), md_cfg_loader=_md_cfg)              # idempotent
+
+    model = modeling.META_ARCH_REGISTRY.get("HIPIE_IMG")(_eval_cfg())
+    assert model.cfg.backbone == "r50" and model.cfg.max_query_len == 8192 and model.cfg.pad_max is True
+    assert model.cfg.num_queries == 20 and model.cfg.md_num_queries == 12
+    assert model._final is False                                                 # nothing weight-derived built at construction
+    conv = model.detr.detr.backbone[0].backbone.stem.conv1
+    assert conv.folded is None
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    sd["detr.detr.backbone.0.backbone.stem.conv1.weight"].fill_(0.25)
+    model._final = True
+    model.load_state_dict(sd, strict=True)
+    assert model._final is False                                                 # a checkpoint load re-arms finalize()
+    with pytest.raises(NotImplementedError, match="CLIP"):
+        modeling.META_ARCH_REGISTRY.get("HIPIE_IMG")(_eval_cfg(**{"MODEL.CLIP.ENABLED": True}))
+    with pytest.raises(NotImplementedError, match="PARALLEL_DET"):
+        modeling.META_ARCH_REGISTRY.get("HIPIE_IMG")(_eval_cfg(**{"MODEL.PARALLEL_DET": True}))
+    with pytest.raises(NotImplementedError, match="USE_DINO"):
+        modeling.META_ARCH_REGISTRY.get("HIPIE_IMG")(_eval_cfg(**{"MODEL.DDETRS.USE_DINO": False}))
+    vit = modeling.BACKBONE_REGISTRY.get("D2ViT")(_eval_cfg(**{"MODEL.BACKBONE.NAME": "D2ViT"}), None)
+    assert vit.blocks[0].attn.qkv.weight.shape == (3 * 768, 768)
+    head = modeling.SEM_SEG_HEADS_REGISTRY.get("MaskDINOHead")(_eval_cfg())
+    assert any(k.startswith("pixel_decoder.") for k in head.state_dict()) and any(k.startswith("predictor.") for k in head.state_dict())
+
+
+def test_r50_fold_follows_a_checkpoint_load():
+    """FrozenBN folds must come from the LOADED weights -- build, load_state_dict, finalize on the CPU and
+    compare the folded stem convolution with conv + FrozenBN of the loaded parameters."""
+    import torch
+    from hipie_amd.modeling.resnet import ResNet50
+    from hipie_amd.config import Precision
+    torch.manual_seed(0)
+    m = ResNet50(Precision.parity()).eval()
+    m.cast_weights()                                                             # a fold of the random init (what finalize-at-build did)
+    stale = m.stem.conv1.folded[0].clone()
+    sd = {k: torch.randn_like(v) * 0.1 + (1.0 if k.endswith("running_var") else 0.0) for k, v in m.state_dict().items()}
+    sd = {k: v.abs() + 0.5 if k.endswith("running_var") else v for k, v in sd.items()}
+    m.load_state_dict(sd)
+    m.cast_weights()
+    assert not torch.allclose(stale, m.stem.conv1.folded[0])
+    x = torch.randn(1, 3, 32, 32)
+    c = m.stem.conv1
+    want = c.norm(torch.nn.functional.conv2d(x, c.weight, None, stride=2, padding=3))
+    got = c(x)
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-5)
