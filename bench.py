@@ -68,16 +68,48 @@ def randomize_degenerate_inits(model):
                 p.copy_(torch.randn(p.shape, generator=g) * 0.02)
 
 
+def _median_time(fn, runs=3, warmup=1):
+    """SURVEY 8d protocol (mirrors detectron2/evaluation/evaluator.py:157-161): warm-up, then the median wall-clock of `runs`."""
+    for _ in range(warmup):
+        fn()
+    ts = []
+    for _ in range(runs):
+        t0 = time.time()
+        fn()
+        ts.append(time.time() - t0)
+    return sorted(ts)[len(ts) // 2]
+
+
 def cpu_baseline(cfg_dict, size, L, n_classes):
-    """oracle (kind "port") on the host cores, bounded: 1 image, the ViT truncated to 1 windowed + 1 global block (each
-    timed), everything after the backbone in full; s/img = t_rest + 8 t_win + 24 t_glob for the 32-block ViT-H."""
+    """oracle (kind "port") on the host cores, bounded, 1 warm-up + 3 timed runs each (median):
+      (1) BASELINE configs[0] in full: ResNet-50 configuration, one 512x512 image + one referring expression;
+      (2) the timed workload's own configuration on ONE image: text encoder + everything after the backbone in full, plus one
+          windowed and one global ViT block, s/img = t_rest + n_win t_win + n_glob t_glob (a full 32-block ViT-H forward per
+          run would take minutes per repetition)."""
     from oracle import model as om
     from hipie_amd.config import HipieConfig, Precision
     from hipie_amd.hipie_img import HIPIE_IMG
     threads = min(os.cpu_count(), 32)       # more threads than this makes the many small fp32 ops slower, not faster
     torch.set_num_threads(threads)
     torch.set_grad_enabled(False)
+    # (1) R50, 512x512, grounding
+    rc = HipieConfig.r50().to_dict()
+    m = HIPIE_IMG(HipieConfig.from_dict(rc), Precision.parity(), device="cpu")
+    randomize_degenerate_inits(m)
+    sd = {k: v.float() for k, v in m.state_dict().items()}
+    del m
+    gb = synth_batch(None, 1, 512, 1, 12, "cpu", seed=1, task="grounding")
+    ids, mask = gb[0]["input_ids"][None], gb[0]["attention_mask"][None]
+
+    def r50_forward():
+        lang = om.bert_encoder(ids, mask, sd, "text_encoder.body.model.", rc)
+        om.coco_inference([gb[0]["image"]], lang, sd, rc, task="grounding")
+    t_r50 = _median_time(r50_forward)
+    del sd
+    # (2) the timed configuration, ViT truncated to 1 windowed + 1 global block for the "rest" measurement
     c = dict(cfg_dict)
+    nwin = len(cfg_dict["vit_window_blocks"])
+    nglob = cfg_dict["vit_depth"] - nwin
     c.update(vit_depth=2, vit_window_blocks=[0])
     m = HIPIE_IMG(HipieConfig.from_dict(c), Precision.parity(), device="cpu")
     randomize_degenerate_inits(m)
@@ -85,25 +117,46 @@ def cpu_baseline(cfg_dict, size, L, n_classes):
     del m
     batch = synth_batch(None, 1, size, n_classes, L, "cpu", seed=1)
     ids, mask = batch[0]["input_ids"][None], batch[0]["attention_mask"][None]
-    t0 = time.time()
-    lang = om.bert_encoder(ids, mask, sd, "text_encoder.body.model.", c)
-    out = om.coco_inference([batch[0]["image"]], lang, sd, c, task="detection")
-    t_total2 = time.time() - t0
+
+    def rest_forward():
+        lang = om.bert_encoder(ids, mask, sd, "text_encoder.body.model.", c)
+        om.coco_inference([batch[0]["image"]], lang, sd, c, task="detection")
+    t_total2 = _median_time(rest_forward, runs=3, warmup=1)
     x = torch.randn(1, size // 16, size // 16, c["vit_embed_dim"])
     p = "detr.detr.backbone.0.backbone.blocks."
-    t0 = time.time()
-    om.vit_block(x, sd, p + "0.", c["vit_heads"], c["vit_window"])
-    t_win = time.time() - t0
-    t0 = time.time()
-    om.vit_block(x, sd, p + "1.", c["vit_heads"], 0)
-    t_glob = time.time() - t0
-    nwin = len(cfg_dict["vit_window_blocks"])
-    nglob = cfg_dict["vit_depth"] - nwin
+    t_win = _median_time(lambda: om.vit_block(x, sd, p + "0.", c["vit_heads"], c["vit_window"]))
+    t_glob = _median_time(lambda: om.vit_block(x, sd, p + "1.", c["vit_heads"], 0))
     s_img = t_total2 + (nwin - 1) * t_win + (nglob - 1) * t_glob
     return {"value": round(1.0 / s_img, 5), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "oracle/ (fp32 PyTorch CPU restatement) on 1 image %dx%d, L=%d: full text encoder + everything after "
-                      "the backbone + 1 windowed and 1 global ViT block measured (%.2fs, %.2fs), scaled to %d+%d blocks; "
-                      "measured part %.1fs" % (size, size, L, t_win, t_glob, nwin, nglob, t_total2 + t_win + t_glob)}
+            "sample": "oracle/ (fp32 PyTorch CPU restatement), 1 warm-up + 3 runs, median: 1 image %dx%d, L=%d: text encoder + "
+                      "everything after the backbone %.2fs (incl. 1 windowed + 1 global ViT block), windowed block %.2fs, global "
+                      "block %.2fs, scaled to %d+%d blocks = %.1fs/image" % (size, size, L, t_total2, t_win, t_glob, nwin, nglob, s_img),
+            "r50_512_grounding_full": {"value": round(1.0 / t_r50, 4), "unit": "images/sec", "s_per_image": round(t_r50, 3),
+                                       "what": "BASELINE configs[0]: ResNet-50, one 512x512 image + one referring expression, full forward"}}
+
+
+def parity_error(policy, device):
+    """max|a-b| / max|b| of every a22 output of the tiny end-to-end model under `policy` against the fixture produced by the
+    reference's own DDETRSegmUniDN.coco_inference (tests/golden/e2e_tiny.npz; top-k pinned) -- the same check as
+    tests/test_gpu_e2e.py, run by the bench so that the timed arithmetic carries its own error."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import _synth
+    from util import Golden, rel_err
+    from hipie_amd.config import HipieConfig
+    from hipie_amd.hipie_img import HIPIE_IMG
+    g = Golden("e2e_tiny")
+    model = HIPIE_IMG(HipieConfig.from_dict(g.meta["cfg"]), policy, device=device)
+    model.load_state_dict(_synth.synth_full_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}), strict=True)
+    imgs = _synth.synth_images([tuple(s) for s in g.meta["sizes"]], seed=73)
+    ids, mask, pmap = _synth.synth_token_ids(2, g.meta["detection"]["n_classes"], 64, seed=74)
+    model.pin_topk(g["detection_topk_fg"], g["detection_topk_md"])
+    out = model.forward_raw([{"image": im, "task": "detection", "input_ids": ids[i], "attention_mask": mask[i],
+                              "positive_map_label_to_token": pmap} for i, im in enumerate(imgs)])
+    keys = ["pred_logits", "pred_boxes", "pred_boxious", "pred_masks", "pred_masks_maskdino", "pred_logits_maskdino", "pred_boxes_maskdino"]
+    errs = {k: rel_err(g.like("detection_" + k, out[k].float().cpu()), g["detection_" + k]) for k in keys}
+    return {"max": float("%.2e" % max(errs.values())), "per_output": {k: float("%.1e" % v) for k, v in errs.items()},
+            "against": "tests/golden/e2e_tiny.npz (reference coco_inference, tiny model, pinned top-k)"}
 
 
 def main():
@@ -121,6 +174,7 @@ def main():
                     help="grounding = the referring-expression call of BASELINE configs[2] (one ~12-token expression)")
     ap.add_argument("--precision", default="fast", choices=["fast", "parity", "bf16", "default"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-leg", action="store_true", help="skip parity_err and the parity-policy timing (rank 0, N = 1)")
     ap.add_argument("--graph", action="store_true", help="capture the forward once into a hipGraph and replay it (experimental: "
                     "after the launch-count reductions the eager path is no longer host-bound, and whole-model replay "
                     "showed an unexplained GPU memory fault -- DESIGN.md section 9)")
@@ -132,6 +186,17 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="after the timed region, time every hand-written kernel class "
                     "and the main stages of one extra step (stderr)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: re-launch under torch.distributed.run, one rank per GPU, loopback rendezvous
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
 
     if args.cpu_baseline_only:          # child process of the cpu_baseline leg (bounded by a timeout in the parent)
         from hipie_amd.config import HipieConfig
@@ -145,7 +210,9 @@ def main():
     from hipie_amd.postprocess import inference
 
     rank, world, local = parallel.init_from_env()
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or "
+                         "run `python bench.py --gpus %d` without a WORLD_SIZE in the environment)" % (args.gpus, world, args.gpus, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.set_grad_enabled(False)
@@ -249,6 +316,36 @@ def main():
         post_ms = (time.perf_counter() - t1) * 1e3
         del out
 
+    # the timed arithmetic carries its own error, and the parity policy (<= 1e-3 on every a22 output) is timed beside it:
+    # same model, same batch, same step definition, fp32 GEMMs (N = 1, rank 0 only; a few steps -- it is ~5x slower)
+    parity_err = other = None
+    if rank == 0 and world == 1 and not args.no_parity_leg:
+        try:
+            parity_err = parity_error(prec, dev)
+            if args.precision != "parity" and args.model == "vit_huge":
+                del model
+                torch.cuda.empty_cache()
+                torch.manual_seed(0)
+                pm = HIPIE_IMG(cfg, Precision.parity(), device=dev)
+                randomize_degenerate_inits(pm)
+                pm.finalize()
+
+                def pstep():
+                    res = inference(pm, pm.forward_raw(batch), batch, with_masks=False, with_sem_pan=False)
+                    return parallel.compact_predictions(res, topk=100, device=dev)
+                pstep()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    pstep()
+                torch.cuda.synchronize()
+                pdt = (time.perf_counter() - t1) / 2
+                other = {"precision_policy": "parity", "dtype": "f32+f16attn", "value": round(args.batch / pdt, 3), "unit": "images/sec",
+                         "ms_per_step": round(pdt * 1e3, 2), "steps": 2, "parity_err": parity_error(Precision.parity(), dev)}
+                model = pm
+        except Exception as e:          # never lose the measured line to the side legs
+            print("bench: parity leg failed: %r" % (e,), file=sys.stderr)
+
     if args.breakdown and rank == 0:
         ops.PROFILE.enable("all")
         torch.cuda.synchronize()
@@ -262,7 +359,7 @@ def main():
 
     if rank == 0:
         traffic = None                  # HBM bytes per launch of the roofline kernel from the committed PMC passes (same shape only)
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_attention.json")
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_attention.json")
         if os.path.exists(pmc) and args.model == "vit_huge" and args.batch == 8 and args.size == 1024:
             traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
         images = args.batch * world * args.steps
@@ -281,13 +378,16 @@ def main():
                        "launch": "hipGraph replay" if graph is not None else "eager",
                        "constants": "weight- and geometry-only tensors (rel-pos tables, position embeddings, valid ratios) are "
                                     "built once; nothing that depends on image or text content is cached"},
-            "roofline": {"bound": "mfma", "kernel": "flash_attn_kernel<bf16,hd80,NB2,4 waves,fused rel-pos bias> (ViT global attention, %d launches timed)" % kern_n,
+            "roofline": {"bound": "mfma", "kernel": "vit_attn_sp_kernel<%s,hd80,NB2,8 waves,in-kernel rel-pos bias> (ViT global attention, %d launches timed)"
+                                                    % (str(prec.attn).split(".")[-1], kern_n),
                          "achieved": None if ach is None else round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": None if ach is None else round(ach / 2500.0, 4), "traffic": traffic,
-                         "traffic_note": "bytes per launch, rocprofv3 PMC FETCH_SIZE (x2, guide correction) + WRITE_SIZE, separate passes: profiles/r01_pmc_attention.md",
+                         "traffic_note": "bytes per launch, rocprofv3 PMC FETCH_SIZE (x2, guide correction) + WRITE_SIZE, separate passes: profiles/r02_pmc_attention.md",
                          "avg_launch_ms": None if not kern_ms else round(kern_ms, 4),
                          "flop_per_launch": flops},
             "postprocess_full_ms": None if post_ms is None else round(post_ms, 2),
+            "parity_err": parity_err,
+            "parity_policy": other,
         }
         if not args.no_cpu_baseline and world == 1 and args.model != "r50":   # rank 0 at N = 1 only (bounded ~20 s CPU sample)
             import subprocess
@@ -296,7 +396,7 @@ def main():
                 for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
                     env.pop(k, None)
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--model", args.model,
-                                    "--size", str(args.size)], capture_output=True, text=True, timeout=240, env=env)
+                                    "--size", str(args.size)], capture_output=True, text=True, timeout=420, env=env)
                 tag = [l for l in r.stdout.splitlines() if l.startswith("CPU_BASELINE ")]
                 line["cpu_baseline"] = json.loads(tag[-1][len("CPU_BASELINE "):]) if tag else \
                     {"value": None, "error": (r.stderr or r.stdout)[-300:]}

@@ -156,19 +156,16 @@ def test_config_from_yacs_key_mapping():
     namespace with those key names stands in for the CfgNode (yacs / detectron2 are not installed here)."""
     from types import SimpleNamespace as NS
     from hipie_amd.config import HipieConfig
-    m = NS(BACKBONE=NS(NAME="D2ViT"), VIT=NS(NAME="ViT-huge"),
-           DDETRS=NS(HIDDEN_DIM=256, NHEADS=8, DIM_FEEDFORWARD=2048, ENC_LAYERS=6, DEC_LAYERS=6, NUM_FEATURE_LEVELS=4,
-                     ENC_N_POINTS=4, DEC_N_POINTS=4, TWO_STAGE_NUM_PROPOSALS=900, TWO_STAGE_NUM_BG_PROPOSALS=10, NUM_VL_LAYERS=1,
-                     VL_HIDDEN_DIM=2048, MASK_STRIDE=4, CTRL_LAYERS=3, MASK_THRES=0.5),
-           LANGUAGE_BACKBONE=NS(LANG_DIM=768), PIXEL_MEAN=[123.675, 116.28, 103.53], PIXEL_STD=[58.395, 57.12, 57.375],
-           DYHEAD=NS(LOG_SCALE=0.0, PRIOR_PROB=0.01), OTA=True, MODE_FREE_MATCHING_INFERENCE=False, PANO_TRANSFORM_EVAL=True,
-           PANO_TEMPERATURE=0.06, OVERLAP_THRESHOLD=0.8, OBJECT_MASK_THRESHOLD=0.25)
-    cfg = NS(MODEL=m, TEST=NS(USE_BG_FOR_PANO_ON=False, BG_CLS_AGNOSTIC=True, MAX_POOL=True))
+    cfg = _eval_cfg(**{"MODEL.BACKBONE.NAME": "D2ViT", "MODEL.VIT.NAME": "ViT-huge", "MODEL.DDETRS.TWO_STAGE_NUM_PROPOSALS": 900,
+                       "MODEL.DDETRS.TWO_STAGE_NUM_BG_PROPOSALS": 10, "MODEL.LANGUAGE_BACKBONE.MAX_QUERY_LEN": 4096,
+                       "TEST.USE_BG_FOR_PANO_ON": False, "TEST.BG_CLS_AGNOSTIC": True, "TEST.MAX_POOL": True})
+    m = cfg.MODEL
     c = HipieConfig.from_yacs(cfg)
     assert (c.backbone, c.vit_embed_dim, c.vit_depth, c.vit_heads) == ("vit", 1280, 32, 16)
     assert (c.num_queries, c.num_bg_queries, c.mask_stride, c.ctrl_layers) == (900, 10, 4, 3)
     assert (c.use_bg_for_pano, c.bg_cls_agnostic, c.max_pool) == (False, True, True)
     assert (c.pano_temp, c.overlap_threshold, c.object_mask_threshold, c.mask_thres) == (0.06, 0.8, 0.25, 0.5)
+    assert (c.max_query_len, c.pad_max, c.clip_enabled) == (4096, True, False)
     m.BACKBONE.NAME = "build_resnet_backbone"
     md = NS(MODEL=NS(MaskDINO=NS(NUM_OBJECT_QUERIES=300, DEC_LAYERS=9, DIM_FEEDFORWARD=2048),
                      SEM_SEG_HEAD=NS(TRANSFORMER_ENC_LAYERS=6, DIM_FEEDFORWARD=2048, MASK_DIM=256, CONVS_DIM=256)))
