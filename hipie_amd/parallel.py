@@ -47,18 +47,39 @@ def compact_predictions(results, topk=100, device=None):
         block[i, :k, :4] = inst.pred_boxes.tensor[:k]
         block[i, :k, 4] = inst.scores[:k]
         block[i, :k, 5] = inst.pred_classes[:k].float()
-        block[i, :k, 6] = torch.arange(k, device=dev, dtype=torch.float32)
+        block[i, :k, 6] = inst.query_index[:k].float() if inst.has("query_index") else -1.0
+    return block
+
+
+def compact_maps(results, hw, stride=4, device=None):
+    """per-image semantic and panoptic label maps at 1/stride resolution: (n_img, 2, hw[0], hw[1]) int16,
+    channel 0 = arg-max class of `sem_seg` (C,H,W), channel 1 = panoptic segment id of `panoptic_seg[0]` (H,W); -1 where the
+    image is smaller than the block or the map is absent (task "grounding", or with_sem_pan=False).  Nearest subsampling."""
+    n = len(results)
+    dev = device or results[0]["instances"].scores.device
+    block = torch.full((n, 2, hw[0], hw[1]), -1, dtype=torch.int16, device=dev)
+    for i, r in enumerate(results):
+        sem, pan = r.get("sem_seg"), (r.get("panoptic_seg") or (None, None))[0]
+        if sem is not None:
+            m = sem[:, ::stride, ::stride].argmax(0)[:hw[0], :hw[1]]
+            block[i, 0, :m.shape[0], :m.shape[1]] = m.to(torch.int16)
+        if pan is not None:
+            m = pan[::stride, ::stride][:hw[0], :hw[1]]
+            block[i, 1, :m.shape[0], :m.shape[1]] = m.to(torch.int16)
     return block
 
 
 def all_gather_predictions(block):
-    """(n_local, topk, F) per rank (same n_local on every rank: pad upstream) -> (world*n_local, topk, F) on every rank."""
+    """(n_local, ...) per rank (same shape on every rank: pad upstream) -> (world*n_local, ...) on every rank.  One
+    all_gather_into_tensor per block: the (n, topk, 7) fp32 instance block and, when computed, the (n, 2, h, w) int16 map block."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return block
     world = dist.get_world_size()
-    out = torch.empty((world * block.shape[0],) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
-    dist.all_gather_into_tensor(out, block.contiguous())
-    return out
+    block = block.contiguous()
+    raw = block if block.dtype == torch.float32 else block.view(torch.uint8)      # bytes: every backend gathers uint8
+    out = torch.empty((world * raw.shape[0],) + tuple(raw.shape[1:]), dtype=raw.dtype, device=raw.device)
+    dist.all_gather_into_tensor(out, raw)
+    return out if block.dtype == torch.float32 else out.view(block.dtype)
 
 
 def barrier():

@@ -239,6 +239,7 @@ def inference(model, out, batched_inputs, do_postprocess=True, with_masks=True, 
         inst.scores = top_v[i][sel]
         inst.pred_classes = labels[i][sel]
         qidx = top_q[i][sel].to(torch.int32).contiguous()
+        inst.query_index = qidx               # foreground-query index of every instance (the data-parallel gather carries it)
         if with_masks:
             inst.pred_masks = ops.mask_finalize(pred_masks[i].contiguous(), qidx, s, image_sizes[i], out_sizes_inst[i], cfg.mask_thres)
         res = {"instances": inst, "panoptic_seg": (None, None), "sem_seg": None}

@@ -25,14 +25,20 @@ def _worker(rank, world, port, total, q):
         gi = idx[i] if i < len(idx) else -1
         k = 3
         from hipie_amd.structures import Boxes, Instances
+        sem = torch.zeros(3, 8, 8)
+        sem[max(gi, 0) % 3] = 1.0                                  # arg-max class = image index mod 3
         results.append({"instances": Instances((8, 8), pred_boxes=Boxes(torch.full((k, 4), float(gi))),
                                                scores=torch.full((k,), float(gi) + 0.5),
-                                               pred_classes=torch.full((k,), gi, dtype=torch.long))})
+                                               pred_classes=torch.full((k,), gi, dtype=torch.long),
+                                               query_index=torch.tensor([7, 3, 11], dtype=torch.int32) + max(gi, 0)),
+                        "sem_seg": sem if gi >= 0 else None,
+                        "panoptic_seg": (torch.full((8, 8), gi + 1, dtype=torch.int32), []) if gi >= 0 else (None, None)})
     block = parallel.compact_predictions(results, topk=5)
     out = parallel.all_gather_predictions(block)
+    maps = parallel.all_gather_predictions(parallel.compact_maps(results, (2, 2), stride=4))
     t = parallel.max_over_ranks(1.0 + r, torch.device("cpu"))
     parallel.barrier()
-    q.put((r, idx, out.tolist(), t))     # plain lists: no shared-memory handles across process exit
+    q.put((r, idx, out.tolist(), t, maps.tolist()))     # plain lists: no shared-memory handles across process exit
 
 
 def test_two_rank_shard_and_gather():
@@ -54,6 +60,14 @@ def test_two_rank_shard_and_gather():
     seen = sorted(int(v) for v in full[:, 0, 5].tolist())
     assert seen == [-1, 0, 1, 2, 3, 4, 5, 6]                               # 7 images + one pad slot
     assert got[0][3] == 2.0 and got[1][3] == 2.0                           # max over ranks
+    img3 = [i for i in range(8) if full[i, 0, 5] == 3][0]
+    assert full[img3, :3, 6].tolist() == [10.0, 6.0, 14.0] and full[img3, 3, 6] == 0.0      # real query indices, zero padding
+    assert got[0][4] == got[1][4]
+    maps = torch.tensor(got[0][4])
+    assert maps.shape == (8, 2, 2, 2)
+    assert (maps[img3, 0] == 0).all() and (maps[img3, 1] == 4).all()        # class 3 % 3, panoptic id 3 + 1
+    pad = [i for i in range(8) if full[i, 0, 5] == -1][0]
+    assert (maps[pad] == -1).all()                                          # the padded slot carries no maps
 
 
 def test_shard_range_covers_everything():
