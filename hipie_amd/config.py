@@ -18,7 +18,8 @@ class Precision:
     attn      16-bit operand type of the hand-written attention kernels (fp16 or bf16)
     head      dtype of the linears/convs after the backbone (the reference runs them in fp32)
     value     dtype of the MSDeformAttn value tensor (fp32 as the reference, or 16-bit to halve the gather traffic)
-    einsum    hipie_mask_einsum precision (0 exact fp32 MFMA, 1 bf16x3, 2 bf16)
+    einsum    mask contraction: fp32 features with 0 exact fp32 MFMA, 1 bf16x3, 2 bf16 (hipie_mask_einsum); features in the 16-bit
+              activation dtype with 3 one product, 4 query embedding split hi + lo (hipie_mask_einsum16; needs act 16 bit)
     act       storage dtype of the activations between kernels: backbone features, the encoder streams, mask logits (fp32, or
               16 bit to halve the elementwise traffic and drop the cast kernels; statistics of LayerNorm / softmax stay fp32)
     resid     dtype of the ViT residual stream (64 additions deep: fp32 keeps the 16-bit policies inside the tolerance at
@@ -45,12 +46,12 @@ class Precision:
     def fast():
         """the timed policy: fp16 operands everywhere (same MFMA rate as bf16, 3 more mantissa bits), fp32 accumulation,
         fp32 ViT residual stream; inside the north star's 1e-3-class tolerance end to end (tests/test_gpu_e2e.py)."""
-        return Precision(torch.float16, torch.float16, torch.float16, torch.float16, 1, torch.float16, torch.float32, True, "fast")
+        return Precision(torch.float16, torch.float16, torch.float16, torch.float16, 4, torch.float16, torch.float32, True, "fast")
 
     @staticmethod
     def bf16():
         """bf16 operands and streams everywhere (round 1's timed policy): widest range, 8 mantissa bits."""
-        return Precision(torch.bfloat16, torch.bfloat16, torch.bfloat16, torch.bfloat16, 1, torch.bfloat16, torch.bfloat16, True, "bf16")
+        return Precision(torch.bfloat16, torch.bfloat16, torch.bfloat16, torch.bfloat16, 3, torch.bfloat16, torch.bfloat16, True, "bf16")
 
 
 @dataclass

@@ -81,6 +81,7 @@ class MaskDINOEncoder(nn.Module):
                                            PConv2d(cd, cfg.md_mask_dim, kernel_size=1))
         self.adapter_1 = NormConv2d(in_channels[0], cd, 1)
         self.layer_1 = NormConv2d(cd, cd, 3, padding=1, relu=True)
+        self.precision = precision
 
     def forward_features(self, features, masks=None):
         f3, f4, f5 = features["res3"], features["res4"], features["res5"]      # the projections cast / lay out their input
@@ -99,7 +100,9 @@ class MaskDINOEncoder(nn.Module):
         z = self.layer_1(z)
         mf = self.mask_features[0](z.to(self.mask_features[0].weight.dtype)).float()
         mf = self.mask_features[3](self.mask_features[2](self.mask_features[1](mf)))
-        mf = mf.float().contiguous()      # NCHW fp32, pixel fastest: the einsum's B-operand layout, produced once for both calls
+        # NCHW, pixel fastest: the einsum's operand layout, produced once for both calls; fp32 for hipie_mask_einsum, the 16-bit
+        # activation dtype for hipie_mask_einsum16 (precision.einsum >= 3)
+        mf = (mf.to(self.precision.act) if self.precision.einsum >= 3 else mf.float()).contiguous()
         return mf, out[0], out          # mask_features (B,256,H/4,W/4), s8 level, [s8,s16,s32,s64]
 
 
@@ -146,8 +149,11 @@ class MaskDINODecoder(nn.Module):
         masks = None
         if pred_mask:
             emb = self.mask_embed(dec)
-            masks = ops.mask_einsum(emb.float().contiguous(), mask_features, precision=self.precision.einsum,
-                                    out_dtype=self.precision.act)
+            if self.precision.einsum >= 3:          # 16-bit features: 3 = single product, 4 = embedding split hi + lo
+                masks = ops.mask_einsum16(emb.float(), mask_features, split=self.precision.einsum == 4)
+            else:
+                masks = ops.mask_einsum(emb.float().contiguous(), mask_features, precision=self.precision.einsum,
+                                        out_dtype=self.precision.act)
         return cls, masks
 
     def forward(self, x, mask_features):

@@ -254,6 +254,25 @@ def mask_einsum(mask_embed, mask_features, precision=1, out_dtype=torch.float32)
     return out
 
 
+@_timed("mask_einsum")
+def mask_einsum16(mask_embed, mask_features, split=True, out_dtype=None):
+    """einsum("bqc,bchw->bqhw") on 16-bit features: mask_embed (B,Q,C) f32 (split here into 16-bit hi + lo parts: two MFMAs per
+    product; split=False: hi only), mask_features (B,C,H,W) f16 | bf16 contiguous -> (B,Q,H,W) out_dtype (default: the feature
+    dtype).  Q <= 320."""
+    lib = _lib.load()
+    B, Q, C = mask_embed.shape
+    _, _, Hh, Ww = mask_features.shape
+    dt = mask_features.dtype
+    out_dtype = out_dtype or dt
+    hi = mask_embed.to(dt).contiguous()
+    lo = (mask_embed.float() - hi.float()).to(dt).contiguous() if split else None
+    out = torch.empty(B, Q, Hh, Ww, dtype=out_dtype, device=mask_embed.device)
+    rc = lib.hipie_mask_einsum16(_chk(hi, "embed_hi"), None if lo is None else _chk(lo, "embed_lo"), _chk(mask_features, "mask_features"),
+                                 out.data_ptr(), B, Q, C, Hh * Ww, _DT[dt], _DT[out_dtype], _stream())
+    _lib.check(rc, "hipie_mask_einsum16")
+    return out
+
+
 @_timed("dynamic_mask")
 def dynamic_mask(mask_feats, ref_points, params, num_queries, stride=8, up=2, out_dtype=torch.float32):
     """mask_feats (B,8,H,W) f32; ref_points (B*Q,2) f32 pixels; params (B*Q,169) f32 -> (B*Q, up*H, up*W)."""

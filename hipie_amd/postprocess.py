@@ -263,7 +263,7 @@ def inference(model, out, batched_inputs, do_postprocess=True, with_masks=True, 
             else:
                 cls_all = logits_all.sigmoid()
             sem, tab = _sem_pan(cls_all, masks_all, s, image_sizes[i], out_sizes[i], thing_vector(is_thing[i], C, dev), cfg,
-                                0 if getattr(getattr(model, "precision", None), "einsum", 0) <= 1 else 1)
+                                0 if getattr(getattr(model, "precision", None), "einsum", 0) in (0, 1, 4) else 1)
             results[i]["sem_seg"] = sem
             tables.append(tab)
         for i, info in enumerate(_segments_info(tables)):

@@ -131,6 +131,15 @@ int hipie_mask_einsum(const float* embed, const float* feats, void* out, int B, 
                       int precision, int out_dtype, void* stream);
 
 /*
+ * The same contraction on 16-bit features (the activation dtype of the 16-bit policies): out[b,q,p] = sum_c embed[b,q,c] *
+ * feats[b,c,p] with feats (B,C,HW) `dtype` (f16 | bf16), the query embedding pre-split by the caller into embed_hi + embed_lo
+ * (both (B,Q,C) `dtype`; embed_lo NULL: single product), out (B,Q,HW) `out_dtype` (= dtype, or f32).  fp32 accumulation.
+ * Replaces the same torch.einsum (maskdino_decoder.py:527).  Q <= 320, C % 16 == 0, HW % 8 == 0 (HW even for f32 output).
+ */
+int hipie_mask_einsum16(const void* embed_hi, const void* embed_lo, const void* feats, void* out, int B, int Q, int C, int HW,
+                        int dtype, int out_dtype, void* stream);
+
+/*
  * Fused CondInst dynamic mask head: relative-coordinate generation + per-instance 10->8->8->1 MLP (ReLU, ReLU, none)
  * + aligned_bilinear x`up`, without materialising the (1, N*10, H, W) input or running a grouped conv.
  * Replaces: DDETRSegmUniDN.dynamic_mask_with_coords (models/ddetrs_dn.py:1411-1502) incl. compute_locations (:1857),

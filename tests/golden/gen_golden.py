@@ -135,6 +135,7 @@ def gen_vit_attn():
         "global16": (160, 2, (64, 64), (2, 16, 16)),     # table 127 -> interpolated to 31
         "global64": (80, 1, (64, 64), (1, 64, 64)),      # the real 64x64 geometry, 1 head
         "global_rect": (160, 2, (64, 64), (1, 12, 20)),  # non-square token grid
+        "global84": (80, 1, (64, 64), (1, 84, 84)),      # 1344-pixel images (BASELINE configs[4]): table 127 -> 167 (utils.py:75-86)
     }
     for name, (dim, heads, insz, (B, H, W)) in cases.items():
         m = vit.Attention(dim, num_heads=heads, qkv_bias=True, use_rel_pos=True, rel_pos_zero_init=True,
@@ -371,8 +372,10 @@ def gen_e2e(c=None, name="e2e_tiny", tasks=(("detection", 9), ("grounding", 1)))
         r = real_topk(*a, **k)
         topk_log.append(r[1].clone())
         return r
-    for task, ncls in tasks:
-        ids, mask, pmap = _synth.synth_token_ids(2, ncls, 64, seed=74)
+    for spec in tasks:
+        task, ncls = spec[0], spec[1]
+        max_len, pad_to = (spec[2], spec[3]) if len(spec) > 2 else (64, None)
+        ids, mask, pmap = _synth.synth_token_ids(2, ncls, max_len, seed=74, pad_to=pad_to)
         lang = bert({"input_ids": ids, "attention_mask": mask}, sep=1012)
         arrays[task + "_lang_hidden"] = lang["hidden"].clone()
         topk_log.clear()
@@ -388,13 +391,19 @@ def gen_e2e(c=None, name="e2e_tiny", tasks=(("detection", 9), ("grounding", 1)))
                 arrays[task + "_" + k] = v
         arrays[task + "_topk_fg"] = topk_log[0]
         arrays[task + "_topk_md"] = topk_log[1]
-        meta[task] = dict(n_classes=ncls, L=int(ids.shape[1]), pmap={str(k): v for k, v in pmap.items()})
+        meta[task] = dict(n_classes=ncls, L=int(ids.shape[1]), max_len=max_len, pad_to=pad_to, pmap={str(k): v for k, v in pmap.items()})
     save(name, meta, **arrays)
 
 
 def gen_e2e_r50():
     """the R50 configs (BASELINE configs[0]/[1]): same tiny heads behind the reference's detectron2 ResNet-50."""
     gen_e2e(dict(TINY, backbone="r50"), "e2e_r50_tiny", (("detection", 9),))
+
+
+def gen_e2e_long():
+    """BASELINE configs[3]-style prompt inside the full path: ~815 real tokens (BertEncoder's > 512 chunking, bert_model.py:61-135),
+    padded to 896 like PAD_MAX does; 400 synthetic classes."""
+    gen_e2e(TINY, "e2e_long_tiny", (("detection", 400, 815, 896),))
 
 
 # ------------------------------------------------------------------------------ sub-module goldens from the e2e model
@@ -574,7 +583,7 @@ def gen_manifest_full():
 
 
 ALL = dict(manifest_full=gen_manifest_full, prompts=gen_prompts, post=gen_post, resnet50=gen_resnet50, msda=gen_msda, vit_attn=gen_vit_attn, vit_backbone=gen_vit_backbone, bi_attn=gen_bi_attn, bert=gen_bert,
-           dynamic_mask=gen_dynamic_mask, e2e=gen_e2e, stages=gen_stages, e2e_r50=gen_e2e_r50)
+           dynamic_mask=gen_dynamic_mask, e2e=gen_e2e, stages=gen_stages, e2e_r50=gen_e2e_r50, e2e_long=gen_e2e_long)
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)

@@ -114,64 +114,6 @@ class _Registry:
         return self._d[name]
 
 
-class _FrozenBatchNorm2d(nn.Module):
-    """detectron2.layers.FrozenBatchNorm2d (batch_norm.py:13-65): four buffers, F.batch_norm(training=False)."""
-
-    def __init__(self, num_features, eps=1e-5):
-        super().__init__()
-        self.eps = eps
-        self.register_buffer("weight", torch.ones(num_features))
-        self.register_buffer("bias", torch.zeros(num_features))
-        self.register_buffer("running_mean", torch.zeros(num_features))
-        self.register_buffer("running_var", torch.ones(num_features) - eps)
-
-    def forward(self, x):
-        return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, training=False, eps=self.eps)
-
-
-def _get_norm(norm, out_channels):
-    if norm is None or norm == "":
-        return None
-    if norm == "FrozenBN":
-        return _FrozenBatchNorm2d(out_channels)
-    if norm == "GN":
-        return nn.GroupNorm(32, out_channels)
-    if norm == "LN":
-        class _LN2d(nn.Module):  # detectron2.layers.batch_norm.LayerNorm (channels-first LN)
-            def __init__(self, c, eps=1e-6):
-                super().__init__()
-                self.weight = nn.Parameter(torch.ones(c))
-                self.bias = nn.Parameter(torch.zeros(c))
-                self.eps = eps
-
-            def forward(self, x):
-                u = x.mean(1, keepdim=True)
-                s = (x - u).pow(2).mean(1, keepdim=True)
-                x = (x - u) / torch.sqrt(s + self.eps)
-                return self.weight[:, None, None] * x + self.bias[:, None, None]
-        return _LN2d(out_channels)
-    raise ValueError(norm)
-
-
-class _D2Conv2d(nn.Conv2d):
-    """detectron2.layers.Conv2d: nn.Conv2d + optional norm + optional activation."""
-
-    def __init__(self, *args, **kwargs):
-        norm = kwargs.pop("norm", None)
-        activation = kwargs.pop("activation", None)
-        super().__init__(*args, **kwargs)
-        self.norm = norm
-        self.activation = activation
-
-    def forward(self, x):
-        x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
-        if self.norm is not None:
-            x = self.norm(x)
-        if self.activation is not None:
-            x = self.activation(x)
-        return x
-
-
 class _Mlp(nn.Module):
     """timm.models.layers.Mlp (fc1 -> act -> fc2; dropout 0)."""
 
@@ -214,16 +156,49 @@ class _CNNBlockBase(nn.Module):
         self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
 
 
+_REF_LAYERS = None
+
+
+def ref_d2_layers():
+    """the reference's own vendored detectron2/layers/wrappers.py (Conv2d with norm / activation, ConvTranspose2d) and
+    detectron2/layers/batch_norm.py (FrozenBatchNorm2d, get_norm, LayerNorm) loaded from their files; only their imports of
+    packages that are absent here (fvcore.nn.distributed, detectron2.utils.comm/env: used by the SyncBN variants) are stubs."""
+    global _REF_LAYERS
+    if _REF_LAYERS is None:
+        import importlib.util
+        pkg = types.ModuleType("ref_d2layers")
+        pkg.__path__ = []
+        sys.modules["ref_d2layers"] = pkg
+        out = {}
+        for name in ("wrappers", "batch_norm"):
+            spec = importlib.util.spec_from_file_location("ref_d2layers." + name, REF_ROOT + "/detectron2/layers/%s.py" % name)
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules["ref_d2layers." + name] = mod
+            spec.loader.exec_module(mod)
+            out[name] = mod
+        _REF_LAYERS = out
+    return _REF_LAYERS
+
+
 def _populate(m):
     n = m.__name__
     if n == "detectron2.layers":
-        m.Conv2d = _D2Conv2d
-        m.ConvTranspose2d = nn.ConvTranspose2d
+        ref = ref_d2_layers()
+        m.Conv2d = ref["wrappers"].Conv2d
+        m.ConvTranspose2d = ref["wrappers"].ConvTranspose2d
         m.ShapeSpec = ShapeSpec
-        m.get_norm = _get_norm
+        m.get_norm = ref["batch_norm"].get_norm
+        m.FrozenBatchNorm2d = ref["batch_norm"].FrozenBatchNorm2d
         m.CNNBlockBase = _CNNBlockBase
     elif n == "detectron2.layers.batch_norm":
-        m.get_norm = _get_norm
+        m.get_norm = ref_d2_layers()["batch_norm"].get_norm
+    elif n == "fvcore.nn.distributed":
+        m.differentiable_all_reduce = None               # SyncBN only
+    elif n == "detectron2.utils.env":
+        m.TORCH_VERSION = tuple(int(x) for x in torch.__version__.split(".")[:2])
+    elif n == "detectron2.utils":
+        m.comm = importlib.import_module("detectron2.utils.comm")
+        m.env = importlib.import_module("detectron2.utils.env")
     elif n == "detectron2.modeling":
         m.BACKBONE_REGISTRY = _Registry()
         m.SEM_SEG_HEADS_REGISTRY = _Registry()

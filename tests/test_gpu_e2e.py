@@ -33,7 +33,8 @@ def build(precision, fixture="e2e_tiny"):
 
 def inputs(g, task):
     imgs = _synth.synth_images([tuple(s) for s in g.meta["sizes"]], seed=73)
-    ids, mask, pmap = _synth.synth_token_ids(2, g.meta[task]["n_classes"], 64, seed=74)
+    ids, mask, pmap = _synth.synth_token_ids(2, g.meta[task]["n_classes"], g.meta[task].get("max_len", 64), seed=74,
+                                             pad_to=g.meta[task].get("pad_to"))
     return [{"image": im, "task": task, "input_ids": ids[i], "attention_mask": mask[i],
              "positive_map_label_to_token": pmap} for i, im in enumerate(imgs)]
 
@@ -48,6 +49,23 @@ def test_e2e_tiny_parity_policy(task):
     print("parity policy %s: " % task + " ".join("%s=%.1e" % kv for kv in errs.items()))
     for k in KEYS:
         assert errs[k] < 1e-3, (k, errs[k])
+
+
+@pytest.mark.parametrize("policy,tol", [("parity", 1e-3), ("fast", 6e-3)])
+def test_e2e_long_prompt(policy, tol):
+    """BASELINE configs[3]-style prompt inside the FULL path: 815 tokens go through BertEncoder's > 512 chunker
+    (bert_model.py:61-135), are padded to 896 (PAD_MAX), and the fusion / class-logit kernels run over L = 896 with a
+    half-masked tail; against the reference's own coco_inference on the same inputs."""
+    from hipie_amd.config import Precision
+    g, model = build(getattr(Precision, policy)(), "e2e_long_tiny")
+    model.pin_topk(g["detection_topk_fg"], g["detection_topk_md"])
+    batch = inputs(g, "detection")
+    assert batch[0]["input_ids"].shape[0] == 896 and int(batch[0]["attention_mask"].sum()) > 512
+    out = model.forward_raw(batch)
+    errs = {k: rel_err(g.like("detection_" + k, out[k].float().cpu()), g["detection_" + k]) for k in KEYS}
+    print("long prompt, %s policy: " % policy + " ".join("%s=%.1e" % kv for kv in errs.items()))
+    for k in KEYS:
+        assert errs[k] < tol, (k, errs[k])
 
 
 def test_e2e_tiny_free_topk_overlap():

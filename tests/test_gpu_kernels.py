@@ -117,6 +117,24 @@ def test_mask_einsum(prec, tol, shape):
         assert rel_err(got16, want) < 8e-3
 
 
+@pytest.mark.parametrize("dt,split,tol", [(torch.float16, True, 6e-4), (torch.float16, False, 1e-3), (torch.bfloat16, True, 4e-3)])
+@pytest.mark.parametrize("shape", [(2, 300, 256, 64, 64), (1, 37, 64, 24, 40), (1, 320, 32, 8, 8), (1, 5, 16, 2, 4)])
+def test_mask_einsum16(dt, split, tol, shape):
+    """hipie_mask_einsum16 (16-bit features, transposed product, 16-byte stores) vs the fp32 einsum of the SAME 16-bit-rounded
+    features: the residual is the rounding of the embedding (hi + lo: ~2^-22, hi only: 2^-12) and of the 16-bit output."""
+    from hipie_amd import ops
+    B, Q, C, H, W = shape
+    gen = torch.Generator().manual_seed(Q + C)
+    emb = torch.randn(B, Q, C, generator=gen)
+    feat = torch.randn(B, C, H, W, generator=gen).to(dt)
+    want = torch.einsum("bqc,bchw->bqhw", emb, feat.float())
+    got = ops.mask_einsum16(emb.to(DEV), feat.to(DEV), split=split)
+    assert got.dtype == dt and got.shape == want.shape
+    assert rel_err(got.float().cpu(), want) < tol
+    got32 = ops.mask_einsum16(emb.to(DEV), feat.to(DEV), split=split, out_dtype=torch.float32)
+    assert rel_err(got32.cpu(), want) < (3e-6 if split and dt == torch.float16 else 1e-4 if split else tol)
+
+
 @pytest.mark.parametrize("name", ["sq", "rect"])
 def test_dynamic_mask(name):
     from hipie_amd import ops
@@ -203,7 +221,7 @@ def _fold_rel(qkv32, tab_h32, tab_w32, heads, hd, dt):
 
 @pytest.mark.parametrize("dt,fast,tol_same,tol_gold", [(torch.float16, False, 1e-3, 2e-3), (torch.float16, True, 1.5e-3, 2e-3),
                                                         (torch.bfloat16, True, 8e-3, 2e-2)])
-@pytest.mark.parametrize("name", ["window14", "global16", "global64", "global_rect"])
+@pytest.mark.parametrize("name", ["window14", "global16", "global64", "global_rect", "global84"])
 def test_vit_attention_rel(name, dt, fast, tol_same, tol_gold):
     """hipie_vit_attn_rel (bias computed in the kernel, pre-scaled q, two key rows per tile for the 14x14 windows) on the
     reference-generated cases: windowed 14x14, a 16x16 grid with interpolated tables, the real 64x64 grid, a 12x20 grid

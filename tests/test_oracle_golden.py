@@ -45,7 +45,7 @@ def vit_attn_case(g, name):
     return c, sd, x
 
 
-@pytest.mark.parametrize("name", ["window14", "global16", "global64", "global_rect"])
+@pytest.mark.parametrize("name", ["window14", "global16", "global64", "global_rect", "global84"])
 def test_vit_attention(name):
     g = Golden("vit_attn")
     c, sd, x = vit_attn_case(g, name)
@@ -114,7 +114,8 @@ def e2e_inputs(g, task):
     cfg = g.meta["cfg"]
     sd = _synth.synth_full_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()})
     imgs = _synth.synth_images([tuple(s) for s in g.meta["sizes"]], seed=73)
-    ids, mask, pmap = _synth.synth_token_ids(2, g.meta[task]["n_classes"], 64, seed=74)
+    ids, mask, pmap = _synth.synth_token_ids(2, g.meta[task]["n_classes"], g.meta[task].get("max_len", 64), seed=74,
+                                             pad_to=g.meta[task].get("pad_to"))
     return cfg, sd, imgs, ids, mask
 
 
@@ -136,6 +137,18 @@ def test_e2e_tiny(task):
     free = om.coco_inference(imgs, lang, sd, cfg, task=task)
     assert torch.equal(free["topk_fg"], g[task + "_topk_fg"])
     assert torch.equal(free["topk_md"], g[task + "_topk_md"])
+
+
+def test_e2e_long_prompt():
+    """BASELINE configs[3]-style prompt through the full path: 815 tokens (BertEncoder's > 512 chunker) padded to 896."""
+    g = Golden("e2e_long_tiny")
+    cfg, sd, imgs, ids, mask = e2e_inputs(g, "detection")
+    assert ids.shape[1] == 896 and int(mask.sum(1).max()) > 512
+    lang = om.bert_encoder(ids, mask, sd, "text_encoder.body.model.", cfg)
+    assert rel_err(g.like("detection_lang_hidden", lang["hidden"]), g["detection_lang_hidden"]) < 5e-5
+    out = om.coco_inference(imgs, lang, sd, cfg, task="detection", topk_fg=g["detection_topk_fg"], topk_md=g["detection_topk_md"])
+    for k in E2E_KEYS:
+        assert rel_err(g.like("detection_" + k, out[k]), g["detection_" + k]) < 2e-4, k
 
 
 def test_e2e_r50_tiny():

@@ -33,6 +33,13 @@ def main():
         by = feat.numel() * 4 + emb.numel() * 4 + B * Q * H * H * (4 if od == torch.float32 else 2)
         print("mask_einsum precision %d out %s: %.3f ms  %.2f TB/s algorithmic  %.0f TFLOP/s" % (
             prec, str(od).split(".")[-1], t, by / t / 1e9, 2.0 * B * Q * C * H * H / t / 1e9))
+    for dt in (torch.float16, torch.bfloat16):
+        f16 = feat.to(dt)
+        for split in (True, False):
+            t = bench(lambda: ops.mask_einsum16(emb, f16, split=split))
+            by = f16.numel() * 2 + emb.numel() * 2 * (2 if split else 1) + B * Q * H * H * 2
+            print("mask_einsum16 %s split=%d: %.3f ms  %.2f TB/s algorithmic  %.0f TFLOP/s" % (
+                str(dt).split(".")[-1], split, t, by / t / 1e9, 2.0 * B * Q * C * H * H / t / 1e9))
     nq = 910
     feats = torch.randn(B, 8, 128, 128, generator=g).to(dev)
     refs = (torch.rand(B * nq, 2, generator=g) * 1024).to(dev)
