@@ -27,7 +27,7 @@ SIGNATURES = {
     "hipie_vit_attn_rel": [c_p, c_p, c_p, c_p] + [c_i] * 7 + [c_p],
     "hipie_bi_xattn": [c_p, c_p, c_p, c_p, c_p, c_p, c_p] + [c_i] * 5 + [c_f, c_i, c_p],
     "hipie_mask_einsum": [c_p, c_p, c_p] + [c_i] * 6 + [c_p],
-    "hipie_mask_einsum16": [c_p, c_p, c_p, c_p] + [c_i] * 6 + [c_p],
+    "hipie_mask_einsum16": [c_p, c_p, c_p, c_p, c_p] + [c_i] * 6 + [c_p],
     "hipie_dynamic_mask": [c_p, c_p, c_p, c_p] + [c_i] * 7 + [c_p],
     "hipie_vit_relpos": [c_p, c_p, c_p, c_p, c_p] + [c_i] * 6 + [c_p],
     "hipie_add_layernorm": [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_i, c_i, c_i, c_p],
@@ -35,6 +35,8 @@ SIGNATURES = {
     "hipie_batched_nms": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p],
     "hipie_mask_finalize": [c_p, c_i, c_p] + [c_i] * 8 + [c_f, c_p, c_p],
     "hipie_sem_pan": [c_p] * 8 + [c_i] * 11 + [c_p],
+    "hipie_sine_embed": [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_f, c_i, c_p],
+    "hipie_box_refine": [c_p, c_p, c_p, c_l, c_f, c_i, c_p],
     "hipie_selftest": [c_i, c_p, c_p, c_p, c_p],
 }
 

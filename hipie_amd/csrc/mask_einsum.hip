@@ -206,7 +206,8 @@ static int dispatch_me(const float* e, const float* f, void* out, int B, int Q, 
 // Workgroup = 8 waves = 256 pixels x 320 queries: wave w owns pixel group w >> 1 (64 pixels) and query blocks 5 (w & 1) ..
 template <typename T, typename OutT, bool LO, int ABL>
 __global__ __launch_bounds__(512, 2) void mask_einsum16_kernel(const T* __restrict__ ehi, const T* __restrict__ elo,
-                                                               const T* __restrict__ feats, OutT* __restrict__ out, int Q, int C, int P) {
+                                                               const T* __restrict__ feats, const float* __restrict__ row_bias,
+                                                               OutT* __restrict__ out, int Q, int C, int P) {
   typedef typename Mfma32<T>::frag frag;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   // embed k-chunk (16 channels of all 320 query rows, hi and lo parts) staged in LDS once per workgroup and k-step, double
@@ -316,6 +317,7 @@ __global__ __launch_bounds__(512, 2) void mask_einsum16_kernel(const T* __restri
     if (q >= Q) continue;
     if (ABL == 2 && acc[i][0][0] != 12345.f) continue;        // timing ablation: no stores
     OutT* orow = O + (long)q * P + p0;
+    const float rb = row_bias ? row_bias[(long)b * Q + q] : 0.f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const long px = p0 + 16 * g + 8 * hi;
@@ -324,15 +326,15 @@ __global__ __launch_bounds__(512, 2) void mask_einsum16_kernel(const T* __restri
         o8 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[2 * e] = elem<OutT>::from_f32(acc[i][0][4 * g + e]);
-          v[2 * e + 1] = elem<OutT>::from_f32(acc[i][1][4 * g + e]);
+          v[2 * e] = elem<OutT>::from_f32(acc[i][0][4 * g + e] + rb);
+          v[2 * e + 1] = elem<OutT>::from_f32(acc[i][1][4 * g + e] + rb);
         }
         *reinterpret_cast<o8*>(orow + 16 * g + 8 * hi) = v;
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          if (px + 2 * e < P) orow[16 * g + 8 * hi + 2 * e] = elem<OutT>::from_f32(acc[i][0][4 * g + e]);
-          if (px + 2 * e + 1 < P) orow[16 * g + 8 * hi + 2 * e + 1] = elem<OutT>::from_f32(acc[i][1][4 * g + e]);
+          if (px + 2 * e < P) orow[16 * g + 8 * hi + 2 * e] = elem<OutT>::from_f32(acc[i][0][4 * g + e] + rb);
+          if (px + 2 * e + 1 < P) orow[16 * g + 8 * hi + 2 * e + 1] = elem<OutT>::from_f32(acc[i][1][4 * g + e] + rb);
         }
       }
     }
@@ -340,17 +342,17 @@ __global__ __launch_bounds__(512, 2) void mask_einsum16_kernel(const T* __restri
 }
 
 template <typename T, typename OutT>
-static int launch_me16(const void* eh, const void* el, const void* f, void* out, int B, int Q, int C, int P, hipStream_t st) {
+static int launch_me16(const void* eh, const void* el, const void* f, const float* rb, void* out, int B, int Q, int C, int P, hipStream_t st) {
   dim3 grid((P + 255) / 256, B);
 #ifdef HIPIE_VA_ABLATIONS
   { const char* e = getenv("HIPIE_ME_ABL"); const int a = e ? atoi(e) : 0;
-    if (a == 1) { hipLaunchKernelGGL((mask_einsum16_kernel<T, OutT, false, 1>), grid, dim3(512), 0, st, (const T*)eh, (const T*)el, (const T*)f, (OutT*)out, Q, C, P); return check_launch("me16"); }
-    if (a == 2) { hipLaunchKernelGGL((mask_einsum16_kernel<T, OutT, false, 2>), grid, dim3(512), 0, st, (const T*)eh, (const T*)el, (const T*)f, (OutT*)out, Q, C, P); return check_launch("me16"); } }
+    if (a == 1) { hipLaunchKernelGGL((mask_einsum16_kernel<T, OutT, false, 1>), grid, dim3(512), 0, st, (const T*)eh, (const T*)el, (const T*)f, rb, (OutT*)out, Q, C, P); return check_launch("me16"); }
+    if (a == 2) { hipLaunchKernelGGL((mask_einsum16_kernel<T, OutT, false, 2>), grid, dim3(512), 0, st, (const T*)eh, (const T*)el, (const T*)f, rb, (OutT*)out, Q, C, P); return check_launch("me16"); } }
 #endif
   if (el != nullptr)
-    hipLaunchKernelGGL((mask_einsum16_kernel<T, OutT, true, 0>), grid, dim3(512), 0, st, (const T*)eh, (const T*)el, (const T*)f, (OutT*)out, Q, C, P);
+    hipLaunchKernelGGL((mask_einsum16_kernel<T, OutT, true, 0>), grid, dim3(512), 0, st, (const T*)eh, (const T*)el, (const T*)f, rb, (OutT*)out, Q, C, P);
   else
-    hipLaunchKernelGGL((mask_einsum16_kernel<T, OutT, false, 0>), grid, dim3(512), 0, st, (const T*)eh, (const T*)el, (const T*)f, (OutT*)out, Q, C, P);
+    hipLaunchKernelGGL((mask_einsum16_kernel<T, OutT, false, 0>), grid, dim3(512), 0, st, (const T*)eh, (const T*)el, (const T*)f, rb, (OutT*)out, Q, C, P);
   return check_launch("mask_einsum16");
 }
 
@@ -372,8 +374,8 @@ extern "C" int hipie_mask_einsum(const float* embed, const float* feats, void* o
   }
 }
 
-extern "C" int hipie_mask_einsum16(const void* embed_hi, const void* embed_lo, const void* feats, void* out, int B, int Q, int C,
-                                   int HW, int dtype, int out_dtype, void* stream) {
+extern "C" int hipie_mask_einsum16(const void* embed_hi, const void* embed_lo, const void* feats, const float* row_bias, void* out,
+                                   int B, int Q, int C, int HW, int dtype, int out_dtype, void* stream) {
   using namespace hipie;
   HIPIE_REQUIRE(embed_hi && feats && out, "mask_einsum16: null pointer");
   HIPIE_REQUIRE(B >= 0 && Q > 0 && Q <= 320 && C > 0 && HW > 0, "mask_einsum16: bad shape (Q=%d must be in 1..320)", Q);
@@ -383,12 +385,12 @@ extern "C" int hipie_mask_einsum16(const void* embed_hi, const void* embed_lo, c
   if (B == 0) return HIPIE_OK;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == HIPIE_F16) {
-    if (out_dtype == HIPIE_F16) { HIPIE_REQUIRE(HW % 8 == 0, "mask_einsum16: HW %% 8"); return launch_me16<f16_t, f16_t>(embed_hi, embed_lo, feats, out, B, Q, C, HW, st); }
-    return launch_me16<f16_t, float>(embed_hi, embed_lo, feats, out, B, Q, C, HW, st);
+    if (out_dtype == HIPIE_F16) { HIPIE_REQUIRE(HW % 8 == 0, "mask_einsum16: HW %% 8"); return launch_me16<f16_t, f16_t>(embed_hi, embed_lo, feats, row_bias, out, B, Q, C, HW, st); }
+    return launch_me16<f16_t, float>(embed_hi, embed_lo, feats, row_bias, out, B, Q, C, HW, st);
   }
   if (dtype == HIPIE_BF16) {
-    if (out_dtype == HIPIE_BF16) { HIPIE_REQUIRE(HW % 8 == 0, "mask_einsum16: HW %% 8"); return launch_me16<bf16_t, bf16_t>(embed_hi, embed_lo, feats, out, B, Q, C, HW, st); }
-    return launch_me16<bf16_t, float>(embed_hi, embed_lo, feats, out, B, Q, C, HW, st);
+    if (out_dtype == HIPIE_BF16) { HIPIE_REQUIRE(HW % 8 == 0, "mask_einsum16: HW %% 8"); return launch_me16<bf16_t, bf16_t>(embed_hi, embed_lo, feats, row_bias, out, B, Q, C, HW, st); }
+    return launch_me16<bf16_t, float>(embed_hi, embed_lo, feats, row_bias, out, B, Q, C, HW, st);
   }
   return set_err(HIPIE_EINVAL, "mask_einsum16: dtype must be f16 or bf16 (got %d)", dtype);
 }

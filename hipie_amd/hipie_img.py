@@ -109,10 +109,12 @@ class HIPIE_IMG(nn.Module):
             bb.cast_weights()
         hd, ad = self.precision.head, self.precision.act
         cast_head(self.detr.detr.transformer.encoder, hd, ad)        # the Nv-token streams (21760 tokens / image)
-        cast_head(self.detr.detr.transformer.decoder.layers, hd)     # query-sized tensors stay fp32
+        cast_head(self.detr.detr.transformer.decoder.layers, hd, ad)       # the query stream lives in `act` ...
+        cast_head(self.detr.detr.transformer.decoder.ref_point_head, hd)      # ... query_pos, the box / class / IoU heads stay fp32
         cast_head(self.detr.detr.input_proj, hd, ad)
         cast_head(self.detr.mask_dino.pixel_decoder, hd, ad)
-        cast_head(self.detr.mask_dino.predictor.decoder.layers, hd)
+        cast_head(self.detr.mask_dino.predictor.decoder.layers, hd, ad)
+        cast_head(self.detr.mask_dino.predictor.decoder.ref_point_head, hd)
         cast_head(self.detr.mask_head, hd, ad)
         return self
 

@@ -7,6 +7,7 @@ transformer_decoder/maskdino_decoder.py (MaskDINODecoder, eval path), transforme
 The branch is called with mask=None (ddetrs_dn.py:885): all-False padding masks, valid_ratio 1.
 """
 import collections
+import os
 
 import torch
 import torch.nn as nn
@@ -29,6 +30,13 @@ class NormConv2d(PConv2d):
     def forward(self, x):
         x = self.norm(super().forward(x))
         return F.relu(x) if self.relu else x
+
+
+class FoldedMaskFeatures(object):
+    """the mask_features head without its last 1x1 convolution (weight (256,256), bias (256)): `pre` (B,256,H/4,W/4) NCHW."""
+
+    def __init__(self, pre, weight, bias):
+        self.pre, self.weight, self.bias = pre, weight, bias
 
 
 class MSDeformAttnTransformerEncoder(nn.Module):
@@ -98,11 +106,17 @@ class MaskDINOEncoder(nn.Module):
         cur = self.adapter_1(f3)
         z = cur + F.interpolate(out[0], size=cur.shape[-2:], mode="bilinear", align_corners=False)
         z = self.layer_1(z)
-        mf = self.mask_features[0](z.to(self.mask_features[0].weight.dtype)).float()
-        mf = self.mask_features[3](self.mask_features[2](self.mask_features[1](mf)))
-        # NCHW, pixel fastest: the einsum's operand layout, produced once for both calls; fp32 for hipie_mask_einsum, the 16-bit
-        # activation dtype for hipie_mask_einsum16 (precision.einsum >= 3)
-        mf = (mf.to(self.precision.act) if self.precision.einsum >= 3 else mf.float()).contiguous()
+        if self.precision.einsum >= 3:
+            # 16-bit policies: stop in front of the head's last 1x1 convolution.  mask logits = emb . (W x + b) = (emb . W) . x +
+            # emb . b, so that convolution folds into the (tiny) query side of the contraction (forward_prediction_heads): no
+            # (B,256,H/4,W/4) GEMM, no fp32 round trips; x leaves NCHW (pixel fastest, the contraction's operand layout) in `act`
+            x = self.mask_features[2](self.mask_features[1](self.mask_features[0](z.to(self.mask_features[0].weight.dtype))))
+            conv = self.mask_features[3]
+            mf = FoldedMaskFeatures(x.to(self.precision.act).contiguous(), conv.weight.reshape(conv.weight.shape[0], -1), conv.bias)
+        else:
+            mf = self.mask_features[0](z.to(self.mask_features[0].weight.dtype)).float()
+            mf = self.mask_features[3](self.mask_features[2](self.mask_features[1](mf)))
+            mf = mf.float().contiguous()  # NCHW fp32, pixel fastest: hipie_mask_einsum's operand layout, produced once for both calls
         return mf, out[0], out          # mask_features (B,256,H/4,W/4), s8 level, [s8,s16,s32,s64]
 
 
@@ -149,8 +163,10 @@ class MaskDINODecoder(nn.Module):
         masks = None
         if pred_mask:
             emb = self.mask_embed(dec)
-            if self.precision.einsum >= 3:          # 16-bit features: 3 = single product, 4 = embedding split hi + lo
-                masks = ops.mask_einsum16(emb.float(), mask_features, split=self.precision.einsum == 4)
+            if isinstance(mask_features, FoldedMaskFeatures):      # 16-bit features: 3 = single product, 4 = embedding split hi + lo
+                e32 = emb.float()
+                w, b = mask_features.weight.float(), mask_features.bias.float()
+                masks = ops.mask_einsum16(e32 @ w, mask_features.pre, split=self.precision.einsum == 4, row_bias=e32 @ b)
             else:
                 masks = ops.mask_einsum(emb.float().contiguous(), mask_features, precision=self.precision.einsum,
                                         out_dtype=self.precision.act)
@@ -180,17 +196,20 @@ class MaskDINODecoder(nn.Module):
         # einsum #1 (:428): interm_outputs
         interm_cls, interm_mask = self.forward_prediction_heads(tgt, mask_features, pred_mask=self.initial_pred_masks)
         ref = ref_un.sigmoid()
-        refs, out, hs = [ref], tgt, []
+        sdt = torch.float32 if os.environ.get("HIPIE_DEC_F32", "1") == "1" else self.decoder.layers[0].linear1.out_dtype
+        wdt = self.decoder.ref_point_head.layers[0].weight.dtype
+        refs, out, hs = [ref], tgt.to(sdt), []
         for lid, layer in enumerate(self.decoder.layers):
             ref_in = ref[:, :, None] * vr2
-            query_pos = self.decoder.ref_point_head(get_sine_pos_embed(ref_in[:, :, 0, :]))
+            query_pos = self.decoder.ref_point_head(ops.sine_embed(ref_in[:, :, 0, :], out_dtype=wdt))
             out = layer(out, query_pos, ref_in, src, spatial_shapes, level_start_index, None)
-            new_ref = (self.decoder.bbox_embed[lid](out) + inverse_sigmoid(ref)).sigmoid()
-            ref = new_ref.detach()
+            new_ref = ops.box_refine(self.decoder.bbox_embed[lid](out), ref)
+            ref = new_ref
             refs.append(new_ref)
-            hs.append(self.decoder.norm(out))
+            if lid == len(self.decoder.layers) - 1:        # eval: heads on the last layer only (maskdino_decoder.py:485)
+                hs.append(self.decoder.norm(out).float())
         cls, masks = self.forward_prediction_heads(hs[-1], mask_features)                 # einsum #2 (:485)
-        boxes = (self.bbox_embed[-1](hs[-1]) + inverse_sigmoid(refs[-2])).sigmoid()       # pred_box (:357-375)
+        boxes = ops.box_refine(self.bbox_embed[-1](hs[-1]), refs[-2])                     # pred_box (:357-375)
         return {"pred_logits": cls, "pred_masks": masks, "pred_boxes": boxes,
                 "interm_outputs": {"pred_logits": interm_cls, "pred_masks": interm_mask, "pred_boxes": ref_un.sigmoid()}}
 

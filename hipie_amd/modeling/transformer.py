@@ -306,7 +306,8 @@ class BiMultiHeadAttention(nn.Module):
         B, Nv, _ = v.shape
         L = l.shape[1]
         H, hd, dt = self.num_heads, self.head_dim, self.attn_dtype
-        q = (self.v_proj(v) * self.scale).to(dt).view(B, Nv, H, hd)
+        wq, bq = self._scaled_q()                              # v_proj with the 1/sqrt(head_dim) folded in: no (B, Nv, 2048) multiply pass
+        q = F.linear(v.to(wq.dtype), wq, bq).to(dt).view(B, Nv, H, hd)
         k = self.l_proj(l).to(dt).view(B, L, H, hd)
         vv = self.values_v_proj(v).to(dt).view(B, Nv, H, hd)
         vl = self.values_l_proj(l).to(dt).view(B, L, H, hd)
@@ -314,6 +315,15 @@ class BiMultiHeadAttention(nn.Module):
             attention_mask_l = torch.ones(B, L, dtype=torch.uint8, device=v.device)
         ov, ol = ops.bi_xattn(q, k, vv, vl, attention_mask_l != 0, clamp=50000.0)
         return self.out_v_proj(ov), self.out_l_proj(ol)
+
+
+    def _scaled_q(self):
+        p = self.v_proj
+        key = tuple((t.data_ptr(), t._version, t.dtype) for t in (p.weight, p.bias))
+        if getattr(self, "_sq_key", None) != key:
+            self._sq = ((p.weight.float() * self.scale).to(p.weight.dtype), (p.bias.float() * self.scale).to(p.bias.dtype))
+            self._sq_key = key
+        return self._sq
 
 
 class BiAttentionBlockForCheckpoint(nn.Module):
@@ -434,12 +444,13 @@ class DeformableTransformerDecoderLayer(nn.Module):
         self.norm3 = PLayerNorm(d_model)
 
     def forward(self, tgt, query_pos, reference_points, src, spatial_shapes, level_start_index, src_padding_mask=None):
+        """every residual add + LayerNorm is one hipie_add_layernorm launch; the stream keeps the dtype it arrives in."""
         qk = tgt + query_pos
-        tgt = self.norm2(tgt + self.self_attn(qk, tgt))
+        tgt = _add_norm(tgt, self.self_attn(qk, tgt), self.norm2)
         tgt2 = self.cross_attn(tgt + query_pos, reference_points, src, spatial_shapes, level_start_index, src_padding_mask)
-        tgt = self.norm1(tgt + tgt2)
+        tgt = _add_norm(tgt, tgt2, self.norm1)
         tgt2 = self.linear2(self.linear1.forward_relu(tgt))
-        return self.norm3(tgt + tgt2)
+        return _add_norm(tgt, tgt2, self.norm3)
 
 
 def get_sine_pos_embed(pos_tensor, num_pos_feats=128, temperature=10000, exchange_xy=True):
@@ -469,17 +480,19 @@ class DeformableTransformerDecoder(nn.Module):
         self.class_embed = None
 
     def forward(self, tgt, reference_points, src, spatial_shapes, level_start_index, valid_ratios, src_padding_mask=None):
-        output, inter, inter_refs = tgt, [], []
+        sdt = torch.float32 if os.environ.get("HIPIE_DEC_F32", "1") == "1" else self.layers[0].linear1.out_dtype   # query stream dtype
+        output, inter, inter_refs = tgt.to(sdt), [], []
         vr2 = torch.cat([valid_ratios, valid_ratios], -1)[:, None]
+        wdt = self.ref_point_head.layers[0].weight.dtype
         for lid, layer in enumerate(self.layers):
             ref_in = reference_points[:, :, None] * vr2
-            query_pos = self.ref_point_head(get_sine_pos_embed(ref_in[:, :, 0, :]))
+            query_pos = self.ref_point_head(ops.sine_embed(ref_in[:, :, 0, :], out_dtype=wdt))      # one launch (was ~21)
             output = layer(output, query_pos, ref_in, src, spatial_shapes, level_start_index, src_padding_mask)
-            new_ref = (self.bbox_embed[lid](output) + inverse_sigmoid(reference_points)).sigmoid()
-            reference_points = new_ref.detach()
+            new_ref = ops.box_refine(self.bbox_embed[lid](output), reference_points)               # one launch (was ~8)
+            reference_points = new_ref
             inter.append(output)
             inter_refs.append(new_ref)
-        return torch.stack(inter), torch.stack(inter_refs)
+        return torch.stack(inter).float(), torch.stack(inter_refs)
 
 
 def gen_encoder_output_proposals(memory, memory_padding_mask, shapes_list, geo_key=None):

@@ -255,10 +255,10 @@ def mask_einsum(mask_embed, mask_features, precision=1, out_dtype=torch.float32)
 
 
 @_timed("mask_einsum")
-def mask_einsum16(mask_embed, mask_features, split=True, out_dtype=None):
+def mask_einsum16(mask_embed, mask_features, split=True, out_dtype=None, row_bias=None):
     """einsum("bqc,bchw->bqhw") on 16-bit features: mask_embed (B,Q,C) f32 (split here into 16-bit hi + lo parts: two MFMAs per
     product; split=False: hi only), mask_features (B,C,H,W) f16 | bf16 contiguous -> (B,Q,H,W) out_dtype (default: the feature
-    dtype).  Q <= 320."""
+    dtype); row_bias (B,Q) is added to every pixel of its query row.  Q <= 320."""
     lib = _lib.load()
     B, Q, C = mask_embed.shape
     _, _, Hh, Ww = mask_features.shape
@@ -267,8 +267,9 @@ def mask_einsum16(mask_embed, mask_features, split=True, out_dtype=None):
     hi = mask_embed.to(dt).contiguous()
     lo = (mask_embed.float() - hi.float()).to(dt).contiguous() if split else None
     out = torch.empty(B, Q, Hh, Ww, dtype=out_dtype, device=mask_embed.device)
+    rb = None if row_bias is None else _chk(row_bias.float().contiguous(), "row_bias", torch.float32)
     rc = lib.hipie_mask_einsum16(_chk(hi, "embed_hi"), None if lo is None else _chk(lo, "embed_lo"), _chk(mask_features, "mask_features"),
-                                 out.data_ptr(), B, Q, C, Hh * Ww, _DT[dt], _DT[out_dtype], _stream())
+                                 rb, out.data_ptr(), B, Q, C, Hh * Ww, _DT[dt], _DT[out_dtype], _stream())
     _lib.check(rc, "hipie_mask_einsum16")
     return out
 
@@ -396,6 +397,49 @@ def sem_pan(masks_lo, cls_all, pscore, up, crop_hw, out_hw, precision=0):
                            N, npad, C, hm, wm, int(up), int(crop_hw[0]), int(crop_hw[1]), oh, ow, int(precision), _stream())
     _lib.check(rc, "hipie_sem_pan")
     return sem, pan_idx, pan_own.bool(), area[:N]
+
+
+_DIM_T = {}
+
+
+@_timed("sine_embed")
+def sine_embed(ref, num_pos_feats=128, temperature=10000, out_dtype=torch.float32):
+    """get_sine_pos_embed(ref, exchange_xy=True): ref (..., 2|4) f32 (last-dim stride 1) -> (..., ncoord * num_pos_feats)."""
+    import math
+    lib = _lib.load()
+    nc = ref.shape[-1]
+    ref = ref.float()
+    rs = nc
+    if ref.dim() == 3 and ref.stride(-1) == 1 and ref.stride(0) == ref.shape[1] * ref.stride(1) and ref.stride(1) >= nc:
+        rs = ref.stride(1)                    # a row-strided view such as ref_in[:, :, 0, :]: read in place
+    elif not ref.is_contiguous():
+        ref = ref.contiguous()
+    key = (num_pos_feats, temperature, str(ref.device))
+    dim_t = _DIM_T.get(key)
+    if dim_t is None:
+        d = torch.arange(num_pos_feats, dtype=torch.float32, device=ref.device)
+        dim_t = (temperature ** (2 * torch.div(d, 2, rounding_mode="floor") / num_pos_feats)).contiguous()
+        _DIM_T[key] = dim_t
+    n = ref.numel() // nc
+    out = torch.empty(ref.shape[:-1] + (nc * num_pos_feats,), dtype=out_dtype, device=ref.device)
+    if not ref.is_cuda:
+        raise RuntimeError("Not implemented on the CPU (ref must be a CUDA/HIP tensor)")
+    rc = lib.hipie_sine_embed(ref.data_ptr(), dim_t.data_ptr(), out.data_ptr(), n, nc, num_pos_feats, rs,
+                              2 * math.pi, _DT[out_dtype], _stream())
+    _lib.check(rc, "hipie_sine_embed")
+    return out
+
+
+@_timed("box_refine")
+def box_refine(delta, ref, eps=1e-5):
+    """sigmoid(delta + inverse_sigmoid(ref)): delta (..., 4) f32|f16|bf16, ref (..., 4) f32 -> (..., 4) f32."""
+    lib = _lib.load()
+    delta, ref = delta.contiguous(), ref.float().contiguous()
+    out = torch.empty_like(ref)
+    rc = lib.hipie_box_refine(_chk(delta, "delta"), _chk(ref, "ref", torch.float32), out.data_ptr(), ref.numel(), float(eps),
+                              _DT[delta.dtype], _stream())
+    _lib.check(rc, "hipie_box_refine")
+    return out
 
 
 def selftest(which, a, b=None):

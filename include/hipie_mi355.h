@@ -134,10 +134,12 @@ int hipie_mask_einsum(const float* embed, const float* feats, void* out, int B, 
  * The same contraction on 16-bit features (the activation dtype of the 16-bit policies): out[b,q,p] = sum_c embed[b,q,c] *
  * feats[b,c,p] with feats (B,C,HW) `dtype` (f16 | bf16), the query embedding pre-split by the caller into embed_hi + embed_lo
  * (both (B,Q,C) `dtype`; embed_lo NULL: single product), out (B,Q,HW) `out_dtype` (= dtype, or f32).  fp32 accumulation.
+ * row_bias (B,Q) f32 or NULL is added to every pixel of a query row: with embed' = embed . W and row_bias = embed . b the last
+ * 1x1 convolution of the pixel decoder's mask_features head (maskdino_encoder.py:283-300) folds into this contraction.
  * Replaces the same torch.einsum (maskdino_decoder.py:527).  Q <= 320, C % 16 == 0, HW % 8 == 0 (HW even for f32 output).
  */
-int hipie_mask_einsum16(const void* embed_hi, const void* embed_lo, const void* feats, void* out, int B, int Q, int C, int HW,
-                        int dtype, int out_dtype, void* stream);
+int hipie_mask_einsum16(const void* embed_hi, const void* embed_lo, const void* feats, const float* row_bias, void* out, int B,
+                        int Q, int C, int HW, int dtype, int out_dtype, void* stream);
 
 /*
  * Fused CondInst dynamic mask head: relative-coordinate generation + per-instance 10->8->8->1 MLP (ReLU, ReLU, none)
@@ -248,6 +250,24 @@ int hipie_mask_finalize(const void* masks, int dtype, const int32_t* qidx, int n
 int hipie_sem_pan(const float* masks, const void* cls_hi, const void* cls_lo, const float* pscore, float* sem,
                   int32_t* pan_idx, uint8_t* pan_own, int32_t* area, int N, int Npad, int C, int hm, int wm, int up,
                   int crop_h, int crop_w, int out_h, int out_w, int precision, void* stream);
+
+/*
+ * Sine embedding of reference points / boxes: the query_pos input of both DINO decoders.
+ * Replaces: get_sine_pos_embed (models/deformable_detr/deformable_transformer_dino.py:636-670) == gen_sineembed_for_position
+ *           (models/maskdino/utils/utils.py:74-100), ~21 eager launches per decoder layer.
+ *   ref (n, ref_stride >= n_coord) f32, n_coord 2 | 4 coordinates (x, y[, w, h]);  dim_t (num_pos_feats) f32 = T^(2*floor(i/2)/F)
+ *   (computed by the caller with the reference's formula);  out (n, n_coord * num_pos_feats) `out_dtype`, coordinate blocks in
+ *   the reference's order (y, x, w, h);  value = sin | cos (even | odd feature) of ref * scale / dim_t, fp32.
+ */
+int hipie_sine_embed(const float* ref, const float* dim_t, void* out, int64_t n, int n_coord, int num_pos_feats, int ref_stride,
+                     float scale, int out_dtype, void* stream);
+
+/*
+ * Iterative box refinement: out = sigmoid(delta + inverse_sigmoid(ref)), inverse_sigmoid with the reference's clamps (eps 1e-5).
+ * Replaces: deformable_transformer_dino.py:502-520 / dino_decoder.py:150-160 + util/misc.py:493-497 (8 eager launches per layer).
+ *   delta (n) `delta_dtype`, ref (n) f32, out (n) f32 (n = boxes * 4).
+ */
+int hipie_box_refine(const void* delta, const float* ref, float* out, int64_t n, float eps, int delta_dtype, void* stream);
 
 /* device-side self-test helpers used by tests/ to pin the MFMA / LDS-transpose lane layouts this library assumes.
  *   which 0: D = A(32x16) . B(16x32) with v_mfma_f32_32x32x16_bf16, operands loaded with the layouts documented in

@@ -133,6 +133,9 @@ def test_mask_einsum16(dt, split, tol, shape):
     assert rel_err(got.float().cpu(), want) < tol
     got32 = ops.mask_einsum16(emb.to(DEV), feat.to(DEV), split=split, out_dtype=torch.float32)
     assert rel_err(got32.cpu(), want) < (3e-6 if split and dt == torch.float16 else 1e-4 if split else tol)
+    rb = torch.randn(B, Q, generator=gen)                             # the folded bias of the mask_features head's last conv
+    gotb = ops.mask_einsum16(emb.to(DEV), feat.to(DEV), split=split, out_dtype=torch.float32, row_bias=rb.to(DEV))
+    assert rel_err(gotb.cpu(), want + rb[:, :, None, None]) < (3e-6 if split and dt == torch.float16 else 1e-4 if split else tol)
 
 
 @pytest.mark.parametrize("name", ["sq", "rect"])
@@ -488,6 +491,27 @@ def test_vit_attention_full_grid_against_materialised_scores():
     bh, bw = ops.vit_relpos(qkv, th, tw, (gh, gw), heads)
     unfused = ops.vit_attn(qkv, bh, bw, (gh, gw), heads, hd ** -0.5).float()
     assert rel_err(unfused.cpu(), want.cpu()) < 1e-3
+
+
+def test_glue_sine_embed_and_box_refine():
+    """hipie_sine_embed / hipie_box_refine against the product's own eager restatements of get_sine_pos_embed
+    (deformable_transformer_dino.py:636-670) and of sigmoid(delta + inverse_sigmoid(ref)), fp32, incl. a row-strided view."""
+    from hipie_amd import ops
+    from hipie_amd.modeling.transformer import get_sine_pos_embed, inverse_sigmoid
+    gen = torch.Generator().manual_seed(5)
+    ref = torch.rand(3, 37, 4, 4, generator=gen).to(DEV)
+    for view in (ref[:, :, 0, :], ref[:, :, 0, :].contiguous(), ref[:, :, 0, :2].contiguous()):
+        want = get_sine_pos_embed(view)
+        got = ops.sine_embed(view)
+        assert got.shape == want.shape and rel_err(got.cpu(), want.cpu()) < 2e-6
+    half = ops.sine_embed(ref[:, :, 0, :], out_dtype=torch.float16)
+    assert rel_err(half.float().cpu(), get_sine_pos_embed(ref[:, :, 0, :]).cpu()) < 6e-4
+    r = torch.rand(2, 50, 4, generator=gen)
+    r[0, 0] = torch.tensor([0.0, 1.0, 1e-7, 1.0 - 1e-7])                       # the clamps of inverse_sigmoid
+    d = torch.randn(2, 50, 4, generator=gen)
+    want = (d + inverse_sigmoid(r)).sigmoid()
+    assert rel_err(ops.box_refine(d.to(DEV), r.to(DEV)).cpu(), want) < 2e-6
+    assert rel_err(ops.box_refine(d.half().to(DEV), r.to(DEV)).cpu(), (d.half().float() + inverse_sigmoid(r)).sigmoid()) < 2e-6
 
 
 def test_empty_inputs_are_handled():
