@@ -37,9 +37,13 @@ def synth_batch(cfg, batch, size, n_classes, L, device, seed=0, task="detection"
     ids = torch.zeros(L, dtype=torch.long)
     mask = torch.zeros(L, dtype=torch.long)
     row, pmap = [101], {}
+    # 80 classes: the COCO caption (1-3 tokens a name, 194 tokens; a longer L is PAD_MAX padding).  Other vocabularies
+    # (BASELINE configs[3]/[4]: ADE-150 at L~815, LVIS-1203 cut at MAX_QUERY_LEN 4096) get names sized so the caption fills L.
+    cap = min(L, 194) if n_classes == 80 else L
+    kmean = 2 if n_classes == 80 else max(1, round((L - 2) / n_classes) - 1)
     for c in range(n_classes):
-        k = int(torch.randint(1, 4, (1,), generator=g))
-        if len(row) + k + 2 > min(L, 194):          # the caption itself is the 80-class one; a longer L is padding
+        k = int(torch.randint(max(1, kmean - 1), kmean + 2, (1,), generator=g))
+        if len(row) + k + 2 > cap:
             break
         pmap[c + 1] = list(range(len(row), len(row) + k))
         row += torch.randint(1996, 29000, (k,), generator=g).tolist() + [1012]
@@ -170,6 +174,9 @@ def main():
                     help="r50 = BASELINE configs[1] (use --batch 4); no ViT attention kernel there: roofline fields are null")
     ap.add_argument("--text-len", type=int, default=194, help="token length of the class prompt: 194 = the 80-class caption "
                     "as is (PAD_MAX off); 4096 = the shipped eval setting that pads every caption to 4096 tokens (SURVEY 8d)")
+    ap.add_argument("--classes", type=int, default=80, help="vocabulary size of the class prompt: 80 (configs[2]); "
+                    "--classes 150 --text-len 815 --size 1344 is the ADE-150 shape of configs[3] (chunked BERT, 84x84 grid), "
+                    "--classes 1203 --text-len 4096 --size 1344 the LVIS shape of configs[4]")
     ap.add_argument("--task", default="detection", choices=["detection", "grounding"],
                     help="grounding = the referring-expression call of BASELINE configs[2] (one ~12-token expression)")
     ap.add_argument("--precision", default="fast", choices=["fast", "parity", "bf16", "default"])
@@ -234,7 +241,7 @@ def main():
     model = HIPIE_IMG(cfg, prec, device=dev)
     randomize_degenerate_inits(model)
     model.finalize()
-    L, n_classes = args.text_len, 80
+    L, n_classes = args.text_len, args.classes
     batch = synth_batch(cfg, args.batch, args.size, n_classes, L, dev, seed=rank, task=args.task)
 
     def local_step():
@@ -367,19 +374,22 @@ def main():
         flops = 4.0 * N * N * cfg.vit_embed_dim * args.batch          # QK^T + PV of one global block, all heads, this batch
         ach = flops / (kern_ms * 1e-3) / 1e12 if kern_ms else None
         line = {
-            "metric": "images/sec @1024x1024 ViT-H bs=8 (single-image inference hot path: box, class and mask logits)",
+            "metric": "images/sec @%dx%d %s bs=%d (single-image inference hot path: box, class and mask logits)"
+                      % (args.size, args.size, {"vit_huge": "ViT-H", "vit_large": "ViT-L", "vit_base": "ViT-B", "r50": "R50"}[args.model], args.batch),
             "value": round(images / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fast": "f16", "parity": "f32+f16attn", "bf16": "bf16", "default": "bf16+f32head"}[args.precision],
             "data": "synthetic (uint8-valued random images resident in HBM, synthetic BERT token ids, random-init weights)",
-            "config": {"workload": "BASELINE.json configs[2]: %s, %dx%d, batch %d per GPU, %d class prompts (L=%d), detection"
-                                   % (args.model, args.size, args.size, args.batch, n_classes, L),
+            "config": {"workload": "BASELINE.json configs[%s]: %s, %dx%d, batch %d per GPU, %d class prompts (L=%d), detection"
+                                   % ({80: "1" if args.model == "r50" else "2", 150: "3", 1203: "4"}.get(n_classes, "-"),
+                                      args.model, args.size, args.size, args.batch, n_classes, L),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "precision_policy": args.precision,
                        "launch": "hipGraph replay" if graph is not None else "eager",
                        "constants": "weight- and geometry-only tensors (rel-pos tables, position embeddings, valid ratios) are "
                                     "built once; nothing that depends on image or text content is cached"},
-            "roofline": {"bound": "mfma", "kernel": "vit_attn_sp_kernel<%s,hd80,NB2,8 waves,in-kernel rel-pos bias> (ViT global attention, %d launches timed)"
-                                                    % (str(prec.attn).split(".")[-1], kern_n),
+            "roofline": {"bound": "mfma", "kernel": "%s<%s,hd%d,%s,8 waves,in-kernel rel-pos bias> (ViT global attention, %d launches timed)"
+                                                    % (("vit_attn_sp_kernel", "vit_attn_kernel")[args.size // 16 > 64], str(prec.attn).split(".")[-1],
+                                                       cfg.vit_embed_dim // cfg.vit_heads, ("NB2", "NB3")[args.size // 16 > 64], kern_n),
                          "achieved": None if ach is None else round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": None if ach is None else round(ach / 2500.0, 4), "traffic": traffic,
                          "traffic_note": "bytes per launch, rocprofv3 PMC FETCH_SIZE (x2, guide correction) + WRITE_SIZE, separate passes: profiles/r02_pmc_attention.md",
@@ -389,7 +399,7 @@ def main():
             "parity_err": parity_err,
             "parity_policy": other,
         }
-        if not args.no_cpu_baseline and world == 1 and args.model != "r50":   # rank 0 at N = 1 only (bounded ~20 s CPU sample)
+        if not args.no_cpu_baseline and world == 1 and args.model != "r50" and args.classes == 80:   # rank 0 at N = 1 only (bounded ~20 s CPU sample)
             import subprocess
             try:                        # separate process, hard time bound: the baseline must never break the measured line
                 env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")

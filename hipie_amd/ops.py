@@ -366,25 +366,25 @@ def mask_finalize(masks, qidx, up, crop_hw, out_hw, threshold):
     return out
 
 
+SEM_PAN_CLASSES = 160          # classes per launch of hipie_sem_pan (register budget of its accumulators); more are tiled
+
+
 def sem_pan_ok(n_queries, n_classes):
-    return 0 < n_classes <= 160 and 0 < n_queries <= 8192
+    return 0 < n_classes and 0 < n_queries <= 8192
 
 
 @_timed("sem_pan")
 def sem_pan(masks_lo, cls_all, pscore, up, crop_hw, out_hw, precision=0):
     """fused semantic + panoptic maps of one image.  masks_lo (N,hm,wm) f32 stride-`up` logits, cls_all (N,C) f32 class
     probabilities, pscore (N) f32 (score of kept queries, <= 0 otherwise) ->
-    sem (C,oh,ow) f32, pan_idx (oh,ow) int32 (-1: no kept query), pan_own (oh,ow) bool, area (N) int32."""
+    sem (C,oh,ow) f32, pan_idx (oh,ow) int32 (-1: no kept query), pan_own (oh,ow) bool, area (N) int32.
+    More than SEM_PAN_CLASSES classes (ADE-847, LVIS-1203: BASELINE configs[3]/[4]) run as class tiles of one launch each;
+    the panoptic outputs do not depend on the classes and are taken from the first tile."""
     lib = _lib.load()
     N, C = cls_all.shape
     _, hm, wm = masks_lo.shape
     dev = masks_lo.device
     npad = (N + 15) // 16 * 16
-    cp = 32 if C <= 32 else 96 if C <= 96 else 160
-    cls_t = torch.zeros(cp, npad, dtype=torch.float32, device=dev)
-    cls_t[:C, :N] = cls_all.t()
-    hi = cls_t.to(torch.bfloat16)
-    lo = (cls_t - hi.float()).to(torch.bfloat16) if precision == 0 else None
     ps = torch.full((npad,), -1.0, dtype=torch.float32, device=dev)
     ps[:N] = pscore
     oh, ow = int(out_hw[0]), int(out_hw[1])
@@ -392,10 +392,25 @@ def sem_pan(masks_lo, cls_all, pscore, up, crop_hw, out_hw, precision=0):
     pan_idx = torch.empty(oh, ow, dtype=torch.int32, device=dev)
     pan_own = torch.empty(oh, ow, dtype=torch.uint8, device=dev)
     area = torch.zeros(npad, dtype=torch.int32, device=dev)
-    rc = lib.hipie_sem_pan(_chk(masks_lo, "masks", torch.float32), hi.data_ptr(), None if lo is None else lo.data_ptr(),
-                           ps.data_ptr(), sem.data_ptr(), pan_idx.data_ptr(), pan_own.data_ptr(), area.data_ptr(),
-                           N, npad, C, hm, wm, int(up), int(crop_hw[0]), int(crop_hw[1]), oh, ow, int(precision), _stream())
-    _lib.check(rc, "hipie_sem_pan")
+    masks_ptr = _chk(masks_lo, "masks", torch.float32)
+    spare = None
+    for c0 in range(0, C, SEM_PAN_CLASSES):
+        cn = min(SEM_PAN_CLASSES, C - c0)
+        cp = 32 if cn <= 32 else 96 if cn <= 96 else 160
+        cls_t = torch.zeros(cp, npad, dtype=torch.float32, device=dev)
+        cls_t[:cn, :N] = cls_all[:, c0:c0 + cn].t()
+        hi = cls_t.to(torch.bfloat16)
+        lo = (cls_t - hi.float()).to(torch.bfloat16) if precision == 0 else None
+        if c0 == 0:
+            outs = (pan_idx, pan_own, area)
+        else:
+            if spare is None:
+                spare = (torch.empty_like(pan_idx), torch.empty_like(pan_own), torch.zeros_like(area))
+            outs = spare
+        rc = lib.hipie_sem_pan(masks_ptr, hi.data_ptr(), None if lo is None else lo.data_ptr(),
+                               ps.data_ptr(), sem[c0:c0 + cn].data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
+                               N, npad, cn, hm, wm, int(up), int(crop_hw[0]), int(crop_hw[1]), oh, ow, int(precision), _stream())
+        _lib.check(rc, "hipie_sem_pan")
     return sem, pan_idx, pan_own.bool(), area[:N]
 
 

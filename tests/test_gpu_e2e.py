@@ -167,3 +167,37 @@ def test_e2e_batch_items_are_independent():
         for k in KEYS:
             assert rel_err(one[k].float().cpu(), full[k][i:i + 1].float().cpu()) < 1e-3, (k, i)
     model.pin_topk(None, None)
+
+
+@pytest.mark.parametrize("n_classes,L", [(150, 815), (1203, 4096)])
+def test_full_size_open_vocabulary_configs(n_classes, L):
+    """BASELINE.json configs[3] / [4] at full size: ViT-H, 1344x1344 (84x84 global-attention grid, the NB=3 kernel),
+    ADE-150 caption of ~815 tokens / LVIS-1203 caption cut at MAX_QUERY_LEN 4096 (chunked BERT, 4 / 16 chunks).
+    No golden at this size (the reference cannot run here in seconds): size-independent properties instead --
+    every a22 output finite, and exchanging the two images of the batch exchanges their rows."""
+    import bench
+    from hipie_amd.config import HipieConfig, Precision
+    from hipie_amd.hipie_img import HIPIE_IMG
+    cfg = HipieConfig.vit_huge()
+    torch.manual_seed(0)
+    model = HIPIE_IMG(cfg, Precision.fast(), device="cuda")
+    bench.randomize_degenerate_inits(model)
+    model.finalize()
+    b = bench.synth_batch(cfg, 2, 1344, n_classes, L, torch.device("cuda"))
+    n_named = len(b[0]["positive_map_label_to_token"])
+    assert n_named == n_classes and int(b[0]["attention_mask"].sum()) > 0.85 * L
+    out = model.forward_raw(b)
+    fg, md = model.last_topk()
+    assert out["pred_masks"].shape[-2:] == (336, 336)
+    for k in KEYS:
+        assert torch.isfinite(out[k].float()).all(), k
+    model.pin_topk(fg.flip(0).cpu(), md.flip(0).cpu())
+    swapped = model.forward_raw(b[::-1])
+    model.pin_topk(None, None)
+    for k in KEYS:
+        # not bit-identical: the library GEMMs' reduction order depends on the row position (fp16 policy: ~1e-3)
+        assert rel_err(swapped[k].float().flip(0).cpu(), out[k].float().cpu()) < 1e-2, k
+    # the instance post-processing sees the whole vocabulary: one score per (query, class)
+    from hipie_amd.postprocess import inference
+    res = inference(model, out, b, with_masks=False, with_sem_pan=False)
+    assert int(res[0]["instances"].pred_classes.max()) < n_classes

@@ -145,7 +145,8 @@ def test_post_product_matches_oracle_large(use_bg):
 
 
 @pytest.mark.parametrize("N,C,crop,out,prec", [(300, 9, (200, 256), (200, 256), 0), (130, 80, (250, 131), (333, 97), 0),
-                                               (77, 150, (256, 256), (256, 256), 1), (40, 33, (64, 100), (50, 300), 1)])
+                                               (77, 150, (256, 256), (256, 256), 1), (40, 33, (64, 100), (50, 300), 1),
+                                               (60, 847, (128, 96), (128, 96), 0), (900, 1203, (96, 128), (120, 160), 1)])
 def test_sem_pan_kernel_matches_torch_formulation(N, C, crop, out, prec):
     """hipie_sem_pan against the reference's tensor formulation (two bilinear resizes, sigmoid, einsum, argmax, areas)."""
     import torch.nn.functional as F
