@@ -36,6 +36,7 @@ class Precision:
     resid: torch.dtype = torch.float32
     attn_fast: bool = True
     name: str = "default"
+    text: torch.dtype = torch.float32      # BERT GEMM / stream dtype (16 bit: fused QKV + hipie_flash_attn + hipie_add_layernorm)
 
     @staticmethod
     def parity():
@@ -46,12 +47,14 @@ class Precision:
     def fast():
         """the timed policy: fp16 operands everywhere (same MFMA rate as bf16, 3 more mantissa bits), fp32 accumulation,
         fp32 ViT residual stream; inside the north star's 1e-3-class tolerance end to end (tests/test_gpu_e2e.py)."""
-        return Precision(torch.float16, torch.float16, torch.float16, torch.float16, 4, torch.float16, torch.float32, True, "fast")
+        return Precision(torch.float16, torch.float16, torch.float16, torch.float16, 4, torch.float16, torch.float32, True, "fast",
+                         torch.float16)
 
     @staticmethod
     def bf16():
         """bf16 operands and streams everywhere (round 1's timed policy): widest range, 8 mantissa bits."""
-        return Precision(torch.bfloat16, torch.bfloat16, torch.bfloat16, torch.bfloat16, 3, torch.bfloat16, torch.bfloat16, True, "bf16")
+        return Precision(torch.bfloat16, torch.bfloat16, torch.bfloat16, torch.bfloat16, 3, torch.bfloat16, torch.bfloat16, True, "bf16",
+                         torch.bfloat16)
 
 
 @dataclass

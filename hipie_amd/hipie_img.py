@@ -116,11 +116,16 @@ class HIPIE_IMG(nn.Module):
         cast_head(self.detr.mask_dino.predictor.decoder.layers, hd, ad)
         cast_head(self.detr.mask_dino.predictor.decoder.ref_point_head, hd)
         cast_head(self.detr.mask_head, hd, ad)
+        self.text_encoder[0].model.set_compute_dtype(self.precision.text)
         return self
 
     # ---- hipie_img.py:880-898 -------------------------------------------------------------------------------
     def preprocess_image(self, batched_inputs):
-        images = [(x["image"].to(self.device).float() - self.pixel_mean) / self.pixel_std for x in batched_inputs]
+        raw = [x["image"].to(self.device) for x in batched_inputs]
+        if len(set(tuple(t.shape) for t in raw)) == 1:         # equal sizes: one normalisation pass over the stacked batch
+            t = (torch.stack(raw).float() - self.pixel_mean) / self.pixel_std
+            return ImageList(t, [(int(t.shape[-2]), int(t.shape[-1]))] * len(raw))
+        images = [(t.float() - self.pixel_mean) / self.pixel_std for t in raw]
         return ImageList.from_tensors(images)
 
     # ---- hipie_img.py:900-922 -------------------------------------------------------------------------------

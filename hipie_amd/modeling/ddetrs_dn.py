@@ -62,7 +62,7 @@ class DDETRSegmUniDN(nn.Module):
         image_sizes = samples.image_sizes
         if not isinstance(samples, NestedTensor):
             div = getattr(self.detr.backbone[0].backbone, "size_divisibility", 32)
-            samples = nested_tensor_from_images(list(samples), size_divisibility=div)
+            samples = nested_tensor_from_images(list(samples), size_divisibility=div, stacked=getattr(samples, "tensor", None))
         features, pos = self.detr.backbone(samples)
         if task in ("grounding", "sot"):
             lang_feat_pool = agg_lang_feat(language_dict_features["hidden"], language_dict_features["masks"]).unsqueeze(1)

@@ -8,6 +8,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
+
 
 class BertSelfAttention(nn.Module):
     def __init__(self, h, heads):
@@ -87,14 +89,64 @@ class BertLayers(nn.Module):
 
 
 class BertModel(nn.Module):
-    """BERT-base encoder, last hidden state (add_pooling_layer=False)."""
+    """BERT-base encoder, last hidden state (add_pooling_layer=False).
+
+    fp32 (the parity policy): the plain formulation below.  With a 16-bit ``compute_dtype`` (set_compute_dtype, called from
+    HIPIE_IMG.finalize) a layer is 8 launches: one fused QKV GEMM, hipie_flash_attn with the padding mask as key mask
+    (the additive finfo.min mask of HuggingFace's BertSelfAttention zeroes the same keys), the output GEMM,
+    hipie_add_layernorm (post-norm residual, fp32 statistics), and the GELU MLP."""
 
     def __init__(self, cfg):
         super().__init__()
         self.embeddings = BertEmbeddings(cfg.bert_vocab, cfg.bert_hidden, cfg.bert_max_pos)
         self.encoder = BertLayers(cfg)
+        self.compute_dtype = torch.float32
+        self._fused = None
+
+    def set_compute_dtype(self, dtype):
+        """cast the GEMM weights (norms and embeddings stay fp32) and build the fused QKV weights; call after loading."""
+        self.compute_dtype = dtype
+        self._fused = None
+        if dtype == torch.float32:
+            return self
+        fused = []
+        for layer in self.encoder.layer:
+            at = layer.attention.self
+            fused.append((torch.cat([at.query.weight, at.key.weight, at.value.weight]).to(dtype).contiguous(),
+                          torch.cat([at.query.bias, at.key.bias, at.value.bias]).to(dtype).contiguous()))
+            for lin in (layer.attention.output.dense, layer.intermediate.dense, layer.output.dense):
+                lin.weight.data = lin.weight.data.to(dtype)
+                lin.bias.data = lin.bias.data.to(dtype)
+        self._fused = fused
+        return self
+
+    def _forward16(self, input_ids, attention_mask):
+        dt = self.compute_dtype
+        emb = self.embeddings
+        L = input_ids.shape[1]
+        x = emb.word_embeddings(input_ids) + emb.position_embeddings.weight[:L][None] + emb.token_type_embeddings.weight[0][None, None]
+        ln = emb.LayerNorm
+        # the post-norm stream stays fp32 (the LayerNorm outputs are both the next residual and the next GEMM input; only the
+        # GEMM input is rounded), the GEMMs and the attention run on 16-bit operands
+        f32 = torch.float32
+        x = ops.add_layernorm(x.float().contiguous(), None, ln.weight, ln.bias, ln.eps, f32)[1]
+        B, L, C = x.shape
+        heads = self.encoder.layer[0].attention.self.heads
+        hd = C // heads
+        kmask = attention_mask.to(torch.uint8).contiguous()
+        for layer, (wqkv, bqkv) in zip(self.encoder.layer, self._fused):
+            qkv = F.linear(x.to(dt), wqkv, bqkv).view(B, L, 3, heads, hd)
+            ctx = ops.flash_attn(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 1.0 / math.sqrt(hd), key_mask=kmask)
+            so = layer.attention.output
+            x = ops.add_layernorm(x, so.dense(ctx), so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.eps, f32, want_res=False)[1]
+            oo = layer.output
+            x = ops.add_layernorm(x, oo.dense(F.gelu(layer.intermediate.dense(x.to(dt)))), oo.LayerNorm.weight, oo.LayerNorm.bias,
+                                  oo.LayerNorm.eps, f32, want_res=False)[1]
+        return x
 
     def forward(self, input_ids, attention_mask):
+        if self.compute_dtype != torch.float32:
+            return self._forward16(input_ids, attention_mask)
         x = self.embeddings(input_ids)
         ext = (1.0 - attention_mask[:, None, None, :].to(x.dtype)) * torch.finfo(x.dtype).min
         for layer in self.encoder.layer:

@@ -56,6 +56,9 @@ class PLayerNorm(nn.LayerNorm):
     """LayerNorm on whatever activation dtype arrives (fp32 parameters, fp32 statistics inside the kernel)."""
 
     def forward(self, x):
+        C = x.shape[-1]
+        if x.is_cuda and C % 4 == 0 and C <= 2048 and self.weight.dtype == torch.float32 and x.dtype in ops._DT:
+            return ops.add_layernorm(x.contiguous(), None, self.weight, self.bias, self.eps, x.dtype)[1]   # fp32 statistics
         return F.layer_norm(x, self.normalized_shape, self.weight.to(x.dtype), self.bias.to(x.dtype), self.eps)
 
 
@@ -119,7 +122,7 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
-            x = F.relu(layer(x)) if i < self.num_layers - 1 else layer(x)
+            x = layer.forward_relu(x) if i < self.num_layers - 1 else layer(x)      # ReLU in the GEMM epilogue
         return x
 
 
@@ -166,13 +169,18 @@ class NestedTensor(object):
         return self.tensors, self.mask
 
 
-def nested_tensor_from_images(images, size_divisibility=32):
-    """hipie/util/misc.py:288-316: zero-pad to the batch max rounded up to size_divisibility; mask True on padding."""
+def nested_tensor_from_images(images, size_divisibility=32, stacked=None):
+    """hipie/util/misc.py:288-316: zero-pad to the batch max rounded up to size_divisibility; mask True on padding.
+    ``stacked``: the same images as one (B,3,H,W) tensor, used as is when no image needs padding."""
     H = max(int(im.shape[1]) for im in images)
     W = max(int(im.shape[2]) for im in images)
     H = (H + size_divisibility - 1) // size_divisibility * size_divisibility
     W = (W + size_divisibility - 1) // size_divisibility * size_divisibility
     dev = images[0].device
+    if stacked is not None and tuple(stacked.shape[-2:]) == (H, W) and all(tuple(im.shape[1:]) == (H, W) for im in images):
+        geo_key = (tuple((H, W) for _ in images), (H, W), str(dev))
+        return NestedTensor(stacked, geo_cached(geo_key, "pixel_mask", lambda: torch.zeros(
+            len(images), H, W, dtype=torch.bool, device=dev)), geo_key)
     t = torch.zeros(len(images), 3, H, W, dtype=images[0].dtype, device=dev)
     geo_key = (tuple((int(im.shape[1]), int(im.shape[2])) for im in images), (H, W), str(dev))
 
@@ -302,7 +310,7 @@ class BiMultiHeadAttention(nn.Module):
         self.out_v_proj, self.out_l_proj = PLinear(embed_dim, v_dim), PLinear(embed_dim, l_dim)
         self.attn_dtype = attn_dtype
 
-    def forward(self, v, l, attention_mask_l=None):
+    def forward(self, v, l, attention_mask_l=None, gamma_v=None):
         B, Nv, _ = v.shape
         L = l.shape[1]
         H, hd, dt = self.num_heads, self.head_dim, self.attn_dtype
@@ -314,8 +322,19 @@ class BiMultiHeadAttention(nn.Module):
         if attention_mask_l is None:
             attention_mask_l = torch.ones(B, L, dtype=torch.uint8, device=v.device)
         ov, ol = ops.bi_xattn(q, k, vv, vl, attention_mask_l != 0, clamp=50000.0)
-        return self.out_v_proj(ov), self.out_l_proj(ol)
+        if gamma_v is None:
+            return self.out_v_proj(ov), self.out_l_proj(ol)
+        wo, bo = self._scaled_out(gamma_v)
+        return F.linear(ov.to(wo.dtype), wo, bo).to(self.out_v_proj.out_dtype), self.out_l_proj(ol)
 
+    def _scaled_out(self, gamma):
+        p = self.out_v_proj
+        key = tuple((t.data_ptr(), t._version, t.dtype) for t in (p.weight, p.bias, gamma))
+        if getattr(self, "_so_key", None) != key:
+            g = gamma.float()
+            self._so = ((p.weight.float() * g[:, None]).to(p.weight.dtype), (p.bias.float() * g).to(p.bias.dtype))
+            self._so_key = key
+        return self._so
 
     def _scaled_q(self):
         p = self.v_proj
@@ -338,8 +357,10 @@ class BiAttentionBlockForCheckpoint(nn.Module):
 
     def forward(self, v, l, attention_mask_l=None, task=None):
         v, l = self.layer_norm_v(v), self.layer_norm_l(l)
-        dv, dl = self.attn(v, l, attention_mask_l=attention_mask_l)
-        return v + self.gamma_v * dv, l + self.gamma_l * dl
+        dv, dl = self.attn(v, l, attention_mask_l=attention_mask_l, gamma_v=self.gamma_v)
+        # gamma_v is folded into the visual output projection (weights only), so the 21760-token stream stays in its own
+        # dtype: `v + gamma_v * dv` would promote it to fp32 and every later encoder GEMM would cast it back
+        return v + dv.to(v.dtype), l + self.gamma_l * dl
 
 
 class VLFuse(nn.Module):
@@ -578,7 +599,11 @@ class DeformableTransformerVLDINO(nn.Module):
         spatial_shapes, level_start_index = level_tensors(shapes_list, src.device)
         valid_ratios = geo_cached(gk, "valid_ratios", lambda: torch.stack([get_valid_ratio(m) for m in masks], 1))
 
-        enc = self.encoder(src, shapes_list, spatial_shapes, level_start_index, valid_ratios, pos, mask,
+        # a batch whose images all fill the canvas has an all-False padding mask: known on the host from the geometry, so the
+        # 12 value projections skip their masked_fill pass (the masked formulation is what runs for ragged batches)
+        no_pad = geo_key is not None and all(tuple(sz) == tuple(geo_key[1]) for sz in geo_key[0])
+        layer_mask = None if no_pad else mask
+        enc = self.encoder(src, shapes_list, spatial_shapes, level_start_index, valid_ratios, pos, layer_mask,
                            language_dict_features, task=task, geo_key=gk)
         memory, language_dict_features = enc["visual"], enc["lang"]
         bs = memory.shape[0]
@@ -598,7 +623,7 @@ class DeformableTransformerVLDINO(nn.Module):
             tgt = torch.cat([self.tgt_embed_bg.weight[None].repeat(bs, 1, 1), tgt], dim=1)
             ref = torch.cat([self.bg_query_refs.weight[None].repeat(bs, 1, 1), ref], dim=1)
         init_ref = ref
-        hs, inter_refs = self.decoder(tgt.float(), ref.float(), memory, spatial_shapes, level_start_index, valid_ratios, mask)
+        hs, inter_refs = self.decoder(tgt.float(), ref.float(), memory, spatial_shapes, level_start_index, valid_ratios, layer_mask)
         return hs, memory, init_ref, inter_refs, enc_cls, enc_coord, language_dict_features, shapes_list
 
 

@@ -1,7 +1,9 @@
 #!/bin/bash
-# PMC passes (tools/pmc_kernel.sh) for the HBM-/gather-bound hand-written kernels at the bench geometry.
+# PMC passes (tools/pmc_kernel.sh) for the hand-written kernels at the bench geometry: the MFMA-bound global attention and the
+# HBM-/gather-bound head kernels.  Output: gpurun_out/pmc_<tag>.txt, summarised by tools/pmc_summary.py into profiles/.
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd $REPO
-bash tools/pmc_kernel.sh "python tools/bench_einsum.py" mask_einsum_kernel:einsum dynamic_mask_kernel:dynmask
+REL=2 DT=f16 bash tools/pmc_kernel.sh "python tools/bench_attn.py" vit_attn_sp_kernel:attention
+bash tools/pmc_kernel.sh "python tools/bench_einsum.py" mask_einsum16_kernel:einsum16 mask_einsum_kernel:einsum dynamic_mask_kernel:dynmask
 bash tools/pmc_kernel.sh "python tools/bench_msda.py" msda_d32_kernel:msda
-bash tools/pmc_kernel.sh "python tools/bench_xattn.py" Li256:xattn256 Li32:fa32
+DT=f16 bash tools/pmc_kernel.sh "python tools/bench_xattn.py" Li256:xattn256 Li32:fa32

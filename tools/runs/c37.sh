@@ -1,0 +1,3 @@
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_e2e.py -x -q -m gpu -s -k "not full_size" 2>&1 | grep -v "^$" | tail -25 > gpurun_out/c37_test.log
+timeout 300 python bench.py --no-cpu-baseline --no-parity-leg > gpurun_out/c37_bench.json 2> gpurun_out/c37_bench.err

@@ -33,19 +33,22 @@ def main():
                                                                    max_name_column_width=40, max_shapes_column_width=90))
     print(open("gpurun_out/torch_profile.txt").read()[:200])
     if os.environ.get("STACKS") == "1":          # who issues the copies / casts: python stacks of the copy-like operators
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof2:
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True,
+                     experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof2:
             model.forward_raw(batch)
             torch.cuda.synchronize()
         import collections
         agg = collections.defaultdict(lambda: [0.0, 0])
         for e in prof2.events():
-            if e.name in ("aten::copy_", "aten::add", "aten::masked_fill_", "aten::cat", "aten::mul", "aten::clamp") and e.device_time_total > 15:
+            if e.name in ("aten::copy_", "aten::add", "aten::masked_fill_", "aten::cat", "aten::mul", "aten::clamp", "aten::native_layer_norm",
+                          "aten::add_", "aten::mul_", "aten::sigmoid", "aten::index", "aten::index_select", "aten::gather", "aten::where",
+                          "aten::sub", "aten::div", "aten::relu", "aten::stack", "aten::softmax", "aten::_softmax", "aten::fill_", "aten::zero_") and e.device_time_total > 4:
                 frames = [f for f in (e.stack or []) if "hipie_amd" in f]
-                key = (e.name, str(e.input_shapes)[:60], frames[0].split("/")[-1][:70] if frames else "?")
+                key = (e.name, str(e.input_shapes)[:60], " < ".join(f.split("/")[-1][:48] for f in frames[:2]) if frames else "?")
                 agg[key][0] += e.device_time_total
                 agg[key][1] += 1
         with open("gpurun_out/torch_profile_stacks.txt", "w") as f:
-            for k, (t, n) in sorted(agg.items(), key=lambda x: -x[1][0])[:60]:
+            for k, (t, n) in sorted(agg.items(), key=lambda x: -x[1][0])[:120]:
                 f.write("%8.1f us %4d x  %-16s %-62s %s\n" % (t, n, k[0], k[1], k[2]))
 
 
