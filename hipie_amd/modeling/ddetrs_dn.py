@@ -47,6 +47,8 @@ class DDETRSegmUniDN(nn.Module):
         self.resizer = FeatureResizer(cfg.lang_dim, d)  # DYNAMIC_LABEL_ENC (training-only use; kept for the state_dict)
         self.mask_dino = MaskDINOHead(cfg, detr.backbone.num_channels, precision)
         self.mask_logit_dtype = precision.act      # mask logits leave in the activation dtype (fp32 in the parity policy)
+        # 16-bit head policies: the dynamic 10-8-8-1 layers on the matrix pipe (hipie_dynamic_mask16); fp32: the VALU kernel
+        self.mask_mlp_dtype = precision.head if precision.head in (torch.float16, torch.bfloat16) else None
         self.feature_keys = ["res3", "res4", "res5"]
         self.mask_dino_cls_embed = _get_clones(self.detr.class_embed[0], cfg.md_dec_layers + 2)
         self.cfg = cfg
@@ -122,5 +124,5 @@ class DDETRSegmUniDN(nn.Module):
         mask_feats = self.mask_head(enc, fpns=None)                           # (bs, 8, H/8, W/8)
         logits = ops.dynamic_mask(mask_feats.float().contiguous(), reference_points.float().contiguous(),
                                   mask_head_params.float().contiguous(), nq, stride=8, up=self.up_rate,
-                                  out_dtype=self.mask_logit_dtype)
+                                  out_dtype=self.mask_logit_dtype, mlp_dtype=self.mask_mlp_dtype)
         return logits.view(bs, nq, 1, logits.shape[-2], logits.shape[-1])

@@ -153,6 +153,15 @@ int hipie_dynamic_mask(const float* feats, const float* refs, const float* param
                        int B, int Q, int H, int W, int stride, int up, int out_dtype, void* stream);
 
 /*
+ * hipie_dynamic_mask (up = 2) with the three layers on the matrix pipe: 16-bit operands (`dtype` f16 / bf16: the features,
+ * the layer weights and the hidden activations are rounded to it; the coordinate weights are split hi + lo), fp32 accumulate,
+ * fp32 biases and reference-point terms.  Same replaced reference code and argument meaning as hipie_dynamic_mask.
+ * W % 4 == 0, stride % 4 == 0, stride * max(H, W) <= 8192 (pixel coordinates exact in 16 bit); else HIPIE_EINVAL.
+ */
+int hipie_dynamic_mask16(const float* feats, const float* refs, const float* params, void* out,
+                         int B, int Q, int H, int W, int stride, int dtype, int out_dtype, void* stream);
+
+/*
  * Decomposed relative-position bias tables of one ViT block, straight from the packed 16-bit qkv tensor.
  * Replaces: add_decomposed_rel_pos's two einsums + get_rel_pos gathers (backbone/utils.py:63-125) feeding hipie_vit_attn.
  *   qkv (B, gh*gw, 3, heads, hd) 16-bit;  tab_h (2*gh-1, hd), tab_w (2*gw-1, hd) 16-bit = rel_pos_h / rel_pos_w after the

@@ -150,6 +150,64 @@ def test_dynamic_mask(name):
     assert rel_err(got, want) < 2e-5
 
 
+def _dynamic_mask16_emulation(feats, refs, params, Q, stride, dt):
+    """the oracle's formulation with hipie_dynamic_mask16's roundings: features, layer weights and hidden activations in `dt`,
+    coordinate weights hi + lo, fp32 (here fp64) accumulation and bias / reference-point terms."""
+    B, C, H, W = feats.shape
+    rd = lambda t: t.to(dt).double()
+    p = params.reshape(-1, 169).double()
+    n_all = p.shape[0]
+    w0, w1, w2 = p[:, :80].reshape(n_all, 8, 10), p[:, 80:144].reshape(n_all, 8, 8), p[:, 144:152].reshape(n_all, 1, 8)
+    b0, b1, b2 = p[:, 152:160], p[:, 160:168], p[:, 168:169]
+    xs = (torch.arange(0, W * stride, stride) + stride // 2).double()
+    ys = (torch.arange(0, H * stride, stride) + stride // 2).double()
+    r = refs.reshape(-1, 2).double()
+    wxy = rd(w0[:, :, :2].float()) + rd((w0[:, :, :2].float() - w0[:, :, :2].float().to(dt).float()))      # hi + lo
+    f = rd(feats).reshape(B, C, H * W)[torch.arange(n_all) // Q]
+    pix = torch.stack([xs.view(1, W).expand(H, W).reshape(-1), ys.view(H, 1).expand(H, W).reshape(-1)])     # (2, HW)
+    c1 = b0 + w0[:, :, 0] * r[:, :1] + w0[:, :, 1] * r[:, 1:]
+    h1 = torch.relu(c1[:, :, None] - wxy @ pix[None] + rd(w0[:, :, 2:].float()) @ f)
+    h2 = torch.relu(rd(w1.float()) @ rd(h1.float()) + b1[:, :, None])
+    y = rd(w2.float()) @ rd(h2.float()) + b2[:, :, None]
+    return oo.aligned_bilinear(y.reshape(n_all, 1, H, W).float(), 2).reshape(n_all, 2 * H, 2 * W)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 3e-3), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("name", ["sq", "rect"])
+def test_dynamic_mask16_golden(name, dt, tol):
+    """the matrix-pipe variant against the reference's fp32 output (golden) within the 16-bit operand tolerance."""
+    from hipie_amd import ops
+    g = Golden("dynamic_mask")
+    c, feats, refs, params = dyn_case(g, name)
+    if c["W"] % 4:
+        pytest.skip("hipie_dynamic_mask16 needs W % 4 == 0")
+    got = ops.dynamic_mask(feats.to(DEV), refs[0].contiguous().to(DEV), params[0].contiguous().to(DEV), c["Q"], stride=8, up=2,
+                           mlp_dtype=dt).cpu()
+    got = got.view(1, c["B"] * c["Q"], 2 * c["H"], 2 * c["W"])
+    assert rel_err(g.like(name + "_out", got), g[name + "_out"]) < tol
+
+
+@pytest.mark.parametrize("B,Q,H,W,dt,odt", [(2, 9, 16, 32, torch.float16, torch.float32), (1, 6, 37, 168, torch.float16, torch.float16),
+                                            (3, 5, 20, 44, torch.bfloat16, torch.float32), (1, 910, 8, 128, torch.float16, torch.float32)])
+def test_dynamic_mask16_matches_rounded_formulation(B, Q, H, W, dt, odt):
+    """ragged shapes (Q % 4 != 0, W % 32 != 0, H % 16 != 0) against the same arithmetic written with torch (same operand
+    roundings, wide accumulation): pins every lane / k-slot map of the three chained MFMA layers."""
+    from hipie_amd import ops
+    gen = torch.Generator().manual_seed(B * 1000 + Q)
+    feats = torch.randn(B, 8, H, W, generator=gen)
+    refs = torch.rand(B * Q, 2, generator=gen) * torch.tensor([8.0 * W, 8.0 * H])
+    params = torch.randn(B * Q, 169, generator=gen) * 0.3
+    params[:, 0:80:10] *= 0.01                                   # coordinate weights: the inputs are ~1000 pixels
+    params[:, 1:80:10] *= 0.01
+    got = ops.dynamic_mask(feats.to(DEV), refs.to(DEV), params.to(DEV), Q, stride=8, up=2, out_dtype=odt, mlp_dtype=dt).float().cpu()
+    want = _dynamic_mask16_emulation(feats, refs, params, Q, 8, dt)
+    # a hidden activation that lands on a rounding boundary may round the other way (fp32 vs wide accumulation): 1 ulp of dt
+    tol = (2e-3 if dt == torch.float16 else 1.5e-2) if odt == torch.float32 else 3e-3
+    assert rel_err(got, want) < tol
+    full = oo.dynamic_mask(feats, refs[None], params[None], [Q] * B, stride=8, up=2)[0]
+    assert rel_err(got, full) < (6e-3 if dt == torch.float16 else 4e-2)
+
+
 def _vit_qkv(c, sd, x):
     import torch.nn.functional as F
     B, H, W, C = x.shape

@@ -48,6 +48,10 @@ def main():
         t = bench(lambda: ops.dynamic_mask(feats, refs, params, nq, stride=8, up=2, out_dtype=od), n=10)
         by = B * nq * 256 * 256 * (4 if od == torch.float32 else 2)
         print("dynamic_mask out %s: %.3f ms  %.2f TB/s written" % (str(od).split(".")[-1], t, by / t / 1e9))
+    for od in (torch.float32, torch.float16):
+        t = bench(lambda: ops.dynamic_mask(feats, refs, params, nq, stride=8, up=2, out_dtype=od, mlp_dtype=torch.float16), n=10)
+        by = B * nq * 256 * 256 * (4 if od == torch.float32 else 2)
+        print("dynamic_mask16 (f16 MFMA layers) out %s: %.3f ms  %.2f TB/s written" % (str(od).split(".")[-1], t, by / t / 1e9))
 
 
 if __name__ == "__main__":
