@@ -21,6 +21,7 @@ SIGNATURES = {
     "hipie_last_error": [],
     "hipie_msda_forward": [c_p, c_p, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p],
     "hipie_msda_fused_forward": [c_p, c_p, c_p, c_p, c_p, c_p, c_p] + [c_i] * 10 + [c_l, c_l, c_p],
+    "hipie_msda_fused_forward_strided": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p] + [c_i] * 10 + [c_l, c_l, c_p],
     "hipie_flash_attn": [c_p, c_p, c_p, c_p] + [c_i] * 5 + [c_l] * 12 + [c_p, c_p, c_i, c_i, c_p, c_f, c_f, c_i, c_p],
     "hipie_vit_attn": [c_p, c_p, c_p, c_p] + [c_i] * 5 + [c_f, c_i, c_p],
     "hipie_vit_attn_fused": [c_p, c_p, c_p, c_p] + [c_i] * 5 + [c_f, c_i, c_p],
@@ -38,6 +39,8 @@ SIGNATURES = {
     "hipie_sem_pan": [c_p] * 8 + [c_i] * 11 + [c_p],
     "hipie_sine_embed": [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_f, c_i, c_p],
     "hipie_box_refine": [c_p, c_p, c_p, c_l, c_f, c_i, c_p],
+    "hipie_add_layernorm_dec": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_i, c_i, c_p],
+    "hipie_add_cast": [c_p, c_p, c_p, c_l, c_i, c_p],
     "hipie_selftest": [c_i, c_p, c_p, c_p, c_p],
 }
 

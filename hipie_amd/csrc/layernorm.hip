@@ -163,6 +163,100 @@ static int ln_delta(int dd, int nd, const void* x, const void* d, const float* g
   }
 }
 
+
+// Post-norm residual of the DINO decoder layers with an fp32 query stream and 16-bit GEMMs: the LayerNorm output leaves once in
+// fp32 (the next residual) and, in the same pass, as the 16-bit operands of the GEMMs that follow: a plain copy (value / FFN /
+// box-head input) and / or the copy with the positional query added (the query of the next attention).  Replaces the
+// add -> cast chains between the launches of a decoder layer (deformable_transformer_dino.py:418-450).
+template <typename Td, typename Ta>
+__global__ __launch_bounds__(256) void add_layernorm_dec_kernel(const float* __restrict__ x, const Td* __restrict__ delta,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* __restrict__ norm_out, Ta* __restrict__ norm16,
+                                                                const Ta* __restrict__ addend, Ta* __restrict__ sum16, long rows,
+                                                                int C, float eps) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int nv = C / 256, tail = (C - nv * 256) / 4;
+  float v[LN_MAXV][4];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const bool on = (i < nv) || (i == nv && lane < tail);
+    if (on) {
+      const long c = row * C + i * 256 + lane * 4;
+      float d[4];
+      V4<float>::ld(x + c, v[i]);
+      V4<Td>::ld(delta + c, d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[i][e] += d[e]; sum += v[i][e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const bool on = (i < nv) || (i == nv && lane < tail);
+    if (on) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  const float rstd = rsqrtf(sq / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const bool on = (i < nv) || (i == nv && lane < tail);
+    if (on) {
+      const int cc = i * 256 + lane * 4;
+      const long c = row * C + cc;
+      const float4 g = *reinterpret_cast<const float4*>(gamma + cc);
+      const float4 b = *reinterpret_cast<const float4*>(beta + cc);
+      float o[4];
+      o[0] = (v[i][0] - mean) * rstd * g.x + b.x;
+      o[1] = (v[i][1] - mean) * rstd * g.y + b.y;
+      o[2] = (v[i][2] - mean) * rstd * g.z + b.z;
+      o[3] = (v[i][3] - mean) * rstd * g.w + b.w;
+      V4<float>::st(norm_out + c, o);
+      if (norm16 != nullptr) V4<Ta>::st(norm16 + c, o);
+      if (sum16 != nullptr) {
+        float a[4];
+        V4<Ta>::ld(addend + c, a);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += o[e];
+        V4<Ta>::st(sum16 + c, a);
+      }
+    }
+  }
+}
+
+template <typename Td, typename Ta>
+static int launch_ln_dec(const float* x, const void* d, const float* g, const float* b, float* n, void* n16, const void* add,
+                         void* s16, long rows, int C, float eps, hipStream_t st) {
+  hipLaunchKernelGGL((add_layernorm_dec_kernel<Td, Ta>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, (const Td*)d, g, b,
+                     n, (Ta*)n16, (const Ta*)add, (Ta*)s16, rows, C, eps);
+  return check_launch("add_layernorm_dec");
+}
+
+// out = (Ta)(a + b): the positional query added to the fp32 stream, rounded once to the GEMM operand type
+template <typename Ta>
+__global__ __launch_bounds__(256) void add_cast_kernel(const float* __restrict__ a, const Ta* __restrict__ b, Ta* __restrict__ out, long n4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float x[4], y[4];
+  V4<float>::ld(a + 4 * i, x);
+  V4<Ta>::ld(b + 4 * i, y);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) x[e] += y[e];
+  V4<Ta>::st(out + 4 * i, x);
+}
+
 }  // namespace hipie
 
 extern "C" int hipie_add_layernorm_rows(const void* x, const void* delta, const float* gamma, const float* beta,
@@ -192,4 +286,43 @@ extern "C" int hipie_add_layernorm(const void* x, const void* delta, const float
     case HIPIE_BF16: return ln_delta<bf16_t>(delta_dtype, norm_dtype, x, delta, gamma, beta, res_out, norm_out, rows, C, eps, st);
     default: return set_err(HIPIE_EINVAL, "add_layernorm: bad x dtype %d", x_dtype);
   }
+}
+
+extern "C" int hipie_add_layernorm_dec(const float* x, const void* delta, const float* gamma, const float* beta, float* norm_out,
+                                       void* norm16_out, const void* addend, void* sum16_out, int64_t rows, int C, float eps,
+                                       int delta_dtype, int aux_dtype, void* stream) {
+  using namespace hipie;
+  HIPIE_REQUIRE(x && delta && gamma && beta && norm_out, "add_layernorm_dec: null pointer");
+  HIPIE_REQUIRE((sum16_out == nullptr) || (addend != nullptr), "add_layernorm_dec: sum16_out needs addend");
+  HIPIE_REQUIRE(rows >= 0 && C > 0 && C % 4 == 0 && C <= LN_MAXV * 256, "add_layernorm_dec: C=%d must be a multiple of 4 and <= %d", C, LN_MAXV * 256);
+  HIPIE_REQUIRE(aux_dtype == HIPIE_F16 || aux_dtype == HIPIE_BF16, "add_layernorm_dec: aux dtype must be f16 or bf16");
+  if (rows == 0) return HIPIE_OK;
+  hipStream_t st = (hipStream_t)stream;
+#define HIPIE_LND(Td)                                                                                                          \
+  return aux_dtype == HIPIE_F16                                                                                                \
+             ? launch_ln_dec<Td, f16_t>(x, delta, gamma, beta, norm_out, norm16_out, addend, sum16_out, rows, C, eps, st)      \
+             : launch_ln_dec<Td, bf16_t>(x, delta, gamma, beta, norm_out, norm16_out, addend, sum16_out, rows, C, eps, st);
+  switch (delta_dtype) {
+    case HIPIE_F32: HIPIE_LND(float)
+    case HIPIE_F16: HIPIE_LND(f16_t)
+    case HIPIE_BF16: HIPIE_LND(bf16_t)
+    default: return set_err(HIPIE_EINVAL, "add_layernorm_dec: bad delta dtype %d", delta_dtype);
+  }
+#undef HIPIE_LND
+}
+
+extern "C" int hipie_add_cast(const float* a, const void* b, void* out, int64_t n, int dtype, void* stream) {
+  using namespace hipie;
+  HIPIE_REQUIRE(a && b && out, "add_cast: null pointer");
+  HIPIE_REQUIRE(n >= 0 && n % 4 == 0, "add_cast: n must be a multiple of 4");
+  HIPIE_REQUIRE(dtype == HIPIE_F16 || dtype == HIPIE_BF16, "add_cast: dtype must be f16 or bf16");
+  if (n == 0) return HIPIE_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const long n4 = n / 4;
+  const unsigned grid = (unsigned)((n4 + 255) / 256);
+  if (dtype == HIPIE_F16)
+    hipLaunchKernelGGL((add_cast_kernel<f16_t>), dim3(grid), dim3(256), 0, st, a, (const f16_t*)b, (f16_t*)out, n4);
+  else
+    hipLaunchKernelGGL((add_cast_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a, (const bf16_t*)b, (bf16_t*)out, n4);
+  return check_launch("add_cast");
 }

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void msda_d32_kernel(const T* __restrict__ val
                                                        const A* __restrict__ loc_or_off, const A* __restrict__ w_or_logit,
                                                        const float* __restrict__ ref, T* __restrict__ out, int S, int M,
                                                        int L, int Lq, int P, int ref_dim, long total_groups,
-                                                       long off_stride, long w_stride) {
+                                                       long off_stride, long w_stride, long vrow) {
   extern __shared__ __attribute__((aligned(16))) float recs[];   // 32 groups x (LP * 8 + 4) words
   // XCD-aware block order: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md); give every XCD one CONTIGUOUS range of
   // (image, query) groups so that neighbouring queries -- which sample neighbouring value pixels -- share that XCD's L2
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void msda_d32_kernel(const T* __restrict__ val
   const long bq = gc / M;
   const int b = (int)(bq / Lq);
   const int LP = L * P;
-  const long row = (long)M * 32;                       // elements per pixel
+  const long row = vrow;                               // elements from one pixel's channels to the next pixel's (>= M * 32)
   float* rec = recs + (threadIdx.x >> 3) * (LP * 8 + 4);      // +4 words: the 8 groups of a wave land on disjoint banks
   // row = one (batch, query); offsets / logits of head m inside the row (dense rows when the strides are M*L*P*2 / M*L*P)
   publish_records<A, FUSED>(rec, sub, loc_or_off + bq * off_stride + (long)m * (LP * 2), w_or_logit + bq * w_stride + (long)m * LP,
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void msda_generic_kernel(const T* __restrict__
                                                            const A* __restrict__ w_or_logit,
                                                            const float* __restrict__ ref, T* __restrict__ out, int S,
                                                            int M, int D, int L, int Lq, int P, int ref_dim, long n,
-                                                           long off_stride, long w_stride) {
+                                                           long off_stride, long w_stride, long vrow) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n) return;
   const int c = (int)(idx % D);
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void msda_generic_kernel(const T* __restrict__
     for (int i = 0; i < LP; ++i) s += expf(elem<A>::to_f32(wp[i]) - wmax);
     winv = 1.f / s;
   }
-  const long row = (long)M * D;
+  const long row = vrow;
   const T* vb = value + (long)b * S * row + m * D + c;
   float col = 0.f;
   for (int l = 0; l < L; ++l) {
@@ -263,23 +263,27 @@ __global__ __launch_bounds__(256) void msda_generic_kernel(const T* __restrict__
   out[idx] = elem<T>::from_f32(col);
 }
 
+// value row stride of the call being dispatched (host-side plumbing through the dtype switch; 0 = dense M * D)
+static thread_local long g_value_row = 0;
+
 template <typename T, typename A, bool FUSED>
 static int launch_msda(const void* value, const int64_t* shapes, const int64_t* lstart, const void* a, const void* w,
                        const float* ref, void* out, int B, int S, int M, int D, int L, int Lq, int P, int ref_dim,
                        long off_stride, long w_stride, hipStream_t st) {
   const long groups = (long)B * Lq * M;
   if (groups == 0) return HIPIE_OK;
+  const long vrow = g_value_row > 0 ? g_value_row : (long)M * D;
   if (D == 32) {
     const long blocks = (groups + 31) / 32;
     const size_t lds = (size_t)32 * (L * P * 8 + 4) * sizeof(float);
     // unroll 2 of the record loop: 0.467 ms vs 0.480 (1, 4, 8) on the bs-8 encoder geometry (tools/bench_msda.py)
     hipLaunchKernelGGL((msda_d32_kernel<T, A, FUSED, 2>), dim3((unsigned)blocks), dim3(256), lds, st, (const T*)value, shapes,
-                       lstart, (const A*)a, (const A*)w, ref, (T*)out, S, M, L, Lq, P, ref_dim, groups, off_stride, w_stride);
+                       lstart, (const A*)a, (const A*)w, ref, (T*)out, S, M, L, Lq, P, ref_dim, groups, off_stride, w_stride, vrow);
   } else {
     const long n = groups * D;
     const long blocks = (n + 255) / 256;
     hipLaunchKernelGGL((msda_generic_kernel<T, A, FUSED>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)value,
-                       shapes, lstart, (const A*)a, (const A*)w, ref, (T*)out, S, M, D, L, Lq, P, ref_dim, n, off_stride, w_stride);
+                       shapes, lstart, (const A*)a, (const A*)w, ref, (T*)out, S, M, D, L, Lq, P, ref_dim, n, off_stride, w_stride, vrow);
   }
   return check_launch("msda");
 }
@@ -306,6 +310,7 @@ static int dispatch_msda(const void* value, const int64_t* shapes, const int64_t
   HIPIE_REQUIRE(value && shapes && lstart && a && w && out, "msda: null pointer");
   HIPIE_REQUIRE((long)B * S * M * D < (1L << 40), "msda: tensor too large");
   HIPIE_REQUIRE(off_stride >= (long)M * L * P * 2 && w_stride >= (long)M * L * P, "msda: row strides too small");
+  HIPIE_REQUIRE(g_value_row == 0 || (g_value_row >= (long)M * D && g_value_row % 8 == 0), "msda: value row stride %ld < M*D or not a multiple of 8", g_value_row);
   if (FUSED) {
     HIPIE_REQUIRE(ref != nullptr && (ref_dim == 2 || ref_dim == 4), "msda_fused: ref_dim must be 2 or 4 (got %d)", ref_dim);
     HIPIE_REQUIRE(L * P <= kMaxLP, "msda_fused: L*P=%d > %d", L * P, kMaxLP);
@@ -334,4 +339,16 @@ extern "C" int hipie_msda_fused_forward(const void* value, const int64_t* spatia
                                         int aux_dtype, int64_t off_row_stride, int64_t logit_row_stride, void* stream) {
   return hipie::dispatch_msda<true>(value, spatial_shapes, level_start, offsets, logits, ref, out, B, S, M, D, L, Lq, P,
                                     ref_dim, value_dtype, aux_dtype, off_row_stride, logit_row_stride, stream);
+}
+
+extern "C" int hipie_msda_fused_forward_strided(const void* value, int64_t value_row_stride, const int64_t* spatial_shapes,
+                                                const int64_t* level_start, const float* ref, const void* offsets,
+                                                const void* logits, void* out, int B, int S, int M, int D, int L, int Lq, int P,
+                                                int ref_dim, int value_dtype, int aux_dtype, int64_t off_row_stride,
+                                                int64_t logit_row_stride, void* stream) {
+  hipie::g_value_row = value_row_stride;
+  const int rc = hipie::dispatch_msda<true>(value, spatial_shapes, level_start, offsets, logits, ref, out, B, S, M, D, L, Lq, P,
+                                            ref_dim, value_dtype, aux_dtype, off_row_stride, logit_row_stride, stream);
+  hipie::g_value_row = 0;
+  return rc;
 }

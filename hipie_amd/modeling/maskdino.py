@@ -16,7 +16,8 @@ import torch.nn.functional as F
 from .. import ops
 from .transformer import (MLP, DeformableTransformerDecoderLayer, DeformableTransformerEncoderLayer, FeatureResizer, geo_cached,
                           PConv2d, PGroupNorm, PLayerNorm, PLinear, PositionEmbeddingSine, _get_clones, encoder_reference_points,
-                          gen_encoder_output_proposals, get_sine_pos_embed, inverse_sigmoid, level_tensors)
+                          gen_encoder_output_proposals, get_sine_pos_embed, inverse_sigmoid, level_tensors,
+                          batched_decoder_values, decoder_fast_path, ref_point_query)
 
 
 class NormConv2d(PConv2d):
@@ -199,7 +200,20 @@ class MaskDINODecoder(nn.Module):
         sdt = torch.float32 if os.environ.get("HIPIE_DEC_F32", "1") == "1" else self.decoder.layers[0].linear1.out_dtype
         wdt = self.decoder.ref_point_head.layers[0].weight.dtype
         refs, out, hs = [ref], tgt.to(sdt), []
-        for lid, layer in enumerate(self.decoder.layers):
+        layers = self.decoder.layers
+        if decoder_fast_path(layers, sdt) and wdt == layers[0].linear1.weight.dtype:
+            values = batched_decoder_values(self.decoder, layers, src, None)
+            t32 = out.contiguous()
+            t16 = t32.to(wdt)
+            for lid, layer in enumerate(layers):
+                ref_in = ref[:, :, None] * vr2
+                qp16 = ref_point_query(self.decoder.ref_point_head, ops.sine_embed(ref_in[:, :, 0, :], out_dtype=wdt))
+                t32, t16 = layer.forward16(t32, t16, qp16, ref_in, values[lid], spatial_shapes, level_start_index)
+                ref = ops.box_refine(self.decoder.bbox_embed[lid](t32), ref)
+                refs.append(ref)
+            hs.append(self.decoder.norm(t32).float())
+            layers = []
+        for lid, layer in enumerate(layers):
             ref_in = ref[:, :, None] * vr2
             query_pos = self.decoder.ref_point_head(ops.sine_embed(ref_in[:, :, 0, :], out_dtype=wdt))
             out = layer(out, query_pos, ref_in, src, spatial_shapes, level_start_index, None)

@@ -288,6 +288,17 @@ class MSDeformAttn(nn.Module):
                              reference_points.float().contiguous(), off, logits)
         return self.output_proj(out)
 
+    def forward_projected(self, query, reference_points, value, input_spatial_shapes, input_level_start_index):
+        """forward with the value projection done by the caller (one GEMM for all decoder layers): `value` (N, S, heads, hd),
+        dense or a column block of the batched projection (sampled in place through its row stride)."""
+        w, b = self._fused_proj()
+        no = self.n_heads * self.n_levels * self.n_points * 2
+        proj = F.linear(query.to(w.dtype), w, b)
+        off = proj[..., :no].unflatten(-1, (self.n_heads, self.n_levels, self.n_points, 2))
+        logits = proj[..., no:].unflatten(-1, (self.n_heads, self.n_levels * self.n_points))
+        out = ops.msda_fused(value, input_spatial_shapes, input_level_start_index, reference_points.float().contiguous(), off, logits)
+        return self.output_proj(out)
+
     def _fused_proj(self):
         so, aw = self.sampling_offsets, self.attention_weights
         key = tuple((p.data_ptr(), p._version, p.dtype) for p in (so.weight, aw.weight, so.bias, aw.bias))
@@ -474,6 +485,55 @@ class DeformableTransformerDecoderLayer(nn.Module):
         return _add_norm(tgt, tgt2, self.norm3)
 
 
+    def forward16(self, t32, t16, qp16, reference_points, value, spatial_shapes, level_start_index):
+        """the same layer for an fp32 query stream with 16-bit GEMMs, 15 launches: t32 the stream, t16 its copy in the GEMM
+        dtype, qp16 the positional query in the GEMM dtype, value this layer's (pre-projected) block.  Every LayerNorm launch
+        also emits the 16-bit operands of the GEMMs that follow it (hipie_add_layernorm_dec); returns (t32, t16)."""
+        wd = t16.dtype
+        sa = self.self_attn(ops.add_cast(t32, qp16), t16)
+        n = self.norm2
+        t32, _, q16 = ops.add_layernorm_dec(t32, sa, n.weight, n.bias, n.eps, wd, addend=qp16)
+        ca = self.cross_attn.forward_projected(q16, reference_points, value, spatial_shapes, level_start_index)
+        n = self.norm1
+        t32, t16, _ = ops.add_layernorm_dec(t32, ca, n.weight, n.bias, n.eps, wd, want16=True)
+        ff = self.linear2(self.linear1.forward_relu(t16))
+        n = self.norm3
+        t32, t16, _ = ops.add_layernorm_dec(t32, ff, n.weight, n.bias, n.eps, wd, want16=True)
+        return t32, t16
+
+
+def decoder_fast_path(layers, stream_dtype):
+    """fp32 query stream + 16-bit layer weights + value tensor in the weight dtype: the launch-lean formulation applies."""
+    l0 = layers[0]
+    wd = l0.linear1.weight.dtype
+    return (stream_dtype == torch.float32 and wd in (torch.float16, torch.bfloat16) and l0.cross_attn.value_dtype == wd
+            and l0.linear1.out_dtype == wd and l0.linear1.weight.is_cuda)
+
+
+def batched_decoder_values(owner, layers, src, padding_mask=None):
+    """value projections of ALL decoder layers as one GEMM on the concatenated weights (they read the same memory); returns
+    the per-layer (N, S, heads, hd) column blocks (views: hipie_msda samples them in place)."""
+    ps = [l.cross_attn.value_proj for l in layers]
+    key = tuple((p.weight.data_ptr(), p.weight._version, p.weight.dtype) for p in ps)
+    if getattr(owner, "_bv_key", None) != key:
+        owner._bv = (torch.cat([p.weight for p in ps], 0).contiguous(), torch.cat([p.bias for p in ps], 0).contiguous())
+        owner._bv_key = key
+    w, b = owner._bv
+    v = F.linear(src.to(w.dtype), w, b)
+    if padding_mask is not None:
+        v.masked_fill_(padding_mask[..., None], 0.0)
+    N, S, _ = v.shape
+    d, H = ps[0].weight.shape[0], layers[0].cross_attn.n_heads
+    return [v[:, :, i * d:(i + 1) * d].unflatten(-1, (H, d // H)) for i in range(len(ps))]
+
+
+def ref_point_query(ref_point_head, sine):
+    """the 2-layer ref_point_head on a 16-bit sine embedding, output left in the GEMM dtype (no cast to the stream dtype)."""
+    l0, l1 = ref_point_head.layers
+    h = torch._addmm_activation(l0.bias, sine.reshape(-1, sine.shape[-1]), l0.weight.t(), use_gelu=False)   # ReLU epilogue
+    return F.linear(h, l1.weight, l1.bias).view(*sine.shape[:-1], -1)
+
+
 def get_sine_pos_embed(pos_tensor, num_pos_feats=128, temperature=10000, exchange_xy=True):
     """deformable_transformer_dino.py:636-670 (== gen_sineembed_for_position, maskdino/utils/utils.py:74-100)."""
     scale = 2 * math.pi
@@ -505,6 +565,18 @@ class DeformableTransformerDecoder(nn.Module):
         output, inter, inter_refs = tgt.to(sdt), [], []
         vr2 = torch.cat([valid_ratios, valid_ratios], -1)[:, None]
         wdt = self.ref_point_head.layers[0].weight.dtype
+        if decoder_fast_path(self.layers, sdt) and wdt == self.layers[0].linear1.weight.dtype:
+            values = batched_decoder_values(self, self.layers, src, src_padding_mask)
+            t32 = output.contiguous()
+            t16 = t32.to(wdt)
+            for lid, layer in enumerate(self.layers):
+                ref_in = reference_points[:, :, None] * vr2
+                qp16 = ref_point_query(self.ref_point_head, ops.sine_embed(ref_in[:, :, 0, :], out_dtype=wdt))
+                t32, t16 = layer.forward16(t32, t16, qp16, ref_in, values[lid], spatial_shapes, level_start_index)
+                reference_points = ops.box_refine(self.bbox_embed[lid](t32), reference_points)
+                inter.append(t32)
+                inter_refs.append(reference_points)
+            return torch.stack(inter), torch.stack(inter_refs)
         for lid, layer in enumerate(self.layers):
             ref_in = reference_points[:, :, None] * vr2
             query_pos = self.ref_point_head(ops.sine_embed(ref_in[:, :, 0, :], out_dtype=wdt))      # one launch (was ~21)

@@ -112,6 +112,11 @@ def msda_fused(value, spatial_shapes, level_start_index, ref, offsets, logits):
     may be column slices of ONE projection output: only the last dim block must be contiguous) -> (B,Lq,M*D)."""
     lib = _lib.load()
     B, S, M, D = value.shape
+    vrow = M * D
+    if not value.is_contiguous():             # a column block of a wider (B, S, n * M * D) projection output: sampled in place
+        vrow = value.stride(1)
+        if value.stride(3) != 1 or value.stride(2) != D or value.stride(0) != S * vrow or vrow % 8 or vrow < M * D:
+            raise RuntimeError("msda_fused: value must be dense or a column block of a dense (B, S, k*M*D) tensor")
     _, Lq, _, L, P, _ = offsets.shape
     if offsets.dtype != logits.dtype or offsets.dtype not in _DT:
         raise RuntimeError("msda_fused: offsets/logits must share a dtype in f32/f16/bf16")
@@ -125,11 +130,13 @@ def msda_fused(value, spatial_shapes, level_start_index, ref, offsets, logits):
         if not t.is_cuda:
             raise RuntimeError("Not implemented on the CPU (%s)" % n)
     out = torch.empty(B, Lq, M * D, dtype=value.dtype, device=value.device)
-    rc = lib.hipie_msda_fused_forward(_chk(value, "value"), _chk(spatial_shapes, "spatial_shapes", torch.int64),
-                                      _chk(level_start_index, "level_start_index", torch.int64),
-                                      _chk(ref, "ref", torch.float32), offsets.data_ptr(), logits.data_ptr(), out.data_ptr(),
-                                      B, S, M, D, L, Lq, P, ref.shape[-1], _DT[value.dtype], _DT[offsets.dtype],
-                                      off_stride, lg_stride, _stream())
+    if not value.is_cuda or value.dtype not in _DT:
+        raise RuntimeError("Not implemented on the CPU (value)" if not value.is_cuda else "msda_fused: bad value dtype")
+    rc = lib.hipie_msda_fused_forward_strided(value.data_ptr(), vrow, _chk(spatial_shapes, "spatial_shapes", torch.int64),
+                                              _chk(level_start_index, "level_start_index", torch.int64),
+                                              _chk(ref, "ref", torch.float32), offsets.data_ptr(), logits.data_ptr(), out.data_ptr(),
+                                              B, S, M, D, L, Lq, P, ref.shape[-1], _DT[value.dtype], _DT[offsets.dtype],
+                                              off_stride, lg_stride, _stream())
     _lib.check(rc, "hipie_msda_fused_forward")
     return out
 
@@ -340,6 +347,38 @@ def add_layernorm(x, delta, weight, bias, eps, norm_dtype, want_res=True, delta_
                                           None if out_src is None else _chk(out_src, "out_src", torch.int32), _stream())
     _lib.check(rc, "hipie_add_layernorm")
     return (x if delta is None else res), out
+
+
+@_timed("add_layernorm")
+def add_layernorm_dec(x, delta, weight, bias, eps, aux_dtype, want16=False, addend=None):
+    """n = LayerNorm(x + delta) for the fp32 query stream of the decoders: returns (n f32, n in aux_dtype or None,
+    (n + addend) in aux_dtype or None) from one launch.  x (..., C) f32; delta any of f32/f16/bf16; addend aux_dtype."""
+    lib = _lib.load()
+    C = x.shape[-1]
+    rows = x.numel() // C
+    out = torch.empty_like(x)
+    n16 = torch.empty(x.shape, dtype=aux_dtype, device=x.device) if want16 else None
+    s16 = torch.empty(x.shape, dtype=aux_dtype, device=x.device) if addend is not None else None
+    if addend is not None and (addend.dtype != aux_dtype or addend.shape != x.shape):
+        raise RuntimeError("add_layernorm_dec: addend must match x's shape in aux_dtype")
+    rc = lib.hipie_add_layernorm_dec(_chk(x, "x", torch.float32), _chk(delta, "delta"), _chk(weight, "weight", torch.float32),
+                                     _chk(bias, "bias", torch.float32), out.data_ptr(), None if n16 is None else n16.data_ptr(),
+                                     None if addend is None else _chk(addend, "addend"), None if s16 is None else s16.data_ptr(),
+                                     rows, C, float(eps), _DT[delta.dtype], _DT[aux_dtype], _stream())
+    _lib.check(rc, "hipie_add_layernorm_dec")
+    return out, n16, s16
+
+
+@_timed("add_cast")
+def add_cast(a, b):
+    """(a f32 + b 16-bit) rounded once to b's dtype; same shapes, numel % 4 == 0."""
+    lib = _lib.load()
+    if a.shape != b.shape:
+        raise RuntimeError("add_cast: shapes differ")
+    out = torch.empty_like(b)
+    rc = lib.hipie_add_cast(_chk(a, "a", torch.float32), _chk(b, "b"), out.data_ptr(), a.numel(), _DT[b.dtype], _stream())
+    _lib.check(rc, "hipie_add_cast")
+    return out
 
 
 @_timed("batched_nms")

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPIE_ABI_VERSION 2
+#define HIPIE_ABI_VERSION 3
 
 /* element types of activations */
 #define HIPIE_F32 0
@@ -74,6 +74,16 @@ int hipie_msda_fused_forward(const void* value, const int64_t* spatial_shapes, c
                              const float* ref, const void* offsets, const void* logits, void* out,
                              int B, int S, int M, int D, int L, int Lq, int P, int ref_dim, int value_dtype,
                              int aux_dtype, int64_t off_row_stride, int64_t logit_row_stride, void* stream);
+
+/*
+ * hipie_msda_fused_forward on a value tensor whose pixel rows are `value_row_stride` elements apart (>= M*D, a multiple of 8):
+ * the value projections of all decoder layers read the same memory, so they run as ONE GEMM on the concatenated weights
+ * (deformable_transformer_dino.py:418-450, one value_proj per layer) and every layer samples its own column block in place.
+ */
+int hipie_msda_fused_forward_strided(const void* value, int64_t value_row_stride, const int64_t* spatial_shapes,
+                                     const int64_t* level_start, const float* ref, const void* offsets, const void* logits,
+                                     void* out, int B, int S, int M, int D, int L, int Lq, int P, int ref_dim, int value_dtype,
+                                     int aux_dtype, int64_t off_row_stride, int64_t logit_row_stride, void* stream);
 
 /*
  * Fused (flash-style) attention core shared by the ViT blocks and the VL fusion:
@@ -219,6 +229,20 @@ int hipie_vit_attn_rel(const void* qkv, const void* tab_h, const void* tab_w, vo
 int hipie_add_layernorm_rows(const void* x, const void* delta, const float* gamma, const float* beta, void* res_out,
                              void* norm_out, int64_t out_rows, int C, float eps, int x_dtype, int delta_dtype,
                              int norm_dtype, const int32_t* delta_row, const int32_t* out_src, void* stream);
+
+/*
+ * The post-norm residual of a DINO decoder layer (deformable_transformer_dino.py:418-450 == dino_decoder.py:222-268) when the
+ * query stream is fp32 and the GEMMs take 16-bit operands:  n = LayerNorm(x + delta) is written once in fp32 (norm_out, the next
+ * residual) and, optionally and in the same pass, as norm16_out = (aux)n and sum16_out = (aux)(n + addend)  (addend = the
+ * positional query, `aux_dtype`): the inputs of the next value / FFN / box GEMMs and of the next attention's query GEMM.
+ *   x (rows, C) f32; delta (rows, C) `delta_dtype`; aux_dtype f16 | bf16; C % 4 == 0, C <= 2048; fp32 two-pass statistics.
+ */
+int hipie_add_layernorm_dec(const float* x, const void* delta, const float* gamma, const float* beta, float* norm_out,
+                            void* norm16_out, const void* addend, void* sum16_out, int64_t rows, int C, float eps,
+                            int delta_dtype, int aux_dtype, void* stream);
+
+/* out = (dtype)(a + b): a (n) f32, b (n) `dtype` f16 | bf16 -- `tgt + query_pos` rounded once to the GEMM operand type. */
+int hipie_add_cast(const float* a, const void* b, void* out, int64_t n, int dtype, void* stream);
 
 /*
  * Batched (class-aware) NMS for one batch of images, the device form of the per-image

@@ -86,6 +86,13 @@ def test_msda_fused(ref_dim):
     want = oo.ms_deform_attn_core(value, shapes, loc, aw)
     got = ops.msda_fused(value.to(DEV), shapes.to(DEV), _lsi(shapes).to(DEV), ref.to(DEV), off.to(DEV), logit.to(DEV)).cpu()
     assert rel_err(got, want) < 2e-5
+    # the value tensor as the middle column block of a 3x wider projection output (one GEMM for all decoder layers): same bits
+    wide = torch.randn(B, S, 3 * M * D, generator=gen).to(DEV)
+    wide[:, :, M * D:2 * M * D] = value.reshape(B, S, M * D).to(DEV)
+    block = wide[:, :, M * D:2 * M * D].unflatten(-1, (M, D))
+    assert not block.is_contiguous()
+    got2 = ops.msda_fused(block, shapes.to(DEV), _lsi(shapes).to(DEV), ref.to(DEV), off.to(DEV), logit.to(DEV)).cpu()
+    assert torch.equal(got2, got)
 
 
 def test_msda_generic_head_dim():
@@ -584,3 +591,23 @@ def test_empty_inputs_are_handled():
                          torch.zeros(1, 0, 1, 2, device=DEV), torch.zeros(1, 0, 8, 1, 4, 2, device=DEV),
                          torch.zeros(1, 0, 8, 4, device=DEV))
     assert out.shape == (1, 0, 256)
+
+
+@pytest.mark.parametrize("dt,ddt", [(torch.float16, torch.float16), (torch.bfloat16, torch.float32)])
+def test_decoder_glue_layernorm_dec_and_add_cast(dt, ddt):
+    """hipie_add_layernorm_dec / hipie_add_cast against the eager chain they replace in the decoder layers."""
+    import torch.nn.functional as F
+    from hipie_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 301, 256, generator=gen).to(DEV)
+    delta = torch.randn(3, 301, 256, generator=gen).to(DEV).to(ddt)
+    qp = torch.randn(3, 301, 256, generator=gen).to(DEV).to(dt)
+    w, b = torch.randn(256, generator=gen).to(DEV), torch.randn(256, generator=gen).to(DEV)
+    want = F.layer_norm(x + delta.float(), (256,), w, b, 1e-5)
+    n32, n16, s16 = ops.add_layernorm_dec(x, delta, w, b, 1e-5, dt, want16=True, addend=qp)
+    assert rel_err(n32.cpu(), want.cpu()) < 2e-6
+    assert torch.equal(n16, n32.to(dt))
+    assert torch.equal(s16, (n32 + qp.float()).to(dt))
+    n32b, none16, nones = ops.add_layernorm_dec(x, delta, w, b, 1e-5, dt)
+    assert none16 is None and nones is None and torch.equal(n32b, n32)
+    assert torch.equal(ops.add_cast(x, qp), (x + qp.float()).to(dt))

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""wall time of the main stages of one bench forward (HIP events around the modules' forward calls, eager launches):
+where the step goes after the backbone.  Output: gpurun_out/stage_times.txt"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from hipie_amd.config import HipieConfig, Precision  # noqa: E402
+from hipie_amd.hipie_img import HIPIE_IMG  # noqa: E402
+
+
+def main():
+    torch.set_grad_enabled(False)
+    dev = torch.device("cuda", 0)
+    cfg = HipieConfig.vit_huge()
+    model = HIPIE_IMG(cfg, Precision.fast(), device=dev)
+    bench.randomize_degenerate_inits(model)
+    model.finalize()
+    batch = bench.synth_batch(cfg, 8, 1024, 80, 194, dev)
+    d = model.detr
+    stages = {"text_encoder (BERT)": model.text_encoder[0], "backbone (ViT-H + SFP)": d.detr.backbone[0],
+              "input_proj": d.detr.input_proj, "DINO encoder (6 layers + VL fusion)": d.detr.transformer.encoder,
+              "DINO decoder (6 layers)": d.detr.transformer.decoder, "DINO transformer total": d.detr.transformer,
+              "MaskDINO pixel decoder": d.mask_dino.pixel_decoder, "MaskDINO decoder + einsums": d.mask_dino.predictor,
+              "mask_head (CondInst convs)": d.mask_head, "whole DDETRSegmUniDN": d}
+    rec = {k: [] for k in stages}
+
+    def pre(name):
+        def f(m, a, kw=None):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            rec[name].append([e, None])
+        return f
+
+    def post(name):
+        def f(m, a, out):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            rec[name][-1][1] = e
+        return f
+    for k, m in stages.items():
+        if isinstance(m, torch.nn.ModuleList):          # input_proj: time each member, summed
+            for sub in m:
+                sub.register_forward_pre_hook(pre(k))
+                sub.register_forward_hook(post(k))
+        else:
+            m.register_forward_pre_hook(pre(k))
+            m.register_forward_hook(post(k))
+    for _ in range(3):
+        model.forward_raw(batch)
+    torch.cuda.synchronize()
+    for k in rec:
+        rec[k].clear()
+    n = 3
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(n):
+        model.forward_raw(batch)
+    t1.record()
+    torch.cuda.synchronize()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/stage_times.txt", "w") as f:
+        f.write("forward_raw %.2f ms (mean of %d, with hooks)\n" % (t0.elapsed_time(t1) / n, n))
+        for k, v in rec.items():
+            f.write("%-40s %8.2f ms  (%d calls / forward)\n" % (k, sum(a.elapsed_time(b) for a, b in v) / n, len(v) // n))
+    print(open("gpurun_out/stage_times.txt").read())
+
+
+if __name__ == "__main__":
+    main()
