@@ -508,10 +508,12 @@ static int launch_fa(FAParams& p, hipStream_t st) {
   p.ntiles = BIAS ? p.kh : (p.Nk + KT - 1) / KT;
   const unsigned grid = (unsigned)(p.nqt * p.B * p.H);
   auto kern = flash_attn_kernel<T, HD, NB, QB, WAVES, BIAS, CLAMP, MASKED, FUSEREL>;
-  static size_t lds_set = 0;     // raise the dynamic-LDS limit once per instantiation (not a stream operation: keep it out of graph capture)
-  if (lds > 64 * 1024 && lds > lds_set) {
+  static size_t lds_set[64] = {0};     // per device: raise the dynamic-LDS limit once per instantiation (not a stream operation: keep it out of graph capture)
+  int dev = -1;
+  (void)hipGetDevice(&dev);
+  if (lds > 64 * 1024 && (dev < 0 || dev >= 64 || lds > lds_set[dev])) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    lds_set = lds;
+    if (dev >= 0 && dev < 64) lds_set[dev] = lds;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st, p);
   return check_launch("flash_attn");

@@ -310,6 +310,7 @@ static int dispatch_msda(const void* value, const int64_t* shapes, const int64_t
   HIPIE_REQUIRE(value && shapes && lstart && a && w && out, "msda: null pointer");
   HIPIE_REQUIRE((long)B * S * M * D < (1L << 40), "msda: tensor too large");
   HIPIE_REQUIRE(off_stride >= (long)M * L * P * 2 && w_stride >= (long)M * L * P, "msda: row strides too small");
+  HIPIE_REQUIRE((long)S * (g_value_row > 0 ? g_value_row : (long)M * D) < (1L << 31), "msda: one image's value block exceeds the 32-bit sample offsets");
   HIPIE_REQUIRE(g_value_row == 0 || (g_value_row >= (long)M * D && g_value_row % 8 == 0), "msda: value row stride %ld < M*D or not a multiple of 8", g_value_row);
   if (FUSED) {
     HIPIE_REQUIRE(ref != nullptr && (ref_dim == 2 || ref_dim == 4), "msda_fused: ref_dim must be 2 or 4 (got %d)", ref_dim);

@@ -169,12 +169,14 @@ extern "C" int hipie_batched_nms(const float* boxes, const int64_t* classes, con
   const int W = (Q + 63) >> 6;
   const size_t smem = sizeof(float) * (4 * NMS_MAXQ + NMS_MAXQ) + sizeof(int) * NMS_MAXQ + sizeof(float) * 16 +
                       sizeof(unsigned long long) * (size_t)Q * W;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {false};               // the attribute is per device
+  int dev = -1;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(batched_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return set_err(HIPIE_ELAUNCH, "batched_nms: cannot raise the dynamic LDS limit");
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   batched_nms_kernel<<<B, NMS_THREADS, smem, (hipStream_t)stream>>>(boxes, classes, order, keep, count, Q, iou_threshold,
                                                                    coordinate_trick);

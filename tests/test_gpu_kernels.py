@@ -611,3 +611,64 @@ def test_decoder_glue_layernorm_dec_and_add_cast(dt, ddt):
     n32b, none16, nones = ops.add_layernorm_dec(x, delta, w, b, 1e-5, dt)
     assert none16 is None and nones is None and torch.equal(n32b, n32)
     assert torch.equal(ops.add_cast(x, qp), (x + qp.float()).to(dt))
+
+
+@pytest.mark.parametrize("nq", [910, 300])
+def test_decoder_self_attention_at_query_counts(nq):
+    """the decoder self-attention (nn.MultiheadAttention semantics, q = k = tgt + pos, v = tgt; deformable_transformer_dino.py
+    :435-436) on hipie_flash_attn at the two query counts of the path -- 910 (900 + 10 background queries, DINO decoder) and
+    300 (MaskDINO decoder) -- against the oracle's fp32 formulation.  fp16 operands: 1e-3."""
+    import oracle.model as om
+    from hipie_amd.modeling.transformer import MultiheadAttention
+    torch.manual_seed(nq)
+    m = MultiheadAttention(256, 8, torch.float16).to(DEV)
+    m.in_proj_bias.data.normal_(0, 0.1)
+    x_v = torch.randn(2, nq, 256)
+    x_qk = x_v + torch.randn(2, nq, 256)
+    sd = {"sa." + k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    want = om.mha(x_qk, x_v, sd, "sa.")
+    got = m(x_qk.to(DEV), x_v.to(DEV)).float().cpu()
+    assert rel_err(got, want) < 1e-3
+    # the 16-bit policy's weights (the fused decoder path): within the fp16 operand tolerance
+    m16 = MultiheadAttention(256, 8, torch.float16).to(DEV)
+    m16.load_state_dict(m.state_dict())
+    m16.in_proj_weight.data = m16.in_proj_weight.data.half()
+    m16.in_proj_bias.data = m16.in_proj_bias.data.half()
+    m16.out_proj.weight.data = m16.out_proj.weight.data.half()
+    m16.out_proj.bias.data = m16.out_proj.bias.data.half()
+    got16 = m16(x_qk.to(DEV).half(), x_v.to(DEV).half()).float().cpu()
+    assert rel_err(got16, want) < 4e-3
+
+
+def test_decoder_layer_fast_path_matches_oracle():
+    """DeformableTransformerDecoderLayer.forward16 (fp32 stream, 16-bit GEMMs, fused LayerNorm outputs, value block of a batched
+    projection) against the oracle's decoder_layer in fp32, 300 queries, 4 levels."""
+    import oracle.model as om
+    from hipie_amd.modeling.transformer import (DeformableTransformerDecoderLayer, batched_decoder_values, cast_head, level_tensors)
+    torch.manual_seed(5)
+    dt = torch.float16
+    layers = torch.nn.ModuleList([DeformableTransformerDecoderLayer(256, 512, 4, 8, 4, dt, dt) for _ in range(3)]).to(DEV)
+    for l in layers:
+        for p in l.parameters():
+            if p.dim() == 1:
+                p.data.normal_(0, 0.1)
+        l.cross_attn.sampling_offsets.weight.data.normal_(0, 0.05)
+        l.cross_attn.attention_weights.weight.data.normal_(0, 0.2)
+        for n in (l.norm1, l.norm2, l.norm3):
+            n.weight.data.fill_(1.0).add_(0.05 * torch.randn(256, device=DEV))
+    sd32 = [{k: v.detach().float().cpu().clone() for k, v in l.state_dict().items()} for l in layers]
+    cast_head(layers, dt, dt)
+    shapes = [(16, 24), (8, 12), (4, 6), (2, 3)]
+    S = sum(h * w for h, w in shapes)
+    B, Q = 2, 300
+    src = torch.randn(B, S, 256)
+    tgt, qpos = torch.randn(B, Q, 256), torch.randn(B, Q, 256) * 0.5
+    refs = torch.rand(B, Q, 4, 4) * 0.5 + 0.25
+    ss, ls = level_tensors(shapes, torch.device(DEV))
+    values = batched_decoder_values(layers, layers, src.to(DEV).to(dt), None)
+    lid = 1                                                                            # a middle column block of the batched GEMM
+    t32, t16 = layers[lid].forward16(tgt.to(DEV), tgt.to(DEV).to(dt), qpos.to(DEV).to(dt), refs.to(DEV), values[lid], ss, ls)
+    sd = {"l." + k: v for k, v in sd32[lid].items()}
+    want = om.decoder_layer(tgt, qpos.to(dt).float(), refs, src, shapes, None, sd, "l.")
+    assert rel_err(t32.float().cpu(), want) < 4e-3
+    assert torch.equal(t16, t32.to(dt))
