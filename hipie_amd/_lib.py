@@ -41,6 +41,7 @@ SIGNATURES = {
     "hipie_box_refine": [c_p, c_p, c_p, c_l, c_f, c_i, c_p],
     "hipie_add_layernorm_dec": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_i, c_i, c_p],
     "hipie_add_cast": [c_p, c_p, c_p, c_l, c_i, c_p],
+    "hipie_group_norm": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_p],
     "hipie_selftest": [c_i, c_p, c_p, c_p, c_p],
 }
 

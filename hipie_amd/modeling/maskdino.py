@@ -29,8 +29,7 @@ class NormConv2d(PConv2d):
         self.relu = relu
 
     def forward(self, x):
-        x = self.norm(super().forward(x))
-        return F.relu(x) if self.relu else x
+        return self.norm(super().forward(x), relu=self.relu)          # the ReLU rides in the GroupNorm pass
 
 
 class FoldedMaskFeatures(object):
@@ -92,6 +91,17 @@ class MaskDINOEncoder(nn.Module):
         self.layer_1 = NormConv2d(cd, cd, 3, padding=1, relu=True)
         self.precision = precision
 
+    def _mask_features_front(self, z, out_dtype=None):
+        """ConvTranspose2d -> GroupNorm -> ReLU of the mask_features head (maskdino_encoder.py:289-292): the transposed conv runs
+        without its bias, which enters the GroupNorm pass as a per-channel pre-bias together with the ReLU (one read + one write
+        of the (B,256,H/4,W/4) map instead of the bias, norm and ReLU passes)."""
+        ct, gn = self.mask_features[0], self.mask_features[1]
+        z = z.contiguous()              # NCHW in, NCHW out: the map leaves pixel-fastest, the mask contraction's operand layout
+        y = F.conv_transpose2d(z.to(ct.weight.dtype), ct.weight, None, ct.stride, ct.padding, ct.output_padding, ct.groups, ct.dilation)
+        if out_dtype is not None:
+            y = y.to(out_dtype)
+        return gn(y, relu=True, prebias=ct.bias.float())
+
     def forward_features(self, features, masks=None):
         f3, f4, f5 = features["res3"], features["res4"], features["res5"]      # the projections cast / lay out their input
         extra = self.input_proj[3](f5)
@@ -111,12 +121,11 @@ class MaskDINOEncoder(nn.Module):
             # 16-bit policies: stop in front of the head's last 1x1 convolution.  mask logits = emb . (W x + b) = (emb . W) . x +
             # emb . b, so that convolution folds into the (tiny) query side of the contraction (forward_prediction_heads): no
             # (B,256,H/4,W/4) GEMM, no fp32 round trips; x leaves NCHW (pixel fastest, the contraction's operand layout) in `act`
-            x = self.mask_features[2](self.mask_features[1](self.mask_features[0](z.to(self.mask_features[0].weight.dtype))))
+            x = self._mask_features_front(z)
             conv = self.mask_features[3]
             mf = FoldedMaskFeatures(x.to(self.precision.act).contiguous(), conv.weight.reshape(conv.weight.shape[0], -1), conv.bias)
         else:
-            mf = self.mask_features[0](z.to(self.mask_features[0].weight.dtype)).float()
-            mf = self.mask_features[3](self.mask_features[2](self.mask_features[1](mf)))
+            mf = self.mask_features[3](self._mask_features_front(z, torch.float32))
             mf = mf.float().contiguous()  # NCHW fp32, pixel fastest: hipie_mask_einsum's operand layout, produced once for both calls
         return mf, out[0], out          # mask_features (B,256,H/4,W/4), s8 level, [s8,s16,s32,s64]
 

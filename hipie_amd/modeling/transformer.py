@@ -63,8 +63,16 @@ class PLayerNorm(nn.LayerNorm):
 
 
 class PGroupNorm(nn.GroupNorm):
-    def forward(self, x):
-        return F.group_norm(x, self.num_groups, self.weight.to(x.dtype), self.bias.to(x.dtype), self.eps)
+    """GroupNorm on whatever activation dtype / memory format arrives (fp32 parameters and statistics): hipie_group_norm for
+    GroupNorm(32, 256) on the GPU, optionally with the ReLU that follows and a per-channel bias that precedes it."""
+
+    def forward(self, x, relu=False, prebias=None):
+        if self.weight.dtype == torch.float32 and ops.group_norm_ok(x, self.num_groups):
+            return ops.group_norm(x, self.num_groups, self.weight, self.bias, self.eps, relu=relu, prebias=prebias)
+        if prebias is not None:
+            x = x + prebias.view(1, -1, 1, 1).to(x.dtype)
+        y = F.group_norm(x, self.num_groups, self.weight.to(x.dtype), self.bias.to(x.dtype), self.eps)
+        return F.relu(y) if relu else y
 
 
 def cast_head(module, dtype, act=torch.float32):

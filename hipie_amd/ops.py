@@ -369,6 +369,38 @@ def add_layernorm_dec(x, delta, weight, bias, eps, aux_dtype, want16=False, adde
     return out, n16, s16
 
 
+_GN_WS = {}
+
+
+def group_norm_ok(x, groups):
+    if not x.is_cuda or x.dim() != 4 or x.dtype not in _DT or x.shape[1] != groups * 8 or groups > 64 or 256 % groups:
+        return False
+    return x.is_contiguous(memory_format=torch.channels_last) or (x.is_contiguous() and (x.shape[2] * x.shape[3]) % 8 == 0)
+
+
+@_timed("group_norm")
+def group_norm(x, groups, weight, bias, eps, relu=False, prebias=None, out_dtype=None):
+    """GroupNorm(groups, C = 8 * groups)(x + prebias[c]) (+ ReLU) on a (B,C,H,W) tensor in the memory format it arrives in
+    (channels-last stays channels-last: no NHWC -> NCHW copy); fp32 statistics."""
+    lib = _lib.load()
+    B, C, H, W = x.shape
+    nhwc = x.is_contiguous(memory_format=torch.channels_last) and not (x.is_contiguous() and C > 1 and H * W > 1)
+    if not nhwc and not x.is_contiguous():
+        raise RuntimeError("group_norm: x must be NCHW- or channels-last-contiguous")
+    out_dtype = out_dtype or x.dtype
+    out = torch.empty_like(x, dtype=out_dtype)            # preserves the memory format
+    key = (str(x.device), B * groups)
+    ws = _GN_WS.get(key)
+    if ws is None:
+        ws = _GN_WS[key] = torch.empty(2 * B * groups * 512, dtype=torch.float32, device=x.device)
+    rc = lib.hipie_group_norm(x.data_ptr(), None if prebias is None else _chk(prebias, "prebias", torch.float32),
+                              _chk(weight, "weight", torch.float32), _chk(bias, "bias", torch.float32), out.data_ptr(),
+                              ws.data_ptr(), B, C, H * W, groups, 1 if nhwc else 0, float(eps), 1 if relu else 0,
+                              _DT[x.dtype], _DT[out_dtype], _stream())
+    _lib.check(rc, "hipie_group_norm")
+    return out
+
+
 @_timed("add_cast")
 def add_cast(a, b):
     """(a f32 + b 16-bit) rounded once to b's dtype; same shapes, numel % 4 == 0."""

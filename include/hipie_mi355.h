@@ -241,6 +241,18 @@ int hipie_add_layernorm_dec(const float* x, const void* delta, const float* gamm
                             void* norm16_out, const void* addend, void* sum16_out, int64_t rows, int C, float eps,
                             int delta_dtype, int aux_dtype, void* stream);
 
+/*
+ * GroupNorm with 8 channels per group (GroupNorm(32, 256) of every conv + GN block after the backbone: input_proj of both heads,
+ * deformable_detr.py:139-160; the pixel decoder's lateral / output convs and mask_features head, maskdino_encoder.py:262-300),
+ * on the layout the tensor arrives in, with an optional per-channel pre-bias (y = GN(x + prebias[c])) and an optional ReLU.
+ *   x, out (B, C, H*W) when channels_last == 0, (B, H*W, C) when 1;  workspace: 2 * B * groups * 512 floats (partial sums);
+ *   gamma, beta (C) f32;  statistics fp32 (sum / sum of squares per group, biased variance, eps inside the sqrt).
+ *   C == 8 * groups, 256 % groups == 0;  NCHW: H*W % 8 == 0.  Two launches, no atomics (deterministic).
+ */
+int hipie_group_norm(const void* x, const float* prebias, const float* gamma, const float* beta, void* out, float* workspace,
+                     int B, int C, int HW, int groups, int channels_last, float eps, int relu, int x_dtype, int out_dtype,
+                     void* stream);
+
 /* out = (dtype)(a + b): a (n) f32, b (n) `dtype` f16 | bf16 -- `tgt + query_pos` rounded once to the GEMM operand type. */
 int hipie_add_cast(const float* a, const void* b, void* out, int64_t n, int dtype, void* stream);
 

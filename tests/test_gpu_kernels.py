@@ -672,3 +672,29 @@ def test_decoder_layer_fast_path_matches_oracle():
     want = om.decoder_layer(tgt, qpos.to(dt).float(), refs, src, shapes, None, sd, "l.")
     assert rel_err(t32.float().cpu(), want) < 4e-3
     assert torch.equal(t16, t32.to(dt))
+
+
+@pytest.mark.parametrize("shape,nhwc,dt,odt,relu,pre", [((2, 256, 16, 24), True, torch.float16, torch.float16, False, False),
+                                                         ((3, 256, 33, 17), True, torch.float32, torch.float32, True, True),
+                                                         ((2, 256, 32, 32), False, torch.float16, torch.float16, True, True),
+                                                         ((1, 256, 128, 128), False, torch.float32, torch.float32, False, False),
+                                                         ((2, 256, 8, 8), True, torch.bfloat16, torch.float32, True, False)])
+def test_group_norm(shape, nhwc, dt, odt, relu, pre):
+    """hipie_group_norm vs torch (fp32 reference of the same op) in both memory formats, with the fused pre-bias and ReLU."""
+    import torch.nn.functional as F
+    from hipie_amd import ops
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(shape, generator=gen) * 2 + 0.5).to(dt)
+    w, b = 1 + 0.2 * torch.randn(256, generator=gen), 0.2 * torch.randn(256, generator=gen)
+    pb = torch.randn(256, generator=gen) if pre else None
+    xin = x.to(DEV)
+    if nhwc:
+        xin = xin.contiguous(memory_format=torch.channels_last)
+    got = ops.group_norm(xin, 32, w.to(DEV), b.to(DEV), 1e-5, relu=relu, prebias=None if pb is None else pb.to(DEV), out_dtype=odt)
+    assert got.is_contiguous(memory_format=torch.channels_last if nhwc else torch.contiguous_format)
+    xr = x.float() + (0 if pb is None else pb.view(1, -1, 1, 1))
+    want = F.group_norm(xr, 32, w, b, 1e-5)
+    if relu:
+        want = F.relu(want)
+    tol = 2e-5 if odt == torch.float32 else 1.5e-3
+    assert rel_err(got.float().cpu(), want) < tol

@@ -29,4 +29,7 @@ run(dataclasses.replace(base, value=f32), "fast value=f32")
 run(dataclasses.replace(base, gemm=f32), "fast gemm(vit)=f32")
 run(dataclasses.replace(base, head=f32, act=f32), "fast head=f32 act=f32")
 run(dataclasses.replace(base, head=f32, act=f32, value=f32), "fast head,act,value=f32")
-run(dataclasses.replace(base, einsum=0), "fast einsum=0")
+run(dataclasses.replace(base, act=f32, einsum=0), "fast act=f32 einsum=0")
+run(dataclasses.replace(base, text=f32), "fast text=f32")
+run(dataclasses.replace(base, attn_fast=False), "fast attn exact")
+run(dataclasses.replace(base, gemm=f32, text=f32), "fast gemm(vit),text=f32")
