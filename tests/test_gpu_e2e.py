@@ -84,7 +84,7 @@ def test_e2e_tiny_free_topk_overlap():
 
 @pytest.mark.parametrize("task", ["detection", "grounding"])
 def test_e2e_tiny_fast_policy(task):
-    """the policy bench.py times (fp16 operands, fp32 accumulation and residual stream): every a22 output within 6e-3
+    """the policy bench.py times (fp16 operands, fp32 accumulation and residual stream): every a22 output within 8e-3
     (a 16-bit operand pipeline of this depth does not reach the parity policy's 1e-3: tools/prec_matrix.py shows every stage
     contributing 1-3e-3; bf16 is at 2-3e-2)."""
     from hipie_amd.config import Precision
@@ -94,7 +94,7 @@ def test_e2e_tiny_fast_policy(task):
     errs = {k: rel_err(g.like(task + "_" + k, out[k].float().cpu()), g[task + "_" + k]) for k in KEYS}
     print("fast policy %s: " % task + " ".join("%s=%.1e" % kv for kv in errs.items()))
     for k in KEYS:
-        assert errs[k] < 6e-3, (k, errs[k])
+        assert errs[k] < 8e-3, (k, errs[k])
 
 
 def test_e2e_tiny_bf16_policy():
@@ -111,7 +111,7 @@ def test_e2e_tiny_bf16_policy():
 def test_e2e_r50_tiny():
     """the R50 configs (BASELINE configs[0]/[1]): MIOpen ResNet-50 + the same HIP heads; parity then fast policy."""
     from hipie_amd.config import Precision
-    for prec, tol in ((Precision.parity(), 1e-3), (Precision.fast(), 6e-3), (Precision.bf16(), 8e-2)):
+    for prec, tol in ((Precision.parity(), 1e-3), (Precision.fast(), 8e-3), (Precision.bf16(), 8e-2)):
         g, model = build(prec, "e2e_r50_tiny")
         model.pin_topk(g["detection_topk_fg"], g["detection_topk_md"])
         out = model.forward_raw(inputs(g, "detection"))
