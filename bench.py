@@ -214,7 +214,7 @@ def main():
     from hipie_amd import ops, parallel
     from hipie_amd.config import HipieConfig, Precision
     from hipie_amd.hipie_img import HIPIE_IMG
-    from hipie_amd.postprocess import inference
+    from hipie_amd.postprocess import inference, inference_compact
 
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:
@@ -246,10 +246,11 @@ def main():
 
     def local_step():
         out = model.forward_raw(batch)
-        # the step ends at the compact per-image predictions that the data-parallel all-gather carries;
-        # instance masks and the semantic/panoptic maps of the full post-processing are timed separately below
-        res = inference(model, out, batch, with_masks=False, with_sem_pan=False)
-        return parallel.compact_predictions(res, topk=100, device=dev)
+        # the step ends at the compact per-image predictions that the data-parallel all-gather carries: class
+        # scores, NMS, top-100, box scaling -- built on the device without a host round trip (postprocess.inference_compact ==
+        # compact_predictions(inference(...)), tests/test_gpu_post.py); instance masks and the semantic / panoptic maps of the
+        # full post-processing are timed separately below
+        return inference_compact(model, out, batch, topk=100)
 
     def step():
         return parallel.all_gather_predictions(local_step())
@@ -275,8 +276,7 @@ def main():
 
             def step():  # noqa: F811
                 graph.replay()
-                res = inference(model, gout, batch, with_masks=False, with_sem_pan=False)
-                return parallel.all_gather_predictions(parallel.compact_predictions(res, topk=100, device=dev))
+                return parallel.all_gather_predictions(inference_compact(model, gout, batch, topk=100))
             step()
             torch.cuda.synchronize()
         except Exception as e:          # fall back to eager launches, say so in the JSON line
@@ -338,8 +338,7 @@ def main():
                 pm.finalize()
 
                 def pstep():
-                    res = inference(pm, pm.forward_raw(batch), batch, with_masks=False, with_sem_pan=False)
-                    return parallel.compact_predictions(res, topk=100, device=dev)
+                    return inference_compact(pm, pm.forward_raw(batch), batch, topk=100)
                 pstep()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()

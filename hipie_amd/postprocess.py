@@ -167,10 +167,10 @@ def _segments_info(tables):
 
 # ------------------------------------------------------------------------------------------------ the entry point
 @torch.no_grad()
-def inference(model, out, batched_inputs, do_postprocess=True, with_masks=True, with_sem_pan=True):
-    """a22 dictionary -> list of {"instances": Instances, "panoptic_seg": (label map, segments_info), "sem_seg"} like
-    HIPIE_IMG.forward's eval branch (hipie_img.py:313-362).  with_masks / with_sem_pan False skip the instance masks /
-    the semantic + panoptic maps (e.g. a detection-only consumer, or the compact all-gather block of parallel.py)."""
+def _instances_on_device(model, out, batched_inputs, do_postprocess=True):
+    """the batched, device-side part of HIPIE_IMG.inference (hipie_img.py:600-668 + segmentation_postprocess): class scores,
+    NMS, the per-image top-k over (kept query, class), boxes scaled / clipped to the output size.  No host synchronisation:
+    every per-image quantity is a row of a (B, K) tensor and `ok` marks the rows that are instances."""
     cfg = model.cfg
     if getattr(model, "enable_clip", False):
         raise NotImplementedError("MaskCLIP score fusion (MODEL.CLIP.ENABLED) is not part of this build (SURVEY 8f-2)")
@@ -229,6 +229,40 @@ def inference(model, out, batched_inputs, do_postprocess=True, with_masks=True, 
         nonempty = torch.ones(boxes.shape[:2], dtype=torch.bool, device=dev)
     n_inst = torch.minimum(count.long() * C, count.new_tensor(K).long())         # num_inst = min(max_num_inst, prob.numel())
     ok = (torch.arange(K, device=dev)[None, :] < n_inst[:, None]) & nonempty
+    return {"boxes": boxes, "scores": top_v, "labels": labels, "query": top_q, "ok": ok, "keep": keep_l, "count": count, "logits": logits,
+            "pred_masks": pred_masks, "image_sizes": image_sizes, "out_sizes": out_sizes, "out_sizes_inst": out_sizes_inst,
+            "pmap": pmap, "C": C, "is_thing": is_thing, "task": task}
+
+
+def inference_compact(model, out, batched_inputs, topk=100, do_postprocess=True):
+    """the (B, topk, 7) block of parallel.compact_predictions(inference(..., with_masks=False, with_sem_pan=False), topk)
+    -- [x0, y0, x1, y1, score, class, query index] per instance, score order, zero padded -- built entirely on the device:
+    the instances are packed to the front of every row with a stable sort instead of a host round trip, so a data-parallel
+    evaluation loop never synchronises with the host between the forward and the all-gather."""
+    d = _instances_on_device(model, out, batched_inputs, do_postprocess)
+    ok = d["ok"]
+    B, K = ok.shape
+    order = torch.sort((~ok).to(torch.int8), dim=1, stable=True)[1]                  # instances first, original (score) order kept
+    rows = torch.cat([d["boxes"], d["scores"][:, :, None], d["labels"][:, :, None].float(), d["query"][:, :, None].float()], 2)
+    rows = torch.where(ok[:, :, None], rows, rows.new_zeros(()))
+    rows = torch.gather(rows, 1, order[:, :, None].expand(-1, -1, rows.shape[2]))
+    if K >= topk:
+        return rows[:, :topk].contiguous()
+    return torch.cat([rows, rows.new_zeros(B, topk - K, rows.shape[2])], 1)
+
+
+def inference(model, out, batched_inputs, do_postprocess=True, with_masks=True, with_sem_pan=True):
+    """a22 dictionary -> list of {"instances": Instances, "panoptic_seg": (label map, segments_info), "sem_seg"} like
+    HIPIE_IMG.forward's eval branch (hipie_img.py:313-362).  with_masks / with_sem_pan False skip the instance masks /
+    the semantic + panoptic maps (e.g. a detection-only consumer, or the compact all-gather block of parallel.py)."""
+    d = _instances_on_device(model, out, batched_inputs, do_postprocess)
+    cfg = model.cfg
+    s = cfg.mask_stride
+    boxes, top_v, labels, top_q, ok, keep_l, count, logits = (d[k] for k in ("boxes", "scores", "labels", "query", "ok", "keep", "count", "logits"))
+    pred_masks, image_sizes, out_sizes, out_sizes_inst = d["pred_masks"], d["image_sizes"], d["out_sizes"], d["out_sizes_inst"]
+    pmap, C, is_thing, task = d["pmap"], d["C"], d["is_thing"], d["task"]
+    B = len(image_sizes)
+    dev = boxes.device
     ok_h, count_h = ok.cpu(), None                                               # the one host sync of the instance path
     results = []
     tables = []

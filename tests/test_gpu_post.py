@@ -183,3 +183,28 @@ def test_sem_pan_no_query_kept():
     cls = torch.full((20, 5), 0.2).cuda()
     sem, idx, own, area = ops.sem_pan(masks, cls, torch.full((20,), -1.0).cuda(), 4, (64, 64), (64, 64), 0)
     assert (idx == -1).all() and not own.any() and torch.isfinite(sem).all()
+
+
+@pytest.mark.parametrize("task,topk", [("detection", 100), ("detection", 7), ("grounding", 100)])
+def test_inference_compact_equals_host_path(task, topk):
+    """the device-only compact block of the data-parallel step == compact_predictions(inference(...)): same instances, same
+    order, same zero padding -- including images whose clipped boxes go empty (dropped in the middle of the score order)."""
+    from hipie_amd import parallel
+    from hipie_amd.postprocess import inference, inference_compact
+    sizes = [(384, 512), (512, 448), (256, 256)]
+    nbg, nfg, nmd, L, ncls = 10, 300, 120, 64, 9
+    a22 = _synth.synth_a22(sizes, nbg, nfg, nmd, L, seed=321)
+    a22["pred_boxes"][1, nbg:nbg + 150, 2:] = 0.0                      # zero-size boxes: non-empty filter drops them after scaling
+    _, _, pmap = _synth.synth_token_ids(3, ncls, L, seed=74)
+    is_thing = {c + 1: (c % 3 == 0) for c in range(ncls)}
+    out = {k: v.cuda() for k, v in a22.items()}
+    out["image_sizes"] = sizes
+    batched = [{"task": task, "positive_map_label_to_token": pmap, "is_thing": is_thing, "height": 300 + 10 * i, "width": 333}
+               for i in range(len(sizes))]
+    model = fake_model(nbg)
+    want = parallel.compact_predictions(inference(model, out, batched, with_masks=False, with_sem_pan=False), topk=topk)
+    got = inference_compact(model, out, batched, topk=topk)
+    assert got.shape == want.shape == (3, topk, parallel.PRED_FIELDS)
+    assert torch.equal(got, want)
+    if task == "detection" and topk == 100:
+        assert int((want[1, :, 4] > 0).sum()) < int((want[0, :, 4] > 0).sum())        # the empty boxes of image 1 were dropped

@@ -41,3 +41,25 @@ for k, (d, n) in sorted(tot.items(), key=lambda x: -x[1][0])[:45]:
 print("\nelementwise / copy kernels by launch size (threads):")
 for (k, th), (d, n) in sorted(split.items(), key=lambda x: -x[1][0])[:30]:
     print("%9.2f ms %6d x %9.1f us  threads=%-10d %s" % (d / 1e6, n, d / n / 1e3, th, k))
+
+# idle gaps inside the window: where the GPU waits for the host (a synchronisation or a launch-bound stretch)
+gaps = []
+prev_end, prev_name = None, None
+for r in rows:
+    st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    if prev_end is not None and st > prev_end:
+        gaps.append((st - prev_end, prev_name, r["Kernel_Name"][:70]))
+    if prev_end is None or en > prev_end:
+        prev_end, prev_name = en, r["Kernel_Name"][:70]
+tot_gap = sum(g[0] for g in gaps)
+print("\nidle gaps: total %.2f ms in %d gaps; > 20 us: %.2f ms in %d gaps" % (
+    tot_gap / 1e6, len(gaps), sum(g[0] for g in gaps if g[0] > 20000) / 1e6, sum(1 for g in gaps if g[0] > 20000)))
+for d, a, b in sorted(gaps, key=lambda x: -x[0])[:25]:
+    print("%9.1f us  after %-70s before %s" % (d / 1e3, a, b))
+by_next = collections.defaultdict(lambda: [0, 0])
+for d, a, b in gaps:
+    by_next[b][0] += d
+    by_next[b][1] += 1
+print("\ngap time by the kernel that follows the gap:")
+for k, (d, n) in sorted(by_next.items(), key=lambda x: -x[1][0])[:20]:
+    print("%9.2f ms %6d x %7.1f us  %s" % (d / 1e6, n, d / n / 1e3, k))
