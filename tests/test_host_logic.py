@@ -381,3 +381,40 @@ def test_r50_fold_follows_a_checkpoint_load():
     want = c.norm(torch.nn.functional.conv2d(x, c.weight, None, stride=2, padding=3))
     got = c(x)
     assert torch.allclose(got, want, rtol=1e-4, atol=1e-5)
+
+
+def test_predictor_input_recipe(tmp_path):
+    """HIPIEPredictor.build_inputs (projects/HIPIE/predictor.py:324-371): output shape of ResizeShortestEdge on the sizes its
+    docstring-era users know (COCO 480x640 -> 800x1067; a 1:3.3 panorama is bound by MAX_SIZE_TEST), BGR -> RGB, CHW float32,
+    the dict keys of both tasks.  (fvcore is absent here, so detectron2's transform classes cannot be imported to pin this:
+    the arithmetic below is the reference's formula, the resampling is the same PIL call.)"""
+    import numpy as np
+    from hipie_amd.predictor import HIPIEPredictor, resize_shortest_edge_shape
+    assert resize_shortest_edge_shape(480, 640, 800, 1333) == (800, 1067)
+    assert resize_shortest_edge_shape(640, 480, 800, 1333) == (1067, 800)
+    assert resize_shortest_edge_shape(427, 640, 800, 1333) == (800, 1199)
+    assert resize_shortest_edge_shape(300, 1000, 800, 1333) == (400, 1333)
+    assert resize_shortest_edge_shape(1024, 1024, 1024, 1024) == (1024, 1024)
+
+    class Echo(object):
+        tokenizer = None
+
+        def __call__(self, batched):
+            return [batched[0]]
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 256, (30, 45, 3), dtype=np.uint8)
+    p = HIPIEPredictor(Echo(), min_size_test=60, max_size_test=80)
+    out = p(img, "grounding", expressions="the left cat")
+    assert out["image"].shape == (3, 53, 80) and out["image"].dtype == torch.float32       # 60/30 = 2 -> 90 > 80: bound by max
+    assert (out["height"], out["width"], out["task"], out["expressions"], out["is_thing"]) == (30, 45, "grounding", "the left cat", {1: True})
+    same = HIPIEPredictor(Echo(), min_size_test=30, max_size_test=45)(img, "grounding", expressions="x")
+    assert torch.equal(same["image"], torch.as_tensor(img[:, :, ::-1].copy()).permute(2, 0, 1).float())      # identity resize, BGR -> RGB
+    tok = _synth.prompt_tokenizer(tmp_path)                     # the small WordPiece vocabulary of the prompts golden
+    cats = _synth.PROMPT_CATEGORIES[:3]
+    det = HIPIEPredictor(Echo(), tokenizer=tok, min_size_test=30, max_size_test=45)(img, "detection", test_categories=cats)
+    from hipie_amd import prompts
+    caption, pmap = prompts.create_queries_and_maps(cats, tok)
+    assert det["expressions"] == caption and det["positive_map_label_to_token"] == pmap
+    assert det["is_thing"] == {i + 1: bool(c.get("isthing", 1)) for i, c in enumerate(cats)}
+    with pytest.raises(ValueError):
+        p(img, "sot")
