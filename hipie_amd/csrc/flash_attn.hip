@@ -639,6 +639,11 @@ extern "C" int hipie_vit_attn_fused(const void* qkv, const void* tab_h, const vo
   return flash_attn_impl(p, hd, dtype, stream);
 }
 
+namespace hipie {
+int xattn_i2t_try(const void* q, const void* k, const void* vl, const uint8_t* mask, void* out, int B, int H, int Nv, int L, int hd,
+                  long E, float clamp, int dtype, hipStream_t st);      // bi_xattn.hip
+}
+
 extern "C" int hipie_bi_xattn(const void* q, const void* k, const void* vv, const void* vl, const uint8_t* text_mask,
                               void* out_v, void* out_l, int B, int H, int Nv, int L, int hd, float clamp, int dtype,
                               void* stream) {
@@ -653,7 +658,9 @@ extern "C" int hipie_bi_xattn(const void* q, const void* k, const void* vv, cons
   a.k_sb = a.v_sb = (long)L * E; a.k_st = a.v_st = E; a.k_sh = a.v_sh = hd;
   a.o_sb = (long)Nv * E; a.o_st = E; a.o_sh = hd;
   a.key_mask = text_mask; a.scale = 1.f; a.clamp = clamp;
-  int rc = flash_attn_impl(a, hd, dtype, stream);
+  static const bool generic_only = getenv("HIPIE_XATTN_GENERIC") != nullptr;      // diagnostics: the flash kernel for both directions
+  int rc = generic_only ? 1 : xattn_i2t_try(q, k, vl, text_mask, out_v, B, H, Nv, L, hd, E, clamp, dtype, (hipStream_t)stream);
+  if (rc == 1) rc = flash_attn_impl(a, hd, dtype, stream);     // shapes the specialised kernel does not cover (L <= 64: one tile; L > 224)
   if (rc != HIPIE_OK) return rc;
   // text rows attend over ALL image tokens: softmax over Nv of the transposed scores, no mask (fuse_helper.py:86-95)
   FAParams t{};

@@ -698,3 +698,32 @@ def test_group_norm(shape, nhwc, dt, odt, relu, pre):
         want = F.relu(want)
     tol = 2e-5 if odt == torch.float32 else 1.5e-3
     assert rel_err(got.float().cpu(), want) < tol
+
+
+@pytest.mark.parametrize("L,nv,nvalid,dt,tol", [(194, 1300, 194, torch.float16, 1.5e-3), (194, 777, 150, torch.bfloat16, 1e-2),
+                                                (100, 300, 100, torch.float16, 1.5e-3), (224, 2000, 201, torch.float16, 1.5e-3),
+                                                (65, 256, 3, torch.float16, 1.5e-3)])
+def test_bi_xattn_short_text_kernel(L, nv, nvalid, dt, tol):
+    """the image -> text kernel for one short text (64 < L <= 224, head dim 256: the 80-class caption is 194 tokens): ragged
+    query tiles (nv % 256 != 0, several tiles per workgroup), padded text rows, a partial text mask, both block counts; against
+    the oracle's BiMultiHeadAttention core on the same 16-bit operands.  The text -> image half of the call runs the generic
+    kernel and is checked in the same breath."""
+    from hipie_amd import ops
+    gen = torch.Generator().manual_seed(L * 7 + nv)
+    B, Hh, hd = 2, 2, 256
+    q = (torch.randn(B, nv, Hh, hd, generator=gen) * 0.25).to(dt)
+    k = (torch.randn(B, L, Hh, hd, generator=gen) * 0.25).to(dt)
+    vv = torch.randn(B, nv, Hh, hd, generator=gen).to(dt)
+    vl = torch.randn(B, L, Hh, hd, generator=gen).to(dt)
+    mask = torch.zeros(B, L, dtype=torch.int64)
+    mask[0, :nvalid] = 1
+    mask[1, :max(1, nvalid // 2)] = 1
+
+    def split(t, n):
+        return t.float().transpose(1, 2).reshape(B * Hh, n, hd)
+    wv, wl = oo.bi_attention_core(split(q, nv), split(k, L), split(vv, nv), split(vl, L), mask)
+    wv = wv.view(B, Hh, nv, hd).transpose(1, 2).reshape(B, nv, Hh * hd)
+    wl = wl.view(B, Hh, L, hd).transpose(1, 2).reshape(B, L, Hh * hd)
+    ov, ol = ops.bi_xattn(q.to(DEV), k.to(DEV), vv.to(DEV), vl.to(DEV), mask.to(DEV))
+    assert rel_err(ov.float().cpu(), wv) < tol
+    assert rel_err(ol.float().cpu(), wl) < tol

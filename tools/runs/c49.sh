@@ -1,0 +1,3 @@
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 > gpurun_out/c49_test.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" > gpurun_out/c49_smoke.log 2>&1
