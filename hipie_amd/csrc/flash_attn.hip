@@ -27,6 +27,8 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <algorithm>
+
 #include "mfma.h"
 
 namespace hipie {
@@ -642,11 +644,24 @@ extern "C" int hipie_vit_attn_fused(const void* qkv, const void* tab_h, const vo
 namespace hipie {
 int xattn_i2t_try(const void* q, const void* k, const void* vl, const uint8_t* mask, void* out, int B, int H, int Nv, int L, int hd,
                   long E, float clamp, int dtype, hipStream_t st);      // bi_xattn.hip
+int xattn_t2i_try(const void* q, const void* k, const void* vv, void* out, float* ws, size_t ws_bytes, int B, int H, int Nv, int L,
+                  int hd, long E, float clamp, int dtype, hipStream_t st);
+size_t xattn_t2i_workspace(int B, int H, int Nv, int L, int hd);
+}
+
+extern "C" int64_t hipie_bi_xattn_workspace(int B, int H, int Nv, int L, int hd) {
+  return (int64_t)hipie::xattn_t2i_workspace(B, H, Nv, L, hd);
 }
 
 extern "C" int hipie_bi_xattn(const void* q, const void* k, const void* vv, const void* vl, const uint8_t* text_mask,
                               void* out_v, void* out_l, int B, int H, int Nv, int L, int hd, float clamp, int dtype,
                               void* stream) {
+  return hipie_bi_xattn_ws(q, k, vv, vl, text_mask, out_v, out_l, nullptr, 0, B, H, Nv, L, hd, clamp, dtype, stream);
+}
+
+extern "C" int hipie_bi_xattn_ws(const void* q, const void* k, const void* vv, const void* vl, const uint8_t* text_mask,
+                                 void* out_v, void* out_l, void* workspace, int64_t workspace_bytes, int B, int H, int Nv, int L,
+                                 int hd, float clamp, int dtype, void* stream) {
   using namespace hipie;
   HIPIE_REQUIRE(q && k && vv && vl && out_v && out_l, "bi_xattn: null pointer");
   const long E = (long)H * hd;
@@ -670,5 +685,8 @@ extern "C" int hipie_bi_xattn(const void* q, const void* k, const void* vv, cons
   t.k_sb = t.v_sb = (long)Nv * E; t.k_st = t.v_st = E; t.k_sh = t.v_sh = hd;
   t.o_sb = (long)L * E; t.o_st = E; t.o_sh = hd;
   t.key_mask = nullptr; t.scale = 1.f; t.clamp = clamp;
+  rc = generic_only ? 1 : xattn_t2i_try(q, k, vv, out_l, (float*)workspace, (size_t)std::max<int64_t>(workspace_bytes, 0), B, H, Nv, L, hd,
+                                        E, clamp, dtype, (hipStream_t)stream);
+  if (rc != 1) return rc;
   return flash_attn_impl(t, hd, dtype, stream);
 }

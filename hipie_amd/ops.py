@@ -231,6 +231,9 @@ def vit_attn_rel(qkv, tab_h, tab_w, grid_hw, heads, fast=False):
     return out
 
 
+_XA_WS = {}
+
+
 @_timed("bi_xattn")
 def bi_xattn(q, k, vv, vl, text_mask, clamp=50000.0):
     """q, vv (B,Nv,H,hd); k, vl (B,L,H,hd) 16-bit contiguous; text_mask (B,L) -> out_v (B,Nv,H*hd), out_l (B,L,H*hd)."""
@@ -240,8 +243,16 @@ def bi_xattn(q, k, vv, vl, text_mask, clamp=50000.0):
     text_mask = text_mask.to(torch.uint8).contiguous()
     out_v = torch.empty(B, Nv, H * hd, dtype=q.dtype, device=q.device)
     out_l = torch.empty(B, L, H * hd, dtype=q.dtype, device=q.device)
-    rc = lib.hipie_bi_xattn(_chk(q, "q"), _chk(k, "k"), _chk(vv, "vv"), _chk(vl, "vl"), _chk(text_mask, "text_mask"),
-                            out_v.data_ptr(), out_l.data_ptr(), B, H, Nv, L, hd, float(clamp), _DT[q.dtype], _stream())
+    need = int(lib.hipie_bi_xattn_workspace(B, H, Nv, L, hd))          # split partials of the text -> image direction (0: none)
+    ws = None
+    if need > 0:
+        key = str(q.device)
+        ws = _XA_WS.get(key)
+        if ws is None or ws.numel() * 4 < need:
+            ws = _XA_WS[key] = torch.empty((need + 3) // 4, dtype=torch.float32, device=q.device)
+    rc = lib.hipie_bi_xattn_ws(_chk(q, "q"), _chk(k, "k"), _chk(vv, "vv"), _chk(vl, "vl"), _chk(text_mask, "text_mask"),
+                               out_v.data_ptr(), out_l.data_ptr(), None if ws is None else ws.data_ptr(), need, B, H, Nv, L, hd,
+                               float(clamp), _DT[q.dtype], _stream())
     _lib.check(rc, "hipie_bi_xattn")
     return out_v, out_l
 

@@ -130,6 +130,19 @@ int hipie_bi_xattn(const void* q, const void* k, const void* vv, const void* vl,
                    void* out_v, void* out_l, int B, int H, int Nv, int L, int hd, float clamp, int dtype, void* stream);
 
 /*
+ * hipie_bi_xattn with a caller-provided workspace (the library never allocates).  For one short text per image
+ * (64 < L <= 224, head dim 256: the class captions of the detection task) both directions run specialised kernels: image -> text
+ * as one softmax window over the resident text, text -> image with the text block in registers and the image range split over
+ * workgroups, whose partial (max, sum, accumulator) triples live in `workspace` until a combine kernel reduces them.
+ * hipie_bi_xattn_workspace returns the bytes needed (0: the shape takes the generic kernel and needs none); a null / short
+ * workspace is not an error -- the text -> image direction then runs the generic kernel.
+ */
+int64_t hipie_bi_xattn_workspace(int B, int H, int Nv, int L, int head_dim);
+int hipie_bi_xattn_ws(const void* q, const void* k, const void* vv, const void* vl, const uint8_t* text_mask,
+                      void* out_v, void* out_l, void* workspace, int64_t workspace_bytes, int B, int H, int Nv, int L,
+                      int head_dim, float clamp, int dtype, void* stream);
+
+/*
  * Mask-logit contraction  out[b,q,p] = sum_c embed[b,q,c] * feats[b,c,p].
  * Replaces: torch.einsum("bqc,bchw->bqhw") in MaskDINODecoder.forward_prediction_heads
  *           (models/maskdino/transformer_decoder/maskdino_decoder.py:520-529).
