@@ -134,14 +134,15 @@ class BertModel(nn.Module):
         heads = self.encoder.layer[0].attention.self.heads
         hd = C // heads
         kmask = attention_mask.to(torch.uint8).contiguous()
+        x16 = x.to(dt)
         for layer, (wqkv, bqkv) in zip(self.encoder.layer, self._fused):
-            qkv = F.linear(x.to(dt), wqkv, bqkv).view(B, L, 3, heads, hd)
+            qkv = F.linear(x16, wqkv, bqkv).view(B, L, 3, heads, hd)
             ctx = ops.flash_attn(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 1.0 / math.sqrt(hd), key_mask=kmask)
-            so = layer.attention.output
-            x = ops.add_layernorm(x, so.dense(ctx), so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.eps, f32, want_res=False)[1]
+            so = layer.attention.output                       # the LayerNorm pass also emits the 16-bit GEMM operand
+            x, x16, _ = ops.add_layernorm_dec(x, so.dense(ctx), so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.eps, dt, want16=True)
             oo = layer.output
-            x = ops.add_layernorm(x, oo.dense(F.gelu(layer.intermediate.dense(x.to(dt)))), oo.LayerNorm.weight, oo.LayerNorm.bias,
-                                  oo.LayerNorm.eps, f32, want_res=False)[1]
+            x, x16, _ = ops.add_layernorm_dec(x, oo.dense(F.gelu(layer.intermediate.dense(x16))), oo.LayerNorm.weight,
+                                              oo.LayerNorm.bias, oo.LayerNorm.eps, dt, want16=True)
         return x
 
     def forward(self, input_ids, attention_mask):

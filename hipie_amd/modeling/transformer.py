@@ -88,6 +88,9 @@ def cast_head(module, dtype, act=torch.float32):
             if isinstance(m, PConv2d) and dtype != torch.float32:
                 m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
                 m.nhwc = True
+        elif isinstance(m, MultiheadAttention):           # packed q/k/v projection (a bare Parameter, not a PLinear)
+            m.in_proj_weight.data = m.in_proj_weight.data.to(dtype)
+            m.in_proj_bias.data = m.in_proj_bias.data.to(dtype)
     return module
 
 

@@ -63,3 +63,7 @@ for d, a, b in gaps:
 print("\ngap time by the kernel that follows the gap:")
 for k, (d, n) in sorted(by_next.items(), key=lambda x: -x[1][0])[:20]:
     print("%9.2f ms %6d x %7.1f us  %s" % (d / 1e6, n, d / n / 1e3, k))
+
+print("\nkernels by launch count (per window):")
+for k, (d, n) in sorted(tot.items(), key=lambda x: -x[1][1])[:60]:
+    print("%6d x %9.1f us  %9.2f ms  %s" % (n, d / n / 1e3, d / 1e6, k))
