@@ -391,7 +391,7 @@ def main():
                                                        cfg.vit_embed_dim // cfg.vit_heads, ("NB2", "NB3")[args.size // 16 > 64], kern_n),
                          "achieved": None if ach is None else round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
                          "frac": None if ach is None else round(ach / 2500.0, 4), "traffic": traffic,
-                         "traffic_note": "bytes per launch, rocprofv3 PMC FETCH_SIZE (x2, guide correction) + WRITE_SIZE, separate passes: profiles/r02_pmc_attention.md",
+                         "traffic_note": "bytes per launch, rocprofv3 PMC FETCH_SIZE (x2, guide correction) + WRITE_SIZE, separate passes: profiles/r02_pmc.md",
                          "avg_launch_ms": None if not kern_ms else round(kern_ms, 4),
                          "flop_per_launch": flops},
             "postprocess_full_ms": None if post_ms is None else round(post_ms, 2),
