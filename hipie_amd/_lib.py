@@ -35,6 +35,7 @@ SIGNATURES = {
     "hipie_dynamic_mask16": [c_p, c_p, c_p, c_p] + [c_i] * 7 + [c_p],
     "hipie_vit_relpos": [c_p, c_p, c_p, c_p, c_p] + [c_i] * 6 + [c_p],
     "hipie_add_layernorm": [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_i, c_i, c_i, c_p],
+    "hipie_add_layernorm_sum": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_i, c_i, c_i, c_p],
     "hipie_add_layernorm_rows": [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_i, c_i, c_i, c_p, c_p, c_p],
     "hipie_batched_nms": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_i, c_p],
     "hipie_mask_finalize": [c_p, c_i, c_p] + [c_i] * 8 + [c_f, c_p, c_p],

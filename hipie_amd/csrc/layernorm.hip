@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const Tx* __restrict
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             Tx* __restrict__ res_out, Tn* __restrict__ norm_out, long rows,
                                                             int C, float eps, const int32_t* __restrict__ delta_row,
-                                                            const int32_t* __restrict__ out_src) {
+                                                            const int32_t* __restrict__ out_src, const Tn* __restrict__ addend,
+                                                            Tn* __restrict__ sum_out) {
   // row maps (both optional): the wave owns OUTPUT row `orow`; it normalises x row `row = out_src[orow]` (-1: the output row
   // is padding -> zeros, e.g. the pad tokens of window_partition) and adds delta row `delta_row[row]` (e.g. the window
   // layout the attention wrote) -- window partition / un-partition become index arithmetic of this pass
@@ -129,15 +130,25 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const Tx* __restrict
       o[2] = (v[i][2] - mean) * rstd * g.z + b.z;
       o[3] = (v[i][3] - mean) * rstd * g.w + b.w;
       V4<Tn>::st(norm_out + orow * C + c, o);
+      if (sum_out != nullptr) {               // the normalised row plus a second addend (e.g. the position embedding of the next query)
+        float a[4];
+        V4<Tn>::ld(addend + orow * C + c, a);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += o[e];
+        V4<Tn>::st(sum_out + orow * C + c, a);
+      }
     }
   }
 }
+
+static thread_local const void* g_ln_addend = nullptr;     // optional extra output of the call being dispatched (as the row maps)
+static thread_local void* g_ln_sum_out = nullptr;
 
 template <typename Tx, typename Td, typename Tn>
 static int launch_ln(const void* x, const void* d, const float* g, const float* b, void* r, void* n, long rows, int C,
                      float eps, hipStream_t st) {
   hipLaunchKernelGGL((add_layernorm_kernel<Tx, Td, Tn>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const Tx*)x,
-                     (const Td*)d, g, b, (Tx*)r, (Tn*)n, rows, C, eps, g_delta_row, g_out_src);
+                     (const Td*)d, g, b, (Tx*)r, (Tn*)n, rows, C, eps, g_delta_row, g_out_src, (const Tn*)g_ln_addend, (Tn*)g_ln_sum_out);
   return check_launch("add_layernorm");
 }
 
@@ -325,4 +336,17 @@ extern "C" int hipie_add_cast(const float* a, const void* b, void* out, int64_t 
   else
     hipLaunchKernelGGL((add_cast_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a, (const bf16_t*)b, (bf16_t*)out, n4);
   return check_launch("add_cast");
+}
+
+extern "C" int hipie_add_layernorm_sum(const void* x, const void* delta, const float* gamma, const float* beta, void* res_out,
+                                       void* norm_out, const void* addend, void* sum_out, int64_t rows, int C, float eps,
+                                       int x_dtype, int delta_dtype, int norm_dtype, void* stream) {
+  using namespace hipie;
+  HIPIE_REQUIRE((addend == nullptr) == (sum_out == nullptr), "add_layernorm_sum: addend and sum_out go together");
+  g_ln_addend = addend;
+  g_ln_sum_out = sum_out;
+  const int rc = hipie_add_layernorm(x, delta, gamma, beta, res_out, norm_out, rows, C, eps, x_dtype, delta_dtype, norm_dtype, stream);
+  g_ln_addend = nullptr;
+  g_ln_sum_out = nullptr;
+  return rc;
 }

@@ -68,8 +68,12 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
         spatial_shapes, level_start_index = level_tensors(shapes_list, src.device)
         refs = geo_cached(gk, "enc_refs", lambda: encoder_reference_points(
             shapes_list, torch.ones(B, len(srcs), 2, device=src.device), src.device))
-        for layer in self.encoder.layers:
-            src = layer(src, pos, refs, spatial_shapes, level_start_index, None)
+        q, n = None, len(self.encoder.layers)
+        for i, layer in enumerate(self.encoder.layers):
+            if i + 1 < n:                                 # the last LayerNorm pass of a layer also emits the next layer's src + pos
+                src, q = layer(src, pos, refs, spatial_shapes, level_start_index, None, query=q, want_query=True)
+            else:
+                src = layer(src, pos, refs, spatial_shapes, level_start_index, None, query=q)
         return src, shapes_list
 
 

@@ -409,11 +409,18 @@ class DeformableTransformerEncoderLayer(nn.Module):
         self.linear1, self.linear2 = PLinear(d_model, d_ffn), PLinear(d_ffn, d_model)
         self.norm2 = PLayerNorm(d_model)
 
-    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
-        src2 = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index, padding_mask)
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None, query=None, want_query=False):
+        """query: `src + pos` when the previous layer already produced it; want_query: also return the NEXT layer's `src + pos`,
+        emitted by the last LayerNorm pass (hipie_add_layernorm_sum) instead of a separate add over the 21760-token stream."""
+        q = src + pos if query is None else query
+        src2 = self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask)
         src = _add_norm(src, src2, self.norm1)
         src2 = self.linear2(self.linear1.forward_relu(src))
-        return _add_norm(src, src2, self.norm2)
+        if want_query and src.is_cuda and src.dtype == pos.dtype and src.dtype in ops._DT:
+            n = self.norm2
+            return ops.add_layernorm_sum(src.contiguous(), src2.to(src.dtype).contiguous(), n.weight, n.bias, n.eps, pos.contiguous())
+        out = _add_norm(src, src2, self.norm2)
+        return (out, None) if want_query else out
 
 
 def encoder_reference_points(spatial_shapes, valid_ratios, device):
@@ -443,10 +450,14 @@ class DeformableTransformerEncoderVL(nn.Module):
                 geo_key=None):
         output = {"visual": src, "lang": lang}
         refs = geo_cached(geo_key, "enc_refs", lambda: encoder_reference_points(shapes_list, valid_ratios, src.device))
-        for vl_layer, layer in zip(self.vl_layers, self.layers):
+        q, n = None, len(self.layers)
+        for i, (vl_layer, layer) in enumerate(zip(self.vl_layers, self.layers)):
             if not isinstance(vl_layer, nn.Identity):
                 output = vl_layer(output, task=task)
-            output["visual"] = layer(output["visual"], pos, refs, spatial_shapes, level_start_index, padding_mask)
+                q = None                                  # the fusion changed the stream: its `src + pos` is recomputed
+            nxt_plain = i + 1 < n and isinstance(self.vl_layers[i + 1], nn.Identity)
+            res = layer(output["visual"], pos, refs, spatial_shapes, level_start_index, padding_mask, query=q, want_query=nxt_plain)
+            output["visual"], q = res if nxt_plain else (res, None)
         return output
 
 

@@ -361,6 +361,22 @@ def add_layernorm(x, delta, weight, bias, eps, norm_dtype, want_res=True, delta_
 
 
 @_timed("add_layernorm")
+def add_layernorm_sum(x, delta, weight, bias, eps, addend):
+    """n = LayerNorm(x + delta) and n + addend, both in x's dtype, one launch (the encoder's post-norm + next `src + pos`)."""
+    lib = _lib.load()
+    C = x.shape[-1]
+    rows = x.numel() // C
+    if addend.dtype != x.dtype or addend.shape != x.shape:
+        raise RuntimeError("add_layernorm_sum: addend must match x")
+    out, s = torch.empty_like(x), torch.empty_like(x)
+    rc = lib.hipie_add_layernorm_sum(_chk(x, "x"), _chk(delta, "delta"), _chk(weight, "weight", torch.float32),
+                                     _chk(bias, "bias", torch.float32), None, out.data_ptr(), _chk(addend, "addend"), s.data_ptr(),
+                                     rows, C, float(eps), _DT[x.dtype], _DT[delta.dtype], _DT[x.dtype], _stream())
+    _lib.check(rc, "hipie_add_layernorm_sum")
+    return out, s
+
+
+@_timed("add_layernorm")
 def add_layernorm_dec(x, delta, weight, bias, eps, aux_dtype, want16=False, addend=None):
     """n = LayerNorm(x + delta) for the fp32 query stream of the decoders: returns (n f32, n in aux_dtype or None,
     (n + addend) in aux_dtype or None) from one launch.  x (..., C) f32; delta any of f32/f16/bf16; addend aux_dtype."""

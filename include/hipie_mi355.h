@@ -244,6 +244,15 @@ int hipie_add_layernorm_rows(const void* x, const void* delta, const float* gamm
                              int norm_dtype, const int32_t* delta_row, const int32_t* out_src, void* stream);
 
 /*
+ * hipie_add_layernorm with a second output  sum_out = norm_out + addend  (both `norm_dtype`, (rows, C)): the post-norm residual of
+ * a deformable ENCODER layer that also prepares the next layer's query `src + pos`
+ * (deformable_transformer_dino.py:384-394, with_pos_embed :380) in the same pass.
+ */
+int hipie_add_layernorm_sum(const void* x, const void* delta, const float* gamma, const float* beta, void* res_out,
+                            void* norm_out, const void* addend, void* sum_out, int64_t rows, int C, float eps,
+                            int x_dtype, int delta_dtype, int norm_dtype, void* stream);
+
+/*
  * The post-norm residual of a DINO decoder layer (deformable_transformer_dino.py:418-450 == dino_decoder.py:222-268) when the
  * query stream is fp32 and the GEMMs take 16-bit operands:  n = LayerNorm(x + delta) is written once in fp32 (norm_out, the next
  * residual) and, optionally and in the same pass, as norm16_out = (aux)n and sum16_out = (aux)(n + addend)  (addend = the

@@ -727,3 +727,21 @@ def test_bi_xattn_short_text_kernel(L, nv, nvalid, dt, tol):
     ov, ol = ops.bi_xattn(q.to(DEV), k.to(DEV), vv.to(DEV), vl.to(DEV), mask.to(DEV))
     assert rel_err(ov.float().cpu(), wv) < tol
     assert rel_err(ol.float().cpu(), wl) < tol
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+def test_add_layernorm_sum(dt):
+    """hipie_add_layernorm_sum: LayerNorm(x + delta) and LayerNorm(x + delta) + addend from one launch."""
+    import torch.nn.functional as F
+    from hipie_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 777, 256, generator=gen).to(DEV).to(dt)
+    d = torch.randn(2, 777, 256, generator=gen).to(DEV).to(dt)
+    pos = torch.randn(2, 777, 256, generator=gen).to(DEV).to(dt)
+    w, b = torch.randn(256, generator=gen).to(DEV), torch.randn(256, generator=gen).to(DEV)
+    n, s = ops.add_layernorm_sum(x, d, w, b, 1e-5, pos)
+    want = F.layer_norm(x.float() + d.float(), (256,), w, b, 1e-5)
+    tol = 2e-6 if dt == torch.float32 else 1e-3
+    assert rel_err(n.float().cpu(), want.cpu()) < tol
+    assert rel_err(s.float().cpu(), (want + pos.float()).cpu()) < tol
+    assert torch.equal(n, ops.add_layernorm(x, d, w, b, 1e-5, dt, want_res=False)[1])
