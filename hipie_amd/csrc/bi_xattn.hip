@@ -33,7 +33,6 @@ struct XAParams {
   int B, H, Nv, L;
   long q_sb, q_st, kv_sb, kv_st, o_sb, o_st;     // element strides: batch, token (head stride = 256)
   float clamp_l2;                        // clamp * log2(e), 0 = no clamp
-  int abl;                               // timing ablations (tools/bench_xattn.py, HIPIE_XA_ABL); 0 in production
 };
 
 template <typename T, int NKB>
@@ -115,10 +114,7 @@ __global__ __launch_bounds__(512) void xattn_i2t_kernel(XAParams p) {
       for (int r = 0; r < 16; ++r) S[blk][r] = 0.f;
       const T* kb = Ks + (32 * blk + li) * XA_KSTR + 128 * hi;
 #pragma unroll
-      for (int ks = 0; ks < XA_KS; ++ks) {
-        if ((p.abl & 16) && ks >= XA_KS / 2) break;
-        S[blk] = Mfma32<T>::mma(*reinterpret_cast<const frag*>(kb + 8 * ks), qf[ks], S[blk]);
-      }
+      for (int ks = 0; ks < XA_KS; ++ks) S[blk] = Mfma32<T>::mma(*reinterpret_cast<const frag*>(kb + 8 * ks), qf[ks], S[blk]);
     }
     // ---- phase B: s = clamp(log2e * qk) + mask; one softmax over all 32 * NKB keys ----
     float mx = -INFINITY;
@@ -147,7 +143,7 @@ __global__ __launch_bounds__(512) void xattn_i2t_kernel(XAParams p) {
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float pv = (p.abl & 2) ? S[blk][8 * s2 + j] : __builtin_amdgcn_exp2f(S[blk][8 * s2 + j] - mref);
+          const float pv = __builtin_amdgcn_exp2f(S[blk][8 * s2 + j] - mref);
           lsum += pv;
           pf[blk][s2][j] = (T)pv;
         }
@@ -161,15 +157,12 @@ __global__ __launch_bounds__(512) void xattn_i2t_kernel(XAParams p) {
       for (int r = 0; r < 16; ++r) O[d][r] = 0.f;
 #pragma unroll
     for (int blk = 0; blk < NKB; ++blk) {
-      if (!(p.abl & 4)) {
-        if (!(qt == qt0 && blk == 0)) __syncthreads();   // tile `step` is in its slot; the other slot is free
-        vstore((step + 1) & 1);                          // tile step + 1 (prefetched) -> the free slot
-        vload((step + 2) % NKB);
-      }
+      if (!(qt == qt0 && blk == 0)) __syncthreads();     // tile `step` is in its slot; the other slot is free
+      vstore((step + 1) & 1);                            // tile step + 1 (prefetched) -> the free slot
+      vload((step + 2) % NKB);
       const T* Vs = Vr + (step & 1) * 32 * XA_VSTR;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        if ((p.abl & 8) && s2 == 1) break;
         const int krow0 = 16 * s2 + 4 * hi;
 #pragma unroll
         for (int d = 0; d < XA_DB; ++d) {
@@ -190,7 +183,7 @@ __global__ __launch_bounds__(512) void xattn_i2t_kernel(XAParams p) {
     // query complete a 32-byte sector per instruction (half the store instructions, no partial sectors)
     {
       T* orow = Og + (long)min(q, p.Nv - 1) * p.o_st;
-      const bool live = q < p.Nv && (!(p.abl & 1) || inv == 12345.f);
+      const bool live = q < p.Nv;
 #pragma unroll
       for (int d = 0; d < XA_DB; ++d)
 #pragma unroll
@@ -242,7 +235,6 @@ int xattn_i2t_try(const void* q, const void* k, const void* vl, const uint8_t* m
   p.B = B; p.H = H; p.Nv = Nv; p.L = L;
   p.q_sb = (long)Nv * E; p.q_st = E; p.kv_sb = (long)L * E; p.kv_st = E; p.o_sb = (long)Nv * E; p.o_st = E;
   p.clamp_l2 = clamp * 1.4426950408889634f;
-  { const char* e = getenv("HIPIE_XA_ABL"); p.abl = e ? atoi(e) : 0; }
   if (dtype == HIPIE_F16) return L <= 128 ? launch_i2t<f16_t, 4>(p, st) : launch_i2t<f16_t, 7>(p, st);
   if (dtype == HIPIE_BF16) return L <= 128 ? launch_i2t<bf16_t, 4>(p, st) : launch_i2t<bf16_t, 7>(p, st);
   return 1;
