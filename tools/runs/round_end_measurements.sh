@@ -1,3 +1,4 @@
+# the other BASELINE configurations, stage times and the kernel-trace summary of the default bench (end of round 2)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
 timeout 300 python bench.py --no-cpu-baseline --no-parity-leg --classes 150 --text-len 815 --size 1344 > gpurun_out/f2_cfg3.json 2> gpurun_out/f2_cfg3.err
 timeout 300 python bench.py --no-cpu-baseline --no-parity-leg --classes 1203 --text-len 4096 --size 1344 > gpurun_out/f2_cfg4.json 2> gpurun_out/f2_cfg4.err
