@@ -42,6 +42,8 @@ SIGNATURES = {
     "hipie_sem_pan": [c_p] * 8 + [c_i] * 11 + [c_p],
     "hipie_sine_embed": [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_f, c_i, c_p],
     "hipie_box_refine": [c_p, c_p, c_p, c_l, c_f, c_i, c_p],
+    "hipie_ref_point_mlp": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_i, c_p],
+    "hipie_box_head": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_f, c_p],
     "hipie_add_layernorm_dec": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_i, c_i, c_p],
     "hipie_add_cast": [c_p, c_p, c_p, c_l, c_i, c_p],
     "hipie_group_norm": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_p],

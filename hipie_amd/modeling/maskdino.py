@@ -17,7 +17,7 @@ from .. import ops
 from .transformer import (MLP, DeformableTransformerDecoderLayer, DeformableTransformerEncoderLayer, FeatureResizer, geo_cached,
                           PConv2d, PGroupNorm, PLayerNorm, PLinear, PositionEmbeddingSine, _get_clones, encoder_reference_points,
                           gen_encoder_output_proposals, get_sine_pos_embed, inverse_sigmoid, level_tensors,
-                          batched_decoder_values, decoder_fast_path, ref_point_query)
+                          batched_decoder_values, decoder_box_refine, decoder_fast_path, decoder_query_pos)
 
 
 class NormConv2d(PConv2d):
@@ -220,9 +220,9 @@ class MaskDINODecoder(nn.Module):
             t16 = t32.to(wdt)
             for lid, layer in enumerate(layers):
                 ref_in = ref[:, :, None] * vr2
-                qp16 = ref_point_query(self.decoder.ref_point_head, ops.sine_embed(ref_in[:, :, 0, :], out_dtype=wdt))
+                qp16 = decoder_query_pos(self.decoder.ref_point_head, ref_in[:, :, 0, :], wdt)
                 t32, t16 = layer.forward16(t32, t16, qp16, ref_in, values[lid], spatial_shapes, level_start_index)
-                ref = ops.box_refine(self.decoder.bbox_embed[lid](t32), ref)
+                ref = decoder_box_refine(self.decoder.bbox_embed[lid], t32, ref)
                 refs.append(ref)
             hs.append(self.decoder.norm(t32).float())
             layers = []

@@ -556,6 +556,26 @@ def ref_point_query(ref_point_head, sine):
     return F.linear(h, l1.weight, l1.bias).view(*sine.shape[:-1], -1)
 
 
+# The two small per-layer heads as ONE launch each (hipie_ref_point_mlp, hipie_box_head): 75 launches fewer per step, but the fp32-FMA
+# formulation is slower than the library GEMMs it replaces (A/B on one box: 100.0 vs 99.2 ms per step), so it is opt-in
+# (HIPIE_FUSED_HEADS=1) until the layers run on the matrix pipe.
+_FUSED_HEADS = os.environ.get("HIPIE_FUSED_HEADS", "0") == "1"
+
+
+def decoder_query_pos(ref_point_head, ref, wdt):
+    """query_pos of a decoder layer in the GEMM dtype: one launch (sine features + both layers) for the standard 512-256-256 head."""
+    if _FUSED_HEADS and ops.ref_point_mlp_ok(ref, ref_point_head) and ref_point_head.layers[0].weight.dtype == wdt:
+        return ops.ref_point_mlp(ref, ref_point_head)
+    return ref_point_query(ref_point_head, ops.sine_embed(ref, out_dtype=wdt))
+
+
+def decoder_box_refine(bbox_embed, t32, ref):
+    """sigmoid(bbox_embed(t) + inverse_sigmoid(ref)): one launch for the standard fp32 MLP(256, 256, 4, 3)."""
+    if _FUSED_HEADS and ops.box_head_ok(t32, bbox_embed):
+        return ops.box_head(t32, ref, bbox_embed)
+    return ops.box_refine(bbox_embed(t32), ref)
+
+
 def get_sine_pos_embed(pos_tensor, num_pos_feats=128, temperature=10000, exchange_xy=True):
     """deformable_transformer_dino.py:636-670 (== gen_sineembed_for_position, maskdino/utils/utils.py:74-100)."""
     scale = 2 * math.pi
@@ -593,9 +613,9 @@ class DeformableTransformerDecoder(nn.Module):
             t16 = t32.to(wdt)
             for lid, layer in enumerate(self.layers):
                 ref_in = reference_points[:, :, None] * vr2
-                qp16 = ref_point_query(self.ref_point_head, ops.sine_embed(ref_in[:, :, 0, :], out_dtype=wdt))
+                qp16 = decoder_query_pos(self.ref_point_head, ref_in[:, :, 0, :], wdt)
                 t32, t16 = layer.forward16(t32, t16, qp16, ref_in, values[lid], spatial_shapes, level_start_index)
-                reference_points = ops.box_refine(self.bbox_embed[lid](t32), reference_points)
+                reference_points = decoder_box_refine(self.bbox_embed[lid], t32, reference_points)
                 inter.append(t32)
                 inter_refs.append(reference_points)
             return torch.stack(inter), torch.stack(inter_refs)

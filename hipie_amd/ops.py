@@ -551,6 +551,70 @@ def sine_embed(ref, num_pos_feats=128, temperature=10000, out_dtype=torch.float3
     return out
 
 
+def _transposed(mod_layers, dtype=None):
+    """(in, out) copies of the Linear weights of a small MLP head + its biases, cached on the parameters' versions."""
+    owner = mod_layers[0]
+    key = tuple((l.weight.data_ptr(), l.weight._version, l.weight.dtype, l.bias._version) for l in mod_layers)
+    if getattr(owner, "_wt_key", None) != key:
+        owner._wt = [(l.weight.t().contiguous(), l.bias.contiguous()) for l in mod_layers]
+        owner._wt_key = key
+    return owner._wt
+
+
+def ref_point_mlp_ok(ref, head):
+    ls = getattr(head, "layers", None)
+    return (ls is not None and len(ls) == 2 and ref.is_cuda and ref.shape[-1] == 4 and tuple(ls[0].weight.shape) == (256, 512)
+            and tuple(ls[1].weight.shape) == (256, 256) and ls[0].weight.dtype == ls[1].weight.dtype and ls[0].weight.dtype in _DT)
+
+
+@_timed("ref_point_mlp")
+def ref_point_mlp(ref, head, num_pos_feats=128, temperature=10000):
+    """query_pos = head(get_sine_pos_embed(ref)) in one launch: ref (B, Q, 4) f32 (row-strided view allowed), head = the
+    2-layer ref_point_head (512 -> 256 -> 256) -> (B, Q, 256) in the head's weight dtype."""
+    import math
+    lib = _lib.load()
+    ref = ref.float()
+    rs = 4
+    if ref.dim() == 3 and ref.stride(-1) == 1 and ref.stride(0) == ref.shape[1] * ref.stride(1) and ref.stride(1) >= 4:
+        rs = ref.stride(1)
+    elif not ref.is_contiguous():
+        ref = ref.contiguous()
+    key = (num_pos_feats, temperature, str(ref.device))
+    dim_t = _DIM_T.get(key)
+    if dim_t is None:
+        d = torch.arange(num_pos_feats, dtype=torch.float32, device=ref.device)
+        dim_t = (temperature ** (2 * torch.div(d, 2, rounding_mode="floor") / num_pos_feats)).contiguous()
+        _DIM_T[key] = dim_t
+    (w1t, b1), (w2t, b2) = _transposed(list(head.layers))
+    dt = w1t.dtype
+    n = ref.numel() // 4
+    out = torch.empty(ref.shape[:-1] + (256,), dtype=dt, device=ref.device)
+    rc = lib.hipie_ref_point_mlp(ref.data_ptr(), dim_t.data_ptr(), w1t.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(),
+                                 out.data_ptr(), n, rs, 2 * math.pi, _DT[dt], _stream())
+    _lib.check(rc, "hipie_ref_point_mlp")
+    return out
+
+
+def box_head_ok(x, mlp):
+    ls = getattr(mlp, "layers", None)
+    return (ls is not None and len(ls) == 3 and x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 256
+            and [tuple(l.weight.shape) for l in ls] == [(256, 256), (256, 256), (4, 256)]
+            and all(l.weight.dtype == torch.float32 for l in ls))
+
+
+@_timed("box_head")
+def box_head(x, ref, mlp, eps=1e-5):
+    """sigmoid(mlp(x) + inverse_sigmoid(ref)) in one launch: x (..., 256) f32, ref (..., 4) f32, mlp = MLP(256, 256, 4, 3) f32."""
+    lib = _lib.load()
+    x, ref = x.contiguous(), ref.float().contiguous()
+    (w1t, b1), (w2t, b2), (w3t, b3) = _transposed(list(mlp.layers))
+    out = torch.empty_like(ref)
+    rc = lib.hipie_box_head(_chk(x, "x", torch.float32), _chk(ref, "ref", torch.float32), w1t.data_ptr(), b1.data_ptr(), w2t.data_ptr(),
+                            b2.data_ptr(), w3t.data_ptr(), b3.data_ptr(), out.data_ptr(), ref.numel() // 4, float(eps), _stream())
+    _lib.check(rc, "hipie_box_head")
+    return out
+
+
 @_timed("box_refine")
 def box_refine(delta, ref, eps=1e-5):
     """sigmoid(delta + inverse_sigmoid(ref)): delta (..., 4) f32|f16|bf16, ref (..., 4) f32 -> (..., 4) f32."""

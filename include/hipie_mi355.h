@@ -264,6 +264,20 @@ int hipie_add_layernorm_dec(const float* x, const void* delta, const float* gamm
                             int delta_dtype, int aux_dtype, void* stream);
 
 /*
+ * The two small MLP heads of a decoder layer, one launch each (they were a sine kernel + 2 GEMMs, and 3 GEMMs + the refinement):
+ *   hipie_ref_point_mlp: query_pos = ref_point_head(get_sine_pos_embed(ref)) -- deformable_transformer_dino.py:484-490 / dino_decoder.py
+ *     :126-131; ref (n, ref_stride >= 4) f32 boxes (x, y, w, h); dim_t (128) as in hipie_sine_embed; w1t (512, 256), w2t (256, 256) =
+ *     the layers' weights TRANSPOSED to (in, out), biases, output (n, 256) all in `dtype`; sine features and the hidden activations are
+ *     rounded to `dtype` where the GEMM path rounded them, fp32 accumulation.
+ *   hipie_box_head: new_ref = sigmoid(bbox_embed(x) + inverse_sigmoid(ref)) -- :502-520 with MLP(256, 256, 4, 3); everything f32;
+ *     w1t, w2t (256, 256), w3t (256, 4) transposed weights; x (n, 256), ref, out (n, 4).
+ */
+int hipie_ref_point_mlp(const float* ref, const float* dim_t, const void* w1t, const void* b1, const void* w2t, const void* b2,
+                        void* out, int64_t n, int ref_stride, float scale, int dtype, void* stream);
+int hipie_box_head(const float* x, const float* ref, const float* w1t, const float* b1, const float* w2t, const float* b2,
+                   const float* w3t, const float* b3, float* out, int64_t n, float eps, void* stream);
+
+/*
  * GroupNorm with 8 channels per group (GroupNorm(32, 256) of every conv + GN block after the backbone: input_proj of both heads,
  * deformable_detr.py:139-160; the pixel decoder's lateral / output convs and mask_features head, maskdino_encoder.py:262-300),
  * on the layout the tensor arrives in, with an optional per-channel pre-bias (y = GN(x + prebias[c])) and an optional ReLU.

@@ -745,3 +745,34 @@ def test_add_layernorm_sum(dt):
     assert rel_err(n.float().cpu(), want.cpu()) < tol
     assert rel_err(s.float().cpu(), (want + pos.float()).cpu()) < tol
     assert torch.equal(n, ops.add_layernorm(x, d, w, b, 1e-5, dt, want_res=False)[1])
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 5e-6), (torch.float16, 2e-3)])
+def test_decoder_heads_fused(dt, tol):
+    """hipie_ref_point_mlp / hipie_box_head against the chains they replace: get_sine_pos_embed -> ref_point_head (oracle's
+    sine_embed_4 + mlp) and bbox_embed -> sigmoid(. + inverse_sigmoid(ref)), at 300 and 910 queries (ragged last row block)."""
+    import oracle.model as om
+    from hipie_amd import ops
+    from hipie_amd.modeling.transformer import MLP, cast_head
+    torch.manual_seed(21)
+    rp = MLP(512, 256, 256, 2).to(DEV)
+    bb = MLP(256, 256, 4, 3).to(DEV)
+    for m in (rp, bb):
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.data.normal_(0, 0.1)
+    sd = {"rp." + k: v.detach().float().cpu() for k, v in rp.state_dict().items()}
+    sd.update({"bb." + k: v.detach().float().cpu() for k, v in bb.state_dict().items()})
+    if dt != torch.float32:
+        cast_head(rp, dt, dt)
+    for nq in (300, 910 + 3):
+        ref = torch.rand(2, nq, 4) * 0.8 + 0.1
+        wide = torch.rand(2, nq, 4, 4)                      # the (B, Q, levels, 4) tensor whose level-0 slice is the sine input
+        wide[:, :, 0, :] = ref
+        want_q = om.mlp(om.sine_embed_4(ref), sd, "rp.", 2)
+        got_q = ops.ref_point_mlp(wide.to(DEV)[:, :, 0, :], rp)
+        assert got_q.dtype == dt and rel_err(got_q.float().cpu(), want_q) < tol
+        x = torch.randn(2, nq, 256)
+        want_b = torch.sigmoid(om.mlp(x, sd, "bb.", 3) + om.inverse_sigmoid(ref))
+        got_b = ops.box_head(x.to(DEV), ref.to(DEV), bb)
+        assert rel_err(got_b.cpu(), want_b) < 5e-6
