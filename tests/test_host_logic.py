@@ -418,3 +418,30 @@ def test_predictor_input_recipe(tmp_path):
     assert det["is_thing"] == {i + 1: bool(c.get("isthing", 1)) for i, c in enumerate(cats)}
     with pytest.raises(ValueError):
         p(img, "sot")
+
+
+@pytest.mark.parametrize("task,topk", [("detection", 100), ("detection", 7), ("grounding", 100)])
+def test_inference_compact_equals_host_path_cpu(task, topk):
+    """postprocess.inference_compact (device-side packing with a stable sort) == compact_predictions(inference(...)) -- on the CPU
+    with OTA off (the NMS kernel is the only GPU-only piece of that path), including images whose clipped boxes go empty."""
+    import types
+    from hipie_amd import parallel
+    from hipie_amd.config import HipieConfig
+    from hipie_amd.postprocess import inference, inference_compact
+    sizes = [(384, 512), (512, 448), (256, 256)]
+    nbg, nfg, nmd, L, ncls = 10, 120, 40, 64, 9
+    a22 = _synth.synth_a22(sizes, nbg, nfg, nmd, L, seed=321)
+    a22["pred_boxes"][1, nbg:nbg + 60, 2:] = 0.0
+    _, _, pmap = _synth.synth_token_ids(3, ncls, L, seed=74)
+    is_thing = {c + 1: (c % 3 == 0) for c in range(ncls)}
+    cfg = HipieConfig()
+    cfg.num_bg_queries, cfg.ota, cfg.use_bg_for_pano = nbg, False, True
+    model = types.SimpleNamespace(cfg=cfg)
+    out = dict(a22)
+    out["image_sizes"] = sizes
+    batched = [{"task": task, "positive_map_label_to_token": pmap, "is_thing": is_thing, "height": 300 + 10 * i, "width": 333}
+               for i in range(len(sizes))]
+    want = parallel.compact_predictions(inference(model, out, batched, with_masks=False, with_sem_pan=False), topk=topk)
+    got = inference_compact(model, out, batched, topk=topk)
+    assert got.shape == want.shape == (3, topk, parallel.PRED_FIELDS)
+    assert torch.equal(got, want)
