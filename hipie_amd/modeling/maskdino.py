@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from .. import ops
 from .transformer import (MLP, DeformableTransformerDecoderLayer, DeformableTransformerEncoderLayer, FeatureResizer, geo_cached,
                           PConv2d, PGroupNorm, PLayerNorm, PLinear, PositionEmbeddingSine, _get_clones, encoder_reference_points,
-                          gen_encoder_output_proposals, get_sine_pos_embed, inverse_sigmoid, level_tensors,
+                          gen_encoder_output_proposals, level_tensors,
                           batched_decoder_values, decoder_box_refine, decoder_fast_path, decoder_query_pos)
 
 

@@ -6,7 +6,6 @@ parameter names, so reference checkpoints load unchanged.  The attention core ru
 parity and fast policies), the GEMM / attention operands use the policy's 16-bit types.
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
