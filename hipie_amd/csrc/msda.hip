@@ -266,6 +266,47 @@ __global__ __launch_bounds__(256) void msda_generic_kernel(const T* __restrict__
 // value row stride of the call being dispatched (host-side plumbing through the dtype switch; 0 = dense M * D)
 static thread_local long g_value_row = 0;
 
+
+// double instantiation of the reference op (AT_DISPATCH_FLOATING_TYPES, ms_deform_attn_cuda.cu:56): one thread per output element,
+// every quantity in f64 in the reference's operation order (ms_deform_attn_im2col_bilinear, ms_deform_im2col_cuda.cuh:21-73, 237-299).
+// Not on the product path -- it completes the plugin boundary (ops/test.py checks the op in double).
+__global__ __launch_bounds__(256) void msda_f64_kernel(const double* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                       const int64_t* __restrict__ lstart, const double* __restrict__ loc,
+                                                       const double* __restrict__ attn, double* __restrict__ out, int S, int M, int D,
+                                                       int L, int Lq, int P, long n) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int c = (int)(idx % D);
+  const long g = idx / D;
+  const int m = (int)(g % M);
+  const long bq = g / M;
+  const int b = (int)(bq / Lq);
+  const long row = (long)M * D;
+  const double* vb = value + (long)b * S * row + m * D + c;
+  const double* lp = loc + g * (long)L * P * 2;
+  const double* wp = attn + g * (long)L * P;
+  double col = 0.0;
+  for (int l = 0; l < L; ++l) {
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+    const double* vl = vb + (long)lstart[l] * row;
+    for (int p = 0; p < P; ++p) {
+      const int i = l * P + p;
+      const double h_im = lp[2 * i + 1] * H - 0.5, w_im = lp[2 * i] * W - 0.5;
+      if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+        const int h0 = (int)floor(h_im), w0 = (int)floor(w_im), h1 = h0 + 1, w1 = w0 + 1;
+        const double lh = h_im - h0, lw = w_im - w0, hh = 1 - lh, hw = 1 - lw;
+        double v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+        if (h0 >= 0 && w0 >= 0) v1 = vl[((long)h0 * W + w0) * row];
+        if (h0 >= 0 && w1 <= W - 1) v2 = vl[((long)h0 * W + w1) * row];
+        if (h1 <= H - 1 && w0 >= 0) v3 = vl[((long)h1 * W + w0) * row];
+        if (h1 <= H - 1 && w1 <= W - 1) v4 = vl[((long)h1 * W + w1) * row];
+        col += (hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4) * wp[i];
+      }
+    }
+  }
+  out[idx] = col;
+}
+
 template <typename T, typename A, bool FUSED>
 static int launch_msda(const void* value, const int64_t* shapes, const int64_t* lstart, const void* a, const void* w,
                        const float* ref, void* out, int B, int S, int M, int D, int L, int Lq, int P, int ref_dim,
@@ -327,9 +368,23 @@ static int dispatch_msda(const void* value, const int64_t* shapes, const int64_t
 
 }  // namespace hipie
 
+static int msda_forward_f64(const void* value, const int64_t* shapes, const int64_t* lstart, const void* loc, const void* attn, void* out,
+                            int B, int S, int M, int D, int L, int Lq, int P, void* stream) {
+  using namespace hipie;
+  HIPIE_REQUIRE(B >= 0 && S > 0 && M > 0 && D > 0 && L > 0 && Lq >= 0 && P > 0, "msda: bad shape");
+  if (B == 0 || Lq == 0) return HIPIE_OK;
+  HIPIE_REQUIRE(value && shapes && lstart && loc && attn && out, "msda: null pointer");
+  const long n = (long)B * Lq * M * D;
+  hipLaunchKernelGGL(msda_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const double*)value, shapes,
+                     lstart, (const double*)loc, (const double*)attn, (double*)out, S, M, D, L, Lq, P, n);
+  return check_launch("msda_f64");
+}
+
 extern "C" int hipie_msda_forward(const void* value, const int64_t* spatial_shapes, const int64_t* level_start,
-                                  const float* sampling_loc, const float* attn_weight, void* out, int B, int S, int M,
+                                  const void* sampling_loc, const void* attn_weight, void* out, int B, int S, int M,
                                   int D, int L, int Lq, int P, int value_dtype, void* stream) {
+  if (value_dtype == HIPIE_F64)
+    return msda_forward_f64(value, spatial_shapes, level_start, sampling_loc, attn_weight, out, B, S, M, D, L, Lq, P, stream);
   return hipie::dispatch_msda<false>(value, spatial_shapes, level_start, sampling_loc, attn_weight, nullptr, out, B, S,
                                      M, D, L, Lq, P, 2, value_dtype, HIPIE_F32, (long)M * L * P * 2, (long)M * L * P, stream);
 }

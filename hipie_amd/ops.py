@@ -90,18 +90,20 @@ def _chk(t, name, dtype=None):
 
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
     """MSDA.ms_deform_attn_forward (ops/src/vision.cpp:13-16): value (B,S,M,D), shapes (L,2) i64, level_start (L,) i64,
-    sampling_loc (B,Lq,M,L,P,2), attn_weight (B,Lq,M,L,P) -> (B,Lq,M*D).  value may be f32/f16/bf16; loc/attn are f32."""
+    sampling_loc (B,Lq,M,L,P,2), attn_weight (B,Lq,M,L,P) -> (B,Lq,M*D).  value may be f32/f16/bf16 with f32 loc/attn, or all f64."""
     lib = _lib.load()
     B, S, M, D = value.shape
     _, Lq, _, L, P, _ = sampling_loc.shape
-    if value.dtype not in _DT:
+    f64 = value.dtype == torch.float64              # the reference op's double instantiation (ops/test.py checks it)
+    if value.dtype not in _DT and not f64:
         raise RuntimeError("ms_deform_attn_forward: unsupported dtype %s" % value.dtype)
+    aux = torch.float64 if f64 else torch.float32
     out = torch.empty(B, Lq, M * D, dtype=value.dtype, device=value.device)
     rc = lib.hipie_msda_forward(_chk(value, "value"), _chk(spatial_shapes, "spatial_shapes", torch.int64),
                                 _chk(level_start_index, "level_start_index", torch.int64),
-                                _chk(sampling_loc, "sampling_loc", torch.float32),
-                                _chk(attn_weight, "attn_weight", torch.float32), out.data_ptr(),
-                                B, S, M, D, L, Lq, P, _DT[value.dtype], _stream())
+                                _chk(sampling_loc, "sampling_loc", aux),
+                                _chk(attn_weight, "attn_weight", aux), out.data_ptr(),
+                                B, S, M, D, L, Lq, P, 3 if f64 else _DT[value.dtype], _stream())
     _lib.check(rc, "hipie_msda_forward")
     return out
 

@@ -27,6 +27,7 @@ extern "C" {
 #define HIPIE_F32 0
 #define HIPIE_F16 1
 #define HIPIE_BF16 2
+#define HIPIE_F64 3          /* hipie_msda_forward only (the reference op dispatches float | double) */
 
 /* flags of the attention entry points that take a `flags` argument */
 #define HIPIE_ATTN_FAST 1    /* deferred running max (rescale only when a row maximum grows by > 2^8) and, where the head dim
@@ -49,16 +50,17 @@ const char* hipie_last_error(void);
  *           = ms_deform_attn_cuda_forward (ops/src/cuda/ms_deform_attn_cuda.cu:20-80)
  *           -> ms_deformable_im2col_gpu_kernel (ops/src/cuda/ms_deform_im2col_cuda.cuh:237-299),
  *           and the identical copy under models/maskdino/pixel_decoder/ops/.
- *   value          (B, S, M, D)        dtype `value_dtype` (f32 as the reference; f16/bf16 halve the gather traffic)
+ *   value          (B, S, M, D)        dtype `value_dtype` (f32 as the reference; f16/bf16 halve the gather traffic; f64: the
+ *                                      reference's double instantiation -- then sampling_loc, attn_weight and out are f64 too)
  *   spatial_shapes (L, 2) int64 (H, W) device
  *   level_start    (L,)   int64        device
- *   sampling_loc   (B, Lq, M, L, P, 2) f32, (x, y) normalised to [0,1] (values outside sample zero padding)
- *   attn_weight    (B, Lq, M, L, P)    f32
+ *   sampling_loc   (B, Lq, M, L, P, 2) f32 (f64 with an f64 value), (x, y) normalised to [0,1] (values outside sample zero padding)
+ *   attn_weight    (B, Lq, M, L, P)    f32 (f64 with an f64 value)
  *   out            (B, Lq, M*D)        dtype `value_dtype`; fully overwritten (the reference at::zeros + writes all)
  * im2col_step of the reference is a batching detail of its host loop and has no equivalent here.
  */
 int hipie_msda_forward(const void* value, const int64_t* spatial_shapes, const int64_t* level_start,
-                       const float* sampling_loc, const float* attn_weight, void* out,
+                       const void* sampling_loc, const void* attn_weight, void* out,
                        int B, int S, int M, int D, int L, int Lq, int P, int value_dtype, void* stream);
 
 /*

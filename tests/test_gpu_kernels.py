@@ -51,6 +51,18 @@ def test_msda_reference_recipe_float():
     assert rel_err(out, g["ref_float_out"]) < 1e-6
 
 
+def test_msda_reference_recipe_double():
+    """the double instantiation of the op (ops/test.py:36-49 check_forward_equal_with_pytorch_double): f64 in, f64 out, 1e-12."""
+    from hipie_amd import ops
+    g = Golden("msda")
+    shapes = g["ref_double_shapes"]
+    f64 = torch.float64                                        # the fixture stores the inputs as they were generated; the op runs in double
+    out = ops.ms_deform_attn_forward(g["ref_double_value"].to(f64).to(DEV), shapes.to(DEV), _lsi(shapes).to(DEV),
+                                     g["ref_double_loc"].to(f64).to(DEV), g["ref_double_attn"].to(f64).to(DEV), 2).cpu()
+    assert out.dtype == torch.float64
+    assert rel_err(out, g["ref_double_out"]) < 1e-12
+
+
 @pytest.mark.parametrize("tag", ["hot_enc", "hot_dec", "hot_rect"])
 def test_msda_hot_geometry(tag):
     from hipie_amd import ops
