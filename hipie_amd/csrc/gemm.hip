@@ -1,0 +1,346 @@
+// gemm.hip -- the linears of the path (ViT qkv / proj / fc1 / fc2, BERT, encoder / decoder FFNs and projections) as one
+// hand-written MFMA GEMM for gfx950:      out = epilogue( alpha * A (M x K) . W^T (N x K) + bias )
+//
+// Both operands are K-contiguous (torch.nn.Linear keeps W as (N, K)), so both MFMA fragments are 16-byte row pieces: no
+// transposes anywhere.  Two operand formats:
+//   HIPIE_F16   one fp16 per element                                                       1 MFMA per tile and k-step
+//   HIPIE_HL8   SPLIT fp16: every group of 8 k-elements is stored as 8 fp16 "hi" then 8 fp16 "lo" with hi + lo == x to 2^-22
+//               (32 bytes per group = the bytes of fp32).  The product is formed as  W_lo.X_hi + W_hi.X_lo + W_hi.X_hi  with
+//               fp32 accumulation: every fp16 x fp16 product is exact in fp32, the dropped lo x lo term is 2^-22 relative, so
+//               the result is fp32-class (the reference runs these linears in fp32, hipie/backbone/vit.py:67-83,212-230;
+//               deformable_transformer_dino.py:378-394) at 3 MFMAs per k-step on the 16-bit matrix pipe -- gfx950's fp32 MFMA
+//               runs at 1/16 of the fp16 rate.  A row's 32-element k slice is one 128-byte line.
+//
+// Design (MI355X_MICROARCH.md, cdna_hip_programming.md section 5):
+//   * workgroup tile 256 (M) x BN (N), BN = 320 | 256, 8 waves as 4 (M) x 2 (N): a wave owns 64 tokens x BN/2 features =
+//     2 x (BN/64) MFMA tiles of 32x32 (160 / 128 accumulator registers).  BN = 320 tiles N = 1280 / 3840 / 5120 of ViT-H
+//     exactly and makes 512 / 1536 / 2048 workgroups at 32768 tokens = whole waves of the 256 CUs;
+//   * the MFMA computes out^T = W . X^T (features are the 32 MFMA rows, tokens the 32 columns), so a lane owns ONE token and
+//     4 consecutive features per accumulator quad: bias / activation / residual / split are per-lane vector work and the stores
+//     are 16 bytes;
+//   * k tile = 128 bytes per row in both formats (64 fp16 elements, or 32 split elements); operand tiles go L2 -> LDS by
+//     LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write), 2 LDS stages of (256 + BN) x 128 B, one barrier
+//     per stage, the DMA instructions of stage t+1 spread between the MFMAs of stage t;
+//   * LDS rows are 128 B, which would put a ds_read_b128 lane group on two 16-byte slots (8-way conflict); the 16-byte chunk c
+//     of row r is therefore stored at chunk position c ^ ((r >> 1) & 7).  The DMA writes LDS lane-linearly, so the swizzle is
+//     applied to the per-lane global SOURCE address; the reader applies the same XOR.  Conflict-free for every b128 lane group;
+//   * block -> tile map: the blocks of one XCD (blockIdx % 8) walk a contiguous range of tiles with the N index fastest, so
+//     the workgroups resident on an XCD share a few A row panels and the W panels through that XCD's L2.
+// Epilogue (runtime switches, once per tile): * alpha, + bias, exact-erf GELU | ReLU, + fp32 residual, then the output as
+// fp32, fp16 or HL8 (optionally scaled) -- the HL8 form is directly the A operand of the next GEMM.
+#include "common.h"
+#include "mfma.h"
+
+namespace hipie {
+
+struct GemmParams {
+  const char* A; const char* W; const float* bias; const float* resid; char* out;
+  long lda_b, ldw_b;          // row strides of A / W in BYTES
+  long ldr, ldo;              // row strides of resid (fp32 elements) / out (elements of the output format: fp32 | fp16; HL8: fp16 elements)
+  int M, N, K;
+  int nkt;                    // 128-byte k tiles
+  int tiles_m, tiles_n;
+  int out_fmt, act;
+  float alpha, oscale;
+};
+
+// LDS-DMA, 16 bytes per lane: LDS[m0 + 16 * lane] <- *(sbase + voff).  Inline asm (see vit_attn.hip: the builtin makes hipcc
+// drain vmcnt(0) before every later ds_read); completion is counted by hand -- vmcnt(0) before the stage barrier.
+__device__ __forceinline__ void gm_dma16(const char* sbase, unsigned int voff, unsigned int lds_dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned int keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+#endif
+}
+
+__device__ __forceinline__ float gm_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ unsigned int gm_pack2(float a, float b) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  h2 v;
+  v[0] = (f16_t)a;
+  v[1] = (f16_t)b;
+  return __builtin_bit_cast(unsigned int, v);
+}
+
+template <int BN, bool SPLIT>
+__global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
+  constexpr int BM = 256;
+  constexpr int ROWS = BM + BN;                // rows of one LDS stage: the A tile then the W tile
+  constexpr int STAGE = ROWS * 128;            // bytes
+  constexpr int NI = ROWS / 64;                // DMA instructions per wave and stage (one covers 8 rows x 128 B)
+  constexpr int NJ = BN / 64;                  // 32-feature blocks per wave
+  constexpr int KS = SPLIT ? 2 : 4;            // k16 steps per stage
+  constexpr int SUB = KS * NJ;                 // (k-step, feature block) sub-steps per stage
+  typedef Mfma32<f16_t>::frag frag;
+
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  const int li = lane & 31, hi = lane >> 5;
+
+  // ---- block -> tile (bijective XCD-aware order: XCD x owns a contiguous range of tile ids) ----
+  int tm, tn;
+  {
+    const int nblk = p.tiles_m * p.tiles_n;
+    const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    tm = v / p.tiles_n;
+    tn = v - tm * p.tiles_n;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- DMA plan: instruction i of this wave fills rows 8 * (8 i + wave) .. + 7 of the stage image; lane -> (row, chunk position) ----
+  unsigned int dvoff[NI];
+  {
+    const int rl = lane >> 3, cp = lane & 7;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = 8 * (8 * i + wave) + rl;              // stage row
+      const int c = cp ^ ((r >> 1) & 7);                  // logical chunk stored at this position
+      if (r < BM) dvoff[i] = (unsigned int)((long)min(r, p.M - 1 - m0) * p.lda_b + 16 * c);
+      else dvoff[i] = (unsigned int)((long)min(r - BM, p.N - 1 - n0) * p.ldw_b + 16 * c);
+    }
+  }
+  const char* abase = p.A + (long)m0 * p.lda_b;
+  const char* wbase = p.W + (long)n0 * p.ldw_b;
+  const unsigned int lds0 = (unsigned int)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
+
+  auto dma = [&](const int i, const int kt, const int stage) {
+    const bool isa = (8 * (8 * i + wave)) < BM;           // wave-uniform: an instruction is all-A or all-W (BM % 64 == 0)
+    const char* sb = (isa ? abase : wbase) + (long)kt * 128;
+    gm_dma16(sb, dvoff[i], __builtin_amdgcn_readfirstlane(lds0 + (unsigned int)(stage * STAGE + 1024 * (8 * i + wave))));
+  };
+
+  // ---- fragment addresses: row = tile base (multiple of 32) + li, so the swizzle term is ((li >> 1) & 7) for every tile ----
+  const int swz = (li >> 1) & 7;
+  const char* xrow = smem + (wm * 64 + li) * 128;                    // + t * 32 * 128
+  const char* wrow = smem + (BM + wn * (BN / 2) + li) * 128;         // + j * 32 * 128
+  // logical chunk of (k-step ks, lane half, lo): plain 2 ks + hi; split 2 (2 ks + hi) + lo
+  auto choff = [&](const int ks, const int lo) -> int { return 16 * ((SPLIT ? (2 * (2 * ks + hi) + lo) : (2 * ks + hi)) ^ swz); };
+
+  f32x16 acc[NJ][2];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
+
+  // ---- prologue: stage 0 ----
+#pragma unroll
+  for (int i = 0; i < NI; ++i) dma(i, 0, 0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
+  __syncthreads();
+
+  for (int kt = 0; kt < p.nkt; ++kt) {
+    const int st = kt & 1;
+    const bool more = kt + 1 < p.nkt;
+    const char* xs = xrow + st * STAGE;
+    const char* ws = wrow + st * STAGE;
+    // software pipeline inside the stage: the fragments of sub-step s + 1 are requested before the MFMAs of sub-step s
+    frag xa[2][2][2];            // [k-step parity][hi | lo][token tile]
+    frag wa[2][2];               // [sub-step parity][hi | lo]
+    auto load_x = [&](const int ks) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        xa[ks & 1][0][t] = *reinterpret_cast<const frag*>(xs + t * 4096 + choff(ks, 0));
+        if (SPLIT) xa[ks & 1][1][t] = *reinterpret_cast<const frag*>(xs + t * 4096 + choff(ks, 1));
+      }
+    };
+    auto load_w = [&](const int s) {
+      const int ks = s / NJ, j = s % NJ;
+      wa[s & 1][0] = *reinterpret_cast<const frag*>(ws + j * 4096 + choff(ks, 0));
+      if (SPLIT) wa[s & 1][1] = *reinterpret_cast<const frag*>(ws + j * 4096 + choff(ks, 1));
+    };
+    load_x(0);
+    load_w(0);
+    constexpr int EVERY = (SUB >= 2 * NI) ? 2 : 1;
+    static_assert(SUB / EVERY >= NI, "every DMA instruction of a stage needs a sub-step slot");
+#pragma unroll
+    for (int s = 0; s < SUB; ++s) {
+      const int ks = s / NJ, j = s % NJ;
+      if (s + 1 < SUB) {
+        if ((s + 1) % NJ == 0) load_x(ks + 1);
+        load_w(s + 1);
+      }
+      const frag wh = wa[s & 1][0];
+      const frag xh0 = xa[ks & 1][0][0], xh1 = xa[ks & 1][0][1];
+      if (SPLIT) {
+        const frag wl = wa[s & 1][1];
+        const frag xl0 = xa[ks & 1][1][0], xl1 = xa[ks & 1][1][1];
+        acc[j][0] = Mfma32<f16_t>::mma(wl, xh0, acc[j][0]);
+        acc[j][1] = Mfma32<f16_t>::mma(wl, xh1, acc[j][1]);
+        acc[j][0] = Mfma32<f16_t>::mma(wh, xl0, acc[j][0]);
+        acc[j][1] = Mfma32<f16_t>::mma(wh, xl1, acc[j][1]);
+      }
+      acc[j][0] = Mfma32<f16_t>::mma(wh, xh0, acc[j][0]);
+      acc[j][1] = Mfma32<f16_t>::mma(wh, xh1, acc[j][1]);
+      // the DMA instructions of the next stage, spread over the sub-steps (a burst blocks the wave's in-order issue)
+      if (more && (s % EVERY) == EVERY - 1 && s / EVERY < NI) dma(s / EVERY, kt + 1, st ^ 1);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's DMA writes of stage t+1 have landed
+    __syncthreads();                          // ... and everybody's; all reads of stage t are done
+  }
+
+  // ---- epilogue: lane = token (column of the MFMA tile), registers = features ----
+  const bool has_bias = p.bias != nullptr, has_res = p.resid != nullptr;
+  const int act = p.act, ofmt = p.out_fmt;
+  const float alpha = p.alpha, osc = p.oscale;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int m = m0 + wm * 64 + t * 32 + li;
+    const bool mok = m < p.M;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int nb = n0 + wn * (BN / 2) + j * 32;             // first feature of the 32-row MFMA block
+      float v[4][4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = nb + 8 * g + 4 * hi;
+        const bool ok = mok && n < p.N;
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), r4 = b4;
+        if (has_bias && n < p.N) b4 = *reinterpret_cast<const float4*>(p.bias + n);
+        if (has_res && ok) r4 = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldr + n);
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = acc[j][t][4 * g + e] * alpha + bb[e];
+          if (act == 1) x = gm_gelu(x);
+          else if (act == 2) x = fmaxf(x, 0.f);
+          v[g][e] = (x + rr[e]) * osc;
+        }
+      }
+      if (ofmt == HIPIE_F32) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = nb + 8 * g + 4 * hi;
+          if (mok && n < p.N)
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (long)m * p.ldo + n) = make_float4(v[g][0], v[g][1], v[g][2], v[g][3]);
+        }
+      } else if (ofmt == HIPIE_F16) {
+        // quads g and g + 1 of the two lane halves are exchanged so that the lower half stores features 8g .. 8g+7 and the upper
+        // half 8(g+1) .. 8(g+1)+7 as ONE 16-byte piece each
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+          typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+          typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+          const u32x2 s0 = __builtin_amdgcn_permlane32_swap(gm_pack2(v[g][0], v[g][1]), gm_pack2(v[g + 1][0], v[g + 1][1]), false, false);
+          const u32x2 s1 = __builtin_amdgcn_permlane32_swap(gm_pack2(v[g][2], v[g][3]), gm_pack2(v[g + 1][2], v[g + 1][3]), false, false);
+          const int n = nb + 8 * (g + hi);
+          if (mok && n < p.N)
+            *reinterpret_cast<u32x4*>(reinterpret_cast<f16_t*>(p.out) + (long)m * p.ldo + n) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+        }
+      } else {   // HIPIE_HL8: group of 8 features = 16 B of hi values then 16 B of lo values; the lower lane half ends up with all 8
+                 // hi values, the upper half with all 8 lo values
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+          typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+          float lo[4];
+          f16_t h[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { h[e] = (f16_t)v[g][e]; lo[e] = v[g][e] - (float)h[e]; }
+          const unsigned int H0 = gm_pack2((float)h[0], (float)h[1]), H1 = gm_pack2((float)h[2], (float)h[3]);
+          const unsigned int L0 = gm_pack2(lo[0], lo[1]), L1 = gm_pack2(lo[2], lo[3]);
+          const u32x2 s0 = __builtin_amdgcn_permlane32_swap(H0, L0, false, false);    // lower: (H0 own, H0 of upper); upper: (L0 of lower, L0 own)
+          const u32x2 s1 = __builtin_amdgcn_permlane32_swap(H1, L1, false, false);
+          const int n = nb + 8 * g;
+          if (mok && n < p.N)
+            *reinterpret_cast<u32x4*>(reinterpret_cast<f16_t*>(p.out) + (long)m * p.ldo + 2 * n + 8 * hi) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+        }
+      }
+    }
+  }
+}
+
+template <int BN, bool SPLIT>
+static int launch_gemm(GemmParams& p, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * (256 + BN) * 128;
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  auto kern = gemm_kernel<BN, SPLIT>;
+  static bool lds_set[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !lds_set[dev]) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (dev >= 0 && dev < 64) lds_set[dev] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), lds, st, p);
+  return check_launch("gemm");
+}
+
+// fp32 / fp16 rows -> HL8 (optionally scaled): the generic producer of split operands (weights are split once on the host)
+template <typename T>
+__global__ __launch_bounds__(256) void to_hl8_kernel(const T* __restrict__ x, f16_t* __restrict__ out, long rows, int K, long ldx, long ldo,
+                                                     float scale) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;       // one group of 8 elements per thread
+  const int gpr = K / 8;
+  if (gid >= rows * gpr) return;
+  const long r = gid / gpr;
+  const int g = (int)(gid - r * gpr);
+  const T* src = x + r * ldx + 8 * g;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (float)src[e] * scale;
+  f16x8 h, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { h[e] = (f16_t)v[e]; l[e] = (f16_t)(v[e] - (float)h[e]); }
+  f16_t* dst = out + r * ldo + 16 * g;
+  *reinterpret_cast<f16x8*>(dst) = h;
+  *reinterpret_cast<f16x8*>(dst + 8) = l;
+}
+
+}  // namespace hipie
+
+using namespace hipie;
+
+extern "C" int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* resid, int64_t ldr,
+                          void* out, int64_t ldo, int M, int N, int K, int in_fmt, int out_fmt, int act, float alpha, float oscale,
+                          void* stream) {
+  HIPIE_REQUIRE(A && W && out, "gemm: null pointer");
+  HIPIE_REQUIRE(in_fmt == HIPIE_F16 || in_fmt == HIPIE_HL8, "gemm: operand format %d (HIPIE_F16 | HIPIE_HL8)", in_fmt);
+  HIPIE_REQUIRE(out_fmt == HIPIE_F32 || out_fmt == HIPIE_F16 || out_fmt == HIPIE_HL8, "gemm: output format %d", out_fmt);
+  HIPIE_REQUIRE(act >= 0 && act <= 2, "gemm: activation %d (0 none, 1 gelu, 2 relu)", act);
+  HIPIE_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0, "gemm: M=%d N=%d K=%d (N must be a multiple of 8)", M, N, K);
+  const bool split = in_fmt == HIPIE_HL8;
+  const int kq = split ? 32 : 64;               // elements per 128-byte k tile
+  HIPIE_REQUIRE(K % kq == 0, "gemm: K=%d must be a multiple of %d", K, kq);
+  const int epr = split ? 2 * K : K;            // fp16 elements per operand row
+  HIPIE_REQUIRE(lda >= epr && ldw >= epr && lda % 8 == 0 && ldw % 8 == 0, "gemm: operand row strides %ld / %ld (>= %d, multiples of 8)",
+                (long)lda, (long)ldw, epr);
+  HIPIE_REQUIRE((long)256 * lda * 2 < (1L << 31) && (long)320 * ldw * 2 < (1L << 31), "gemm: row stride too large");
+  const int opr = out_fmt == HIPIE_HL8 ? 2 * N : N;
+  HIPIE_REQUIRE(ldo >= opr && ldo % 4 == 0, "gemm: output row stride %ld (>= %d)", (long)ldo, opr);
+  HIPIE_REQUIRE(resid == nullptr || (ldr >= N && ldr % 4 == 0), "gemm: residual row stride %ld", (long)ldr);
+  HIPIE_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
+                ((uintptr_t)bias % 16) == 0 && ((uintptr_t)resid % 16) == 0, "gemm: pointers must be 16-byte aligned");
+  GemmParams p;
+  p.A = (const char*)A; p.W = (const char*)W; p.bias = bias; p.resid = resid; p.out = (char*)out;
+  p.lda_b = lda * 2; p.ldw_b = ldw * 2; p.ldr = ldr; p.ldo = ldo;
+  p.M = M; p.N = N; p.K = K; p.nkt = K / kq;
+  p.out_fmt = out_fmt; p.act = act; p.alpha = alpha; p.oscale = oscale;
+  hipStream_t st = (hipStream_t)stream;
+  const bool wide = (N % 320 == 0);
+  if (split) return wide ? launch_gemm<320, true>(p, st) : launch_gemm<256, true>(p, st);
+  return wide ? launch_gemm<320, false>(p, st) : launch_gemm<256, false>(p, st);
+}
+
+extern "C" int hipie_to_hl8(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int K, int x_dtype, float scale, void* stream) {
+  HIPIE_REQUIRE(x && out && rows > 0 && K > 0 && K % 8 == 0, "to_hl8: rows=%ld K=%d (K must be a multiple of 8)", (long)rows, K);
+  HIPIE_REQUIRE(ldx >= K && ldo >= 2 * K && ldo % 8 == 0, "to_hl8: row strides %ld / %ld", (long)ldx, (long)ldo);
+  const long n = rows * (K / 8);
+  const dim3 grid((unsigned)((n + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+  switch (x_dtype) {
+    case HIPIE_F32: hipLaunchKernelGGL(to_hl8_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (f16_t*)out, rows, K, ldx, ldo, scale); break;
+    case HIPIE_F16: hipLaunchKernelGGL(to_hl8_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t*)x, (f16_t*)out, rows, K, ldx, ldo, scale); break;
+    default: return set_err(HIPIE_EINVAL, "to_hl8: dtype %d", x_dtype);
+  }
+  return check_launch("to_hl8");
+}

@@ -9,6 +9,7 @@ import torch
 from . import _lib
 
 _DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+F32, F16, BF16, HL8 = 0, 1, 2, 4          # include/hipie_mi355.h: HIPIE_F32 / F16 / BF16 / HL8
 
 
 class _Profile(object):
@@ -634,4 +635,83 @@ def selftest(which, a, b=None):
     out = torch.empty(32 * 32 if which == 0 else 256, dtype=torch.float32, device=a.device)
     rc = lib.hipie_selftest(which, a.data_ptr(), None if b is None else b.data_ptr(), out.data_ptr(), _stream())
     _lib.check(rc, "hipie_selftest")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# hipie_gemm: the linears on the hand-written MFMA GEMM.  HL8 ("split fp16") tensors are plain fp16 torch tensors whose last
+# dimension is 2K: K/8 groups of [8 hi | 8 lo] (include/hipie_mi355.h HIPIE_HL8).
+def hl8_pack(x, scale=1.0):
+    """(..., K) float tensor -> (..., 2K) fp16 in HL8 layout, written with torch ops (weights, once per checkpoint; tests)."""
+    K = x.shape[-1]
+    assert K % 8 == 0
+    xs = x.float() * scale
+    hi = xs.half()
+    lo = (xs - hi.float()).half()
+    return torch.stack([hi.reshape(*x.shape[:-1], K // 8, 8), lo.reshape(*x.shape[:-1], K // 8, 8)], dim=-2).reshape(*x.shape[:-1], 2 * K).contiguous()
+
+
+def hl8_unpack(x):
+    """(..., 2K) fp16 HL8 -> (..., K) fp32 (hi + lo)."""
+    K2 = x.shape[-1]
+    g = x.reshape(*x.shape[:-1], K2 // 16, 2, 8).float()
+    return (g[..., 0, :] + g[..., 1, :]).reshape(*x.shape[:-1], K2 // 2)
+
+
+@_timed("to_hl8")
+def to_hl8(x, scale=1.0):
+    """(rows..., K) fp32 | fp16 device tensor (last dim contiguous, uniform row stride) -> (rows..., 2K) fp16 HL8 (hipie_to_hl8)."""
+    lib = _lib.load()
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    out = torch.empty(*x.shape[:-1], 2 * K, dtype=torch.float16, device=x.device)
+    if not x.is_cuda:
+        raise RuntimeError("Not implemented on the CPU (to_hl8)")
+    rc = lib.hipie_to_hl8(x2.data_ptr(), x2.stride(0), out.data_ptr(), 2 * K, x2.shape[0], K, _DT[x.dtype], float(scale), _stream())
+    _lib.check(rc, "hipie_to_hl8")
+    return out
+
+
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+
+@_timed(lambda a, w, *args, **kw: kw.get("tag", "gemm"))
+def gemm(a, w, bias=None, resid=None, out_fmt=F32, act=ACT_NONE, alpha=1.0, oscale=1.0, split=None, out=None, tag="gemm"):
+    """out = ((act(alpha * a . w^T + bias)) + resid) * oscale on hipie_gemm.
+    a (..., K) fp16 and w (N, K) fp16 (one product), or both HL8: a (..., 2K), w (N, 2K) fp16 (three products, fp32-class);
+    `split` tells which (default: inferred -- pass it when K is ambiguous).  a may be a row-strided 2-d view.  bias (N) f32,
+    resid (..., N) f32.  out_fmt F32 | F16 | HL8 -> (..., N) f32 / f16 or (..., 2N) fp16 HL8."""
+    lib = _lib.load()
+    if a.dtype != torch.float16 or w.dtype != torch.float16 or not a.is_cuda:
+        raise RuntimeError("gemm: operands must be fp16 (plain or HL8) device tensors")
+    if split is None:
+        raise RuntimeError("gemm: say split=True (HL8 operands) or split=False (plain fp16)")
+    N = w.shape[0]
+    Kw = w.shape[1] // 2 if split else w.shape[1]
+    lead = a.shape[:-1]
+    a2 = a if a.dim() == 2 else a.reshape(-1, a.shape[-1])
+    if a2.stride(-1) != 1 or a2.shape[-1] != w.shape[1]:
+        raise RuntimeError("gemm: a rows must be contiguous and as long as w rows (%s vs %s)" % (tuple(a.shape), tuple(w.shape)))
+    M = a2.shape[0]
+    if out is None:
+        if out_fmt == F32:
+            out = torch.empty(*lead, N, dtype=torch.float32, device=a.device)
+        elif out_fmt == F16:
+            out = torch.empty(*lead, N, dtype=torch.float16, device=a.device)
+        else:
+            out = torch.empty(*lead, 2 * N, dtype=torch.float16, device=a.device)
+    o2 = out.reshape(-1, out.shape[-1])
+    r2 = None
+    if resid is not None:
+        r2 = resid.reshape(-1, N)
+        if r2.dtype != torch.float32 or r2.stride(-1) != 1:
+            raise RuntimeError("gemm: resid must be fp32 with contiguous rows")
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
+        raise RuntimeError("gemm: bias must be contiguous fp32")
+    rc = lib.hipie_gemm(a2.data_ptr(), a2.stride(0), _chk(w, "w"), w.shape[1], None if bias is None else bias.data_ptr(),
+                        None if r2 is None else r2.data_ptr(), 0 if r2 is None else r2.stride(0), o2.data_ptr(), o2.stride(0),
+                        M, N, Kw, HL8 if split else F16, int(out_fmt), int(act), float(alpha), float(oscale), _stream())
+    _lib.check(rc, "hipie_gemm")
     return out

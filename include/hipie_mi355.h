@@ -21,13 +21,17 @@
 extern "C" {
 #endif
 
-#define HIPIE_ABI_VERSION 3
+#define HIPIE_ABI_VERSION 4
 
 /* element types of activations */
 #define HIPIE_F32 0
 #define HIPIE_F16 1
 #define HIPIE_BF16 2
 #define HIPIE_F64 3          /* hipie_msda_forward only (the reference op dispatches float | double) */
+#define HIPIE_HL8 4          /* SPLIT fp16 ("hi + lo in groups of 8"): a logical row of K values is stored as K/8 groups of 32 bytes,
+                                8 fp16 hi[0..7] then 8 fp16 lo[0..7], with hi = fp16(x), lo = fp16(x - hi): hi + lo == x to 2^-22.
+                                Same bytes as fp32; the operand format of the fp32-class products on the 16-bit matrix pipe
+                                (hipie_gemm, hipie_vit_attn_rel with HIPIE_ATTN_SPLIT).  Row strides are given in fp16 elements (>= 2K). */
 
 /* flags of the attention entry points that take a `flags` argument */
 #define HIPIE_ATTN_FAST 1    /* deferred running max (rescale only when a row maximum grows by > 2^8) and, where the head dim
@@ -351,6 +355,30 @@ int hipie_sine_embed(const float* ref, const float* dim_t, void* out, int64_t n,
  *   delta (n) `delta_dtype`, ref (n) f32, out (n) f32 (n = boxes * 4).
  */
 int hipie_box_refine(const void* delta, const float* ref, float* out, int64_t n, float eps, int delta_dtype, void* stream);
+
+/*
+ * The linears of the path as one hand-written MFMA GEMM:   out = epilogue( alpha * A (M x K) . W^T + bias ),  W (N x K) as
+ * torch.nn.Linear stores it.  Replaces: nn.Linear / F.linear of Attention.qkv / proj and Mlp.fc1 / fc2 (hipie/backbone/vit.py:
+ * 67-83, 193-197, 212-230), BertLayer's dense layers (transformers BertModel via models/deformable_detr/bert_model.py:54-58), the
+ * FFNs and projections of the deformable encoder / decoder layers (models/deformable_detr/deformable_transformer_dino.py:378-394,
+ * 418-450; ops/modules/ms_deform_attn.py:95-99) -- which the reference runs in fp32.
+ *   in_fmt   HIPIE_F16: A (M, K) and W (N, K) fp16, one MFMA per product;
+ *            HIPIE_HL8: both operands split fp16 (rows of 2K fp16); the product is W_lo.A_hi + W_hi.A_lo + W_hi.A_hi with fp32
+ *            accumulation = fp32-class results (every fp16 x fp16 product is exact in fp32; the dropped lo x lo term is 2^-22).
+ *   lda, ldw row strides in fp16 elements (multiples of 8);  K a multiple of 64 (F16) / 32 (HL8);  N a multiple of 8
+ *   bias     (N) f32 or NULL;   resid (M, N) f32 with row stride ldr, or NULL
+ *   epilogue y = alpha * acc + bias;  act 1: exact-erf GELU(y), 2: ReLU(y);  y = (y + resid) * oscale
+ *   out      (M, N) in out_fmt HIPIE_F32 | HIPIE_F16 | HIPIE_HL8 (row stride ldo in elements of that format; HL8: fp16 elements >= 2N):
+ *            the HL8 form is directly the A operand of a following hipie_gemm.
+ * All pointers 16-byte aligned.  Deterministic (fixed accumulation order).
+ */
+int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* resid, int64_t ldr,
+               void* out, int64_t ldo, int M, int N, int K, int in_fmt, int out_fmt, int act, float alpha, float oscale,
+               void* stream);
+
+/* rows of `x_dtype` (HIPIE_F32 | HIPIE_F16) values -> HIPIE_HL8 rows of scale * x (K a multiple of 8; ldx in elements of x, ldo in
+ * fp16 elements >= 2K): the generic producer of split operands (the LayerNorm / GEMM epilogues emit HL8 directly). */
+int hipie_to_hl8(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int K, int x_dtype, float scale, void* stream);
 
 /* device-side self-test helpers used by tests/ to pin the MFMA / LDS-transpose lane layouts this library assumes.
  *   which 0: D = A(32x16) . B(16x32) with v_mfma_f32_32x32x16_bf16, operands loaded with the layouts documented in

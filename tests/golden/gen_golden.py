@@ -406,6 +406,18 @@ def gen_e2e_long():
     gen_e2e(TINY, "e2e_long_tiny", (("detection", 400, 815, 896),))
 
 
+DEEP = dict(TINY, vit_depth=32, vit_window_blocks=[0, 1, 3, 4, 6, 7, 9, 10], dim_feedforward=2048, enc_layers=6, dec_layers=6,
+            num_queries=900, num_bg_queries=10, md_num_queries=300, md_dec_layers=9, md_enc_layers=6, md_dim_feedforward=2048,
+            md_enc_dim_feedforward=2048, bert_layers=12)
+
+
+def gen_e2e_deep():
+    """the shipped DEPTHS on a narrow ViT: 32 blocks with the real window pattern (vit.py:412-421; dim 160 = 2 heads x 80 keeps
+    the CPU run short), encoder 6 / decoder 6 / MaskDINO encoder 6 + decoder 9, FFN 2048, 900 + 10 / 300 queries, 12-layer
+    BERT, two 256-pixel images -- rounding errors accumulate over the real number of layers (e2e_tiny is 3 / 2 / 2 / 3 deep)."""
+    gen_e2e(DEEP, "e2e_deep", (("detection", 9),))
+
+
 # ------------------------------------------------------------------------------ sub-module goldens from the e2e model
 def gen_stages():
     """Intermediate tensors of the same tiny model (detection task), for stage-by-stage checks:
@@ -583,7 +595,7 @@ def gen_manifest_full():
 
 
 ALL = dict(manifest_full=gen_manifest_full, prompts=gen_prompts, post=gen_post, resnet50=gen_resnet50, msda=gen_msda, vit_attn=gen_vit_attn, vit_backbone=gen_vit_backbone, bi_attn=gen_bi_attn, bert=gen_bert,
-           dynamic_mask=gen_dynamic_mask, e2e=gen_e2e, stages=gen_stages, e2e_r50=gen_e2e_r50, e2e_long=gen_e2e_long)
+           dynamic_mask=gen_dynamic_mask, e2e=gen_e2e, stages=gen_stages, e2e_r50=gen_e2e_r50, e2e_long=gen_e2e_long, e2e_deep=gen_e2e_deep)
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)

@@ -1,0 +1,182 @@
+"""GPU: hipie_gemm (plain fp16 and split-fp16 "HL8" operands) against fp64 torch.matmul.
+
+Tolerances (max|a-b| / max|b|):
+  split (HL8 x HL8, three MFMA products, fp32 accumulation)  3e-6 against the fp64 product of the ORIGINAL fp32 operands --
+        the reference runs these linears in fp32 (hipie/backbone/vit.py:67-83, deformable_transformer_dino.py:378-394);
+  plain fp16                                                  3e-6 against the fp64 product of the fp16-ROUNDED operands (the only
+        error left is the fp32 accumulation order), 1e-3 against the product of the unrounded operands (the operand rounding).
+"""
+import pytest
+import torch
+
+from util import rel_err
+
+torch.set_grad_enabled(False)
+
+
+def test_hl8_pack_roundtrip_cpu():
+    from hipie_amd import ops
+    x = torch.randn(7, 64) * torch.logspace(-6, 3, 64)
+    p = ops.hl8_pack(x)
+    assert p.shape == (7, 128) and p.dtype == torch.float16
+    back = ops.hl8_unpack(p)
+    big = x.abs() > 0.25                 # lo = fp16(x - hi) is a NORMAL fp16 there: the pair carries 22 bits
+    assert ((back - x).abs()[big] <= x.abs()[big] * 2.0 ** -21).all()
+    assert ((back - x).abs() <= 2.0 ** -25 + x.abs() * 2.0 ** -21).all()      # below: lo is subnormal, absolute error 2^-25
+    # layout: group g of 8 values -> 8 hi then 8 lo
+    assert torch.equal(p[:, 0:8], x[:, 0:8].half())
+    assert torch.equal(p[:, 16:24], x[:, 8:16].half())
+
+
+gpu = pytest.mark.gpu
+
+
+def _ref(a, w, bias, resid, act, alpha, oscale):
+    y = alpha * (a.double() @ w.double().t())
+    if bias is not None:
+        y = y + bias.double()
+    if act == 1:
+        y = torch.nn.functional.gelu(y)
+    elif act == 2:
+        y = torch.relu(y)
+    if resid is not None:
+        y = y + resid.double()
+    return y * oscale
+
+
+@gpu
+def test_to_hl8_kernel_matches_torch_pack():
+    from hipie_amd import ops
+    x = (torch.randn(301, 1280, device="cuda") * 3).contiguous()
+    assert torch.equal(ops.to_hl8(x), ops.hl8_pack(x))
+    assert torch.equal(ops.to_hl8(x, 16.0), ops.hl8_pack(x, 16.0))
+    xs = torch.randn(50, 512, device="cuda")[:, :256]          # row-strided view
+    assert torch.equal(ops.to_hl8(xs), ops.hl8_pack(xs))
+    xh = torch.randn(33, 64, device="cuda").half()
+    assert torch.equal(ops.to_hl8(xh), ops.hl8_pack(xh))
+
+
+SHAPES = [  # M, N, K
+    (300, 256, 256),          # M tail, one N tile of 256
+    (512, 1280, 1280),        # the 320-wide tile (ViT-H proj), two full M tiles
+    (700, 384, 768),          # N tail inside a 256 tile
+    (257, 640, 2048),         # 320 tile, M tail of one row
+    (64, 2048, 256),          # small M
+    (1000, 3840, 1280),       # ViT-H qkv
+]
+
+
+@gpu
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_split_fp32_class(M, N, K):
+    from hipie_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g) * 2.0
+    w = torch.randn(N, K, device="cuda", generator=g) * (K ** -0.5)
+    bias = torch.randn(N, device="cuda", generator=g)
+    out = ops.gemm(ops.hl8_pack(a), ops.hl8_pack(w), bias, split=True)
+    err = rel_err(out.cpu(), _ref(a, w, bias, None, 0, 1.0, 1.0).cpu())
+    print("split M=%d N=%d K=%d err %.2e" % (M, N, K, err))
+    assert err < 3e-6
+
+
+@gpu
+def test_gemm_split_small_magnitudes():
+    """operands whose lo halves are fp16 SUBNORMALS (|x| ~ 1e-2): the matrix pipe must not flush them (error would be ~1e-4)."""
+    from hipie_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.randn(512, 512, device="cuda", generator=g) * 1e-2
+    w = torch.randn(256, 512, device="cuda", generator=g) * 1e-2
+    out = ops.gemm(ops.hl8_pack(a), ops.hl8_pack(w), None, split=True)
+    err = rel_err(out.cpu(), _ref(a, w, None, None, 0, 1.0, 1.0).cpu())
+    print("split, subnormal lo parts: err %.2e" % err)
+    assert err < 2e-5
+
+
+@gpu
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_plain_fp16(M, N, K):
+    from hipie_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M * 3 + N + K)
+    a = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) * (K ** -0.5)
+    bias = torch.randn(N, device="cuda", generator=g)
+    a16, w16 = a.half(), w.half()
+    out = ops.gemm(a16, w16, bias, split=False)
+    e16 = rel_err(out.cpu(), _ref(a16, w16, bias, None, 0, 1.0, 1.0).cpu())
+    e32 = rel_err(out.cpu(), _ref(a, w, bias, None, 0, 1.0, 1.0).cpu())
+    print("plain M=%d N=%d K=%d err vs rounded operands %.2e, vs fp32 operands %.2e" % (M, N, K, e16, e32))
+    assert e16 < 3e-6 and e32 < 1e-3
+
+
+@gpu
+@pytest.mark.parametrize("split", [True, False])
+@pytest.mark.parametrize("out_fmt", ["f32", "f16", "hl8"])
+@pytest.mark.parametrize("act,with_res", [(0, False), (1, False), (2, True), (0, True)])
+def test_gemm_epilogues(split, out_fmt, act, with_res):
+    from hipie_amd import ops
+    M, N, K = 333, 640, 512
+    g = torch.Generator(device="cuda").manual_seed(17)
+    a = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) * (K ** -0.5)
+    bias = torch.randn(N, device="cuda", generator=g)
+    resid = torch.randn(M, N, device="cuda", generator=g) if with_res else None
+    alpha, osc = 0.5, (4.0 if out_fmt != "f32" else 1.0)
+    if split:
+        A, W = ops.hl8_pack(a), ops.hl8_pack(w)
+        ar, wr = a, w
+    else:
+        A, W = a.half(), w.half()
+        ar, wr = A, W
+    fmt = {"f32": ops.F32, "f16": ops.F16, "hl8": ops.HL8}[out_fmt]
+    out = ops.gemm(A, W, bias, resid, out_fmt=fmt, act=act, alpha=alpha, oscale=osc, split=split)
+    ref = _ref(ar, wr, bias, resid, act, alpha, osc).cpu()
+    if out_fmt == "hl8":
+        assert out.shape == (M, 2 * N) and out.dtype == torch.float16
+        got = ops.hl8_unpack(out).cpu()
+        tol = 3e-6
+        # the pair is exactly the split of the fp32 value the kernel computed
+        assert torch.equal(out.cpu(), ops.hl8_pack(got))
+    elif out_fmt == "f16":
+        got, tol = out.float().cpu(), 6e-4          # one fp16 rounding of the result
+    else:
+        got, tol = out.cpu(), 3e-6
+    err = rel_err(got, ref)
+    print("epilogue split=%s out=%s act=%d res=%s err %.2e" % (split, out_fmt, act, with_res, err))
+    assert err < tol
+
+
+@gpu
+def test_gemm_strided_rows_and_chaining():
+    """A as a column block of a wider tensor (row stride > K) and an HL8 output fed straight into the next GEMM (fc1 -> GELU -> fc2)."""
+    from hipie_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(23)
+    M, K, Hd = 520, 256, 1024
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w1 = torch.randn(Hd, K, device="cuda", generator=g) * (K ** -0.5)
+    w2 = torch.randn(K, Hd, device="cuda", generator=g) * (Hd ** -0.5)
+    b1 = torch.randn(Hd, device="cuda", generator=g)
+    b2 = torch.randn(K, device="cuda", generator=g)
+    wide = torch.zeros(M, 3 * 2 * K, dtype=torch.float16, device="cuda")
+    wide[:, 2 * K:4 * K] = ops.hl8_pack(x)
+    h = ops.gemm(wide[:, 2 * K:4 * K], ops.hl8_pack(w1), b1, out_fmt=ops.HL8, act=ops.ACT_GELU, split=True)
+    y = ops.gemm(h, ops.hl8_pack(w2), b2, resid=x, split=True)
+    ref = torch.nn.functional.gelu(x.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double() + x.double()
+    err = rel_err(y.cpu(), ref.cpu())
+    print("chained split MLP err %.2e" % err)
+    assert err < 3e-6
+
+
+@gpu
+def test_gemm_rejects_bad_arguments():
+    from hipie_amd import ops
+    a = torch.zeros(8, 96, dtype=torch.float16, device="cuda")
+    w = torch.zeros(16, 96, dtype=torch.float16, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.gemm(a, w, split=False)             # K = 96 is not a multiple of 64
+    with pytest.raises(RuntimeError):
+        ops.gemm(a.float(), w, split=False)
+    w2 = torch.zeros(12, 128, dtype=torch.float16, device="cuda")
+    a2 = torch.zeros(8, 128, dtype=torch.float16, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.gemm(a2, w2, split=False)           # N = 12 is not a multiple of 8

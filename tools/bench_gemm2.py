@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""hipie_gemm (plain fp16 / split HL8) vs the library GEMMs on the ViT-H linears (M = batch * 4096 tokens) and the head shapes.
+Prints ms, algorithmic TFLOP/s (2MNK / t) and, for the split form, the MFMA-issue rate (3x)."""
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, ".")
+from hipie_amd import ops  # noqa: E402
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+SHAPES = [("qkv", M, 1280, 3840), ("proj", M, 1280, 1280), ("fc1", M, 1280, 5120), ("fc2", M, 5120, 1280),
+          ("enc_ffn1", 174080, 256, 2048), ("enc_ffn2", 174080, 2048, 256), ("dec", 7280, 256, 256)]
+
+
+def bench(fn, n=10):
+    for _ in range(2):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+def main():
+    for name, m, K, N in SHAPES:
+        x = torch.randn(m, K, device="cuda")
+        w = torch.randn(N, K, device="cuda") * K ** -0.5
+        b = torch.randn(N, device="cuda")
+        x16, w16, b16 = x.half(), w.half(), b.half()
+        xs, ws = ops.to_hl8(x), ops.hl8_pack(w)
+        gf = 2.0 * m * K * N / 1e9
+        t_lib16 = bench(lambda: F.linear(x16, w16, b16))
+        t_lib32 = bench(lambda: F.linear(x, w, b), n=3)
+        t_p = bench(lambda: ops.gemm(x16, w16, b, out_fmt=ops.F16, split=False))
+        t_s = bench(lambda: ops.gemm(xs, ws, b, out_fmt=ops.F32, split=True))
+        t_sg = bench(lambda: ops.gemm(xs, ws, b, out_fmt=ops.HL8, act=ops.ACT_GELU, split=True))
+        print("%-9s M=%6d K=%4d N=%4d | lib fp16 %.3f ms %5.0f TF | lib fp32 %.3f ms %4.0f TF | hipie fp16 %.3f ms %5.0f TF | "
+              "hipie split %.3f ms %4.0f TF (MFMA %5.0f) | split+gelu->hl8 %.3f ms" %
+              (name, m, K, N, t_lib16, gf / t_lib16, t_lib32, gf / t_lib32, t_p, gf / t_p, t_s, gf / t_s, 3 * gf / t_s, t_sg), flush=True)
+        del x, w, x16, w16, xs, ws
+
+
+if __name__ == "__main__":
+    main()
