@@ -37,6 +37,8 @@ class Precision:
     attn_fast: bool = True
     name: str = "default"
     text: torch.dtype = torch.float32      # BERT GEMM / stream dtype (16 bit: fused QKV + hipie_flash_attn + hipie_add_layernorm)
+    split: bool = False                    # every linear as hipie_gemm on SPLIT fp16 operands (hi + lo, three MFMA products, fp32
+                                           # accumulation = fp32-class results), ViT attention logits likewise (hipie_vit_attn_split)
 
     @staticmethod
     def parity():
@@ -44,9 +46,21 @@ class Precision:
         return Precision(torch.float32, torch.float16, torch.float32, torch.float32, 0, torch.float32, torch.float32, False, "parity")
 
     @staticmethod
+    def split3():
+        """the TIMED policy: the reference's fp32 arithmetic reproduced on the 16-bit matrix pipe.  Every linear runs as the split-fp16
+        GEMM (hipie_gemm, HIPIE_HL8 operands: x.w = x_lo.w_hi + x_hi.w_lo + x_hi.w_hi with fp32 accumulation, ~2^-22 operand error),
+        the ViT attention forms its logits the same way (hipie_vit_attn_split); probabilities are one fp16, streams / norms / softmax /
+        deformable sampling / convolutions / contractions fp32 as in the parity policy.  tools/prec_sim.py: 4.9e-4 on the full-depth
+        fixture (the parity policy's single-fp16 attention logits: 1.9e-3)."""
+        p = Precision.parity()
+        p.split, p.name = True, "split"
+        return p
+
+    @staticmethod
     def fast():
-        """the timed policy: fp16 operands everywhere (same MFMA rate as bf16, 3 more mantissa bits), fp32 accumulation,
-        fp32 ViT residual stream; inside the north star's 1e-3-class tolerance end to end (tests/test_gpu_e2e.py)."""
+        """fp16 operands everywhere (same MFMA rate as bf16, 3 more mantissa bits), fp32 accumulation, fp32 ViT residual stream.
+        OUTSIDE the north star's 1e-3 tolerance (measured 1e-3 .. 6e-3 on the 3-block fixture, 1.2e-2 at the shipped depths):
+        an opt-in throughput mode, not the default and not the headline."""
         return Precision(torch.float16, torch.float16, torch.float16, torch.float16, 4, torch.float16, torch.float32, True, "fast",
                          torch.float16)
 

@@ -46,6 +46,18 @@ template <> struct elem<f16_t> {
   static __device__ __forceinline__ f16_t from_f32(float x) { return (f16_t)x; }
 };
 
+// x -> (hi, lo) fp16 pair with hi = fp16(x), lo = fp16(x - hi)  (HIPIE_HL8).  The value is pinned in a register first: hipcc otherwise
+// folds the multiply that PRODUCED x into a v_fma_mix*_f16 for one of its two uses (single rounding of the exact product) while the other
+// use converts the fp32-rounded product -- near an fp16 tie the stored hi and the hi the remainder was taken from then differ by one ulp
+// (measured: isolated 1-ulp(hi) errors in one output of 1e5).
+__device__ __forceinline__ void hl_split(float x, f16_t& h, f16_t& l) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(x));
+#endif
+  h = (f16_t)x;
+  l = (f16_t)(x - (float)h);
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace hipie

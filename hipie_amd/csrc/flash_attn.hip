@@ -42,6 +42,7 @@ struct FAParams {
   const uint8_t* key_mask;
   float scale, clamp, defer;
   int nqt, ntiles, swz, prio;
+  int out_f32;                  // HIPIE_OUT_F32: `out` is fp32 (strides in fp32 elements) -- no 16-bit rounding of the attention output
 };
 
 constexpr float kLog2e = 1.4426950408889634f;
@@ -474,7 +475,19 @@ __global__ __launch_bounds__(WAVES * 64, ((WAVES == 8 || HD <= 80) && QB == 1) ?
   for (int qb = 0; qb < QB; ++qb) {
     const float l_tot = LTRICK ? __shfl(O[qb][DB - 1][L_REG], li + 32 * L_HI) : l_run[qb] + __shfl_xor(l_run[qb], 32);
     const float inv = 1.f / l_tot;
-    if (qi[qb] < p.Nq) {
+    if (qi[qb] < p.Nq && p.out_f32) {
+      float* orow = reinterpret_cast<float*>(p.out) + b * p.o_sb + h * p.o_sh + (long)qi[qb] * p.o_st;
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int d0 = 32 * d + 8 * rr + 4 * hi;
+          if (d0 < HD)
+            *reinterpret_cast<float4*>(orow + d0) = make_float4(O[qb][d][4 * rr] * inv, O[qb][d][4 * rr + 1] * inv, O[qb][d][4 * rr + 2] * inv,
+                                                                O[qb][d][4 * rr + 3] * inv);
+        }
+      }
+    } else if (qi[qb] < p.Nq) {
       T* orow = Og + (long)qi[qb] * p.o_st;
 #pragma unroll
       for (int d = 0; d < DB; ++d) {
@@ -570,7 +583,7 @@ static int flash_attn_impl(FAParams p, int hd, int dtype, void* stream) {
   for (long s : strides) HIPIE_REQUIRE(s % 8 == 0, "flash_attn: strides must be multiples of 8 elements (16 bytes), got %ld", s);
   HIPIE_REQUIRE((((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v | (uintptr_t)p.out) & 15) == 0, "flash_attn: pointers must be 16-byte aligned");
   p.swz = ((p.B * p.H) % 8 == 0) ? 1 : 0;
-  p.defer = (dtype == HIPIE_F16) ? 0.f : kDefer;      // fp16 = parity policy: classic running max
+  p.defer = ((dtype & ~HIPIE_OUT_F32) == HIPIE_F16) ? 0.f : kDefer;      // fp16 = parity policy: classic running max
   { const char* d = getenv("HIPIE_FA_DEFER"); if (d) p.defer = (float)atof(d); }
   { static int prio = -1; if (prio < 0) { const char* e = getenv("HIPIE_FA_PRIO"); prio = e ? atoi(e) : 1; } p.prio = prio; }   // +1.5 % (tools/bench_attn.py)
   // 8 waves (256 queries) per workgroup halve the K/V traffic per query but keep all waves of a CU in lockstep
@@ -578,6 +591,8 @@ static int flash_attn_impl(FAParams p, int hd, int dtype, void* stream) {
   const char* e = getenv("HIPIE_FA_WAVES");
   if (e && (e[0] == '4' || e[0] == '8')) wide = (e[0] == '8');
   hipStream_t st = (hipStream_t)stream;
+  p.out_f32 = (dtype & HIPIE_OUT_F32) ? 1 : 0;
+  dtype &= ~HIPIE_OUT_F32;
   switch (dtype) {
     case HIPIE_F16: return dispatch_hd<f16_t>(p, hd, st, wide);
     case HIPIE_BF16: return dispatch_hd<bf16_t>(p, hd, st, wide);
@@ -673,7 +688,9 @@ extern "C" int hipie_bi_xattn_ws(const void* q, const void* k, const void* vv, c
   a.k_sb = a.v_sb = (long)L * E; a.k_st = a.v_st = E; a.k_sh = a.v_sh = hd;
   a.o_sb = (long)Nv * E; a.o_st = E; a.o_sh = hd;
   a.key_mask = text_mask; a.scale = 1.f; a.clamp = clamp;
-  static const bool generic_only = getenv("HIPIE_XATTN_GENERIC") != nullptr;      // diagnostics: the flash kernel for both directions
+  // the flash kernel for both directions: diagnostics, and fp32 outputs (the specialised kernels write the operand type)
+  static const bool generic_env = getenv("HIPIE_XATTN_GENERIC") != nullptr;
+  const bool generic_only = generic_env || (dtype & HIPIE_OUT_F32) != 0;
   int rc = generic_only ? 1 : xattn_i2t_try(q, k, vl, text_mask, out_v, B, H, Nv, L, hd, E, clamp, dtype, (hipStream_t)stream);
   if (rc == 1) rc = flash_attn_impl(a, hd, dtype, stream);     // shapes the specialised kernel does not cover (L <= 64: one tile; L > 224)
   if (rc != HIPIE_OK) return rc;

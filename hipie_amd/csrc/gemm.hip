@@ -64,6 +64,14 @@ __device__ __forceinline__ unsigned int gm_pack2(float a, float b) {
   return __builtin_bit_cast(unsigned int, v);
 }
 
+__device__ __forceinline__ unsigned int gm_pack2h(f16_t a, f16_t b) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  h2 v;
+  v[0] = a;
+  v[1] = b;
+  return __builtin_bit_cast(unsigned int, v);
+}
+
 template <int BN, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
   constexpr int BM = 256;
@@ -188,24 +196,39 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
   }
 
   // ---- epilogue: lane = token (column of the MFMA tile), registers = features ----
-  const bool has_bias = p.bias != nullptr, has_res = p.resid != nullptr;
+  const bool has_res = p.resid != nullptr;
   const int act = p.act, ofmt = p.out_fmt;
   const float alpha = p.alpha, osc = p.oscale;
+  // the tile's bias values go through LDS once (the stage buffers are free after the last barrier): the per-quad bias reads are then
+  // LDS reads the compiler can schedule freely between the global stores (a global read behind every store serialised the epilogue)
+  float* sbias = reinterpret_cast<float*>(smem);
+  if (tid < BN) sbias[tid] = (p.bias != nullptr && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
+  __syncthreads();
+  // residual rows: the four quads of block (t, j + 1) are requested before block (t, j) is processed
+  float4 rq[2][4];
+  auto load_res = [&](const int t, const int j, float4 (&dst)[4]) {
+    const int m = m0 + wm * 64 + t * 32 + li;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * hi;
+      dst[g] = (has_res && m < p.M && n < p.N) ? *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  load_res(0, 0, rq[0]);
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int m = m0 + wm * 64 + t * 32 + li;
     const bool mok = m < p.M;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
+      const int blk = t * NJ + j;
+      if (blk + 1 < 2 * NJ) load_res((blk + 1) / NJ, (blk + 1) % NJ, rq[(blk + 1) & 1]);
       const int nb = n0 + wn * (BN / 2) + j * 32;             // first feature of the 32-row MFMA block
       float v[4][4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n = nb + 8 * g + 4 * hi;
-        const bool ok = mok && n < p.N;
-        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), r4 = b4;
-        if (has_bias && n < p.N) b4 = *reinterpret_cast<const float4*>(p.bias + n);
-        if (has_res && ok) r4 = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldr + n);
+        const float4 b4 = *reinterpret_cast<const float4*>(sbias + (nb - n0) + 8 * g + 4 * hi);
+        const float4 r4 = rq[blk & 1][g];
         const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -241,12 +264,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
         for (int g = 0; g < 4; ++g) {
           typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
           typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-          float lo[4];
-          f16_t h[4];
+          f16_t h[4], l[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { h[e] = (f16_t)v[g][e]; lo[e] = v[g][e] - (float)h[e]; }
-          const unsigned int H0 = gm_pack2((float)h[0], (float)h[1]), H1 = gm_pack2((float)h[2], (float)h[3]);
-          const unsigned int L0 = gm_pack2(lo[0], lo[1]), L1 = gm_pack2(lo[2], lo[3]);
+          for (int e = 0; e < 4; ++e) hl_split(v[g][e], h[e], l[e]);
+          const unsigned int H0 = gm_pack2h(h[0], h[1]), H1 = gm_pack2h(h[2], h[3]);
+          const unsigned int L0 = gm_pack2h(l[0], l[1]), L1 = gm_pack2h(l[2], l[3]);
           const u32x2 s0 = __builtin_amdgcn_permlane32_swap(H0, L0, false, false);    // lower: (H0 own, H0 of upper); upper: (L0 of lower, L0 own)
           const u32x2 s1 = __builtin_amdgcn_permlane32_swap(H1, L1, false, false);
           const int n = nb + 8 * g;
@@ -285,12 +307,14 @@ __global__ __launch_bounds__(256) void to_hl8_kernel(const T* __restrict__ x, f1
   const long r = gid / gpr;
   const int g = (int)(gid - r * gpr);
   const T* src = x + r * ldx + 8 * g;
-  float v[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = (float)src[e] * scale;
   f16x8 h, l;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { h[e] = (f16_t)v[e]; l[e] = (f16_t)(v[e] - (float)h[e]); }
+  for (int e = 0; e < 8; ++e) {
+    f16_t hh, ll;
+    hl_split((float)src[e] * scale, hh, ll);
+    h[e] = hh;
+    l[e] = ll;
+  }
   f16_t* dst = out + r * ldo + 16 * g;
   *reinterpret_cast<f16x8*>(dst) = h;
   *reinterpret_cast<f16x8*>(dst + 8) = l;

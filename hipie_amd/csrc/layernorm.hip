@@ -51,6 +51,36 @@ template <> struct V4<f16_t> {
   }
 };
 
+// HIPIE_HL8 as an OUTPUT (or addend) type of these kernels.  An HL8 row of C values occupies 4 C bytes like an fp32 row, so the kernels'
+// element indexing (row * C + c, 4-byte elements) lands on the right row; inside the row the 4 consecutive values of a lane (c % 8 is 0
+// or 4) live at bytes 32 (c / 8) + 2 (c % 8) (hi) and + 16 (lo).  With p = base + 4 c that is p / p + 16 for c % 8 == 0 and p - 8 / p + 8 for
+// c % 8 == 4 (bit 4 of p: the rows are 32-byte aligned because C % 8 == 0 and torch allocations are).
+struct hl8_t { unsigned int u; };
+template <> struct V4<hl8_t> {
+  static __device__ __forceinline__ void ld(const hl8_t* p, float (&v)[4]) {
+    const char* q = reinterpret_cast<const char*>(p);
+    const bool second = (reinterpret_cast<uintptr_t>(q) & 16) != 0;
+    const f16x4 h = *reinterpret_cast<const f16x4*>(second ? q - 8 : q);
+    const f16x4 l = *reinterpret_cast<const f16x4*>(second ? q + 8 : q + 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)h[i] + (float)l[i];
+  }
+  static __device__ __forceinline__ void st(hl8_t* p, const float (&v)[4]) {
+    char* q = reinterpret_cast<char*>(p);
+    const bool second = (reinterpret_cast<uintptr_t>(q) & 16) != 0;
+    f16x4 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f16_t hh, ll;
+      hl_split(v[i], hh, ll);
+      h[i] = hh;
+      l[i] = ll;
+    }
+    *reinterpret_cast<f16x4*>(second ? q - 8 : q) = h;
+    *reinterpret_cast<f16x4*>(second ? q + 8 : q + 16) = l;
+  }
+};
+
 constexpr int LN_MAXV = 8;     // up to 8 x 4 elements per lane: C <= 2048
 // row maps of the call being dispatched (host-side plumbing through the dtype switch; set and cleared by the entry points)
 static thread_local const int32_t* g_delta_row = nullptr;
@@ -159,6 +189,9 @@ static int ln_out(int nd, const void* x, const void* d, const float* g, const fl
     case HIPIE_F32: return launch_ln<Tx, Td, float>(x, d, g, b, r, n, rows, C, eps, st);
     case HIPIE_F16: return launch_ln<Tx, Td, f16_t>(x, d, g, b, r, n, rows, C, eps, st);
     case HIPIE_BF16: return launch_ln<Tx, Td, bf16_t>(x, d, g, b, r, n, rows, C, eps, st);
+    case HIPIE_HL8:
+      if (C % 8 != 0 || (reinterpret_cast<uintptr_t>(n) & 31) != 0) return set_err(HIPIE_EINVAL, "add_layernorm: HL8 output needs C %% 8 == 0 and a 32-byte aligned buffer");
+      return launch_ln<Tx, Td, hl8_t>(x, d, g, b, r, n, rows, C, eps, st);
     default: return set_err(HIPIE_EINVAL, "add_layernorm: bad norm dtype %d", nd);
   }
 }
@@ -306,12 +339,16 @@ extern "C" int hipie_add_layernorm_dec(const float* x, const void* delta, const 
   HIPIE_REQUIRE(x && delta && gamma && beta && norm_out, "add_layernorm_dec: null pointer");
   HIPIE_REQUIRE((sum16_out == nullptr) || (addend != nullptr), "add_layernorm_dec: sum16_out needs addend");
   HIPIE_REQUIRE(rows >= 0 && C > 0 && C % 4 == 0 && C <= LN_MAXV * 256, "add_layernorm_dec: C=%d must be a multiple of 4 and <= %d", C, LN_MAXV * 256);
-  HIPIE_REQUIRE(aux_dtype == HIPIE_F16 || aux_dtype == HIPIE_BF16, "add_layernorm_dec: aux dtype must be f16 or bf16");
+  HIPIE_REQUIRE(aux_dtype == HIPIE_F16 || aux_dtype == HIPIE_BF16 || aux_dtype == HIPIE_HL8, "add_layernorm_dec: aux dtype must be f16, bf16 or HL8");
+  HIPIE_REQUIRE(aux_dtype != HIPIE_HL8 || (C % 8 == 0 && (((uintptr_t)norm16_out | (uintptr_t)addend | (uintptr_t)sum16_out) & 31) == 0),
+                "add_layernorm_dec: HL8 outputs need C %% 8 == 0 and 32-byte aligned buffers");
   if (rows == 0) return HIPIE_OK;
   hipStream_t st = (hipStream_t)stream;
 #define HIPIE_LND(Td)                                                                                                          \
   return aux_dtype == HIPIE_F16                                                                                                \
              ? launch_ln_dec<Td, f16_t>(x, delta, gamma, beta, norm_out, norm16_out, addend, sum16_out, rows, C, eps, st)      \
+         : aux_dtype == HIPIE_HL8                                                                                              \
+             ? launch_ln_dec<Td, hl8_t>(x, delta, gamma, beta, norm_out, norm16_out, addend, sum16_out, rows, C, eps, st)      \
              : launch_ln_dec<Td, bf16_t>(x, delta, gamma, beta, norm_out, norm16_out, addend, sum16_out, rows, C, eps, st);
   switch (delta_dtype) {
     case HIPIE_F32: HIPIE_LND(float)
@@ -326,12 +363,15 @@ extern "C" int hipie_add_cast(const float* a, const void* b, void* out, int64_t 
   using namespace hipie;
   HIPIE_REQUIRE(a && b && out, "add_cast: null pointer");
   HIPIE_REQUIRE(n >= 0 && n % 4 == 0, "add_cast: n must be a multiple of 4");
-  HIPIE_REQUIRE(dtype == HIPIE_F16 || dtype == HIPIE_BF16, "add_cast: dtype must be f16 or bf16");
+  HIPIE_REQUIRE(dtype == HIPIE_F16 || dtype == HIPIE_BF16 || dtype == HIPIE_HL8, "add_cast: dtype must be f16, bf16 or HL8");
+  HIPIE_REQUIRE(dtype != HIPIE_HL8 || (n % 8 == 0 && (((uintptr_t)b | (uintptr_t)out) & 31) == 0), "add_cast: HL8 needs n %% 8 == 0 and 32-byte aligned buffers");
   if (n == 0) return HIPIE_OK;
   hipStream_t st = (hipStream_t)stream;
   const long n4 = n / 4;
   const unsigned grid = (unsigned)((n4 + 255) / 256);
-  if (dtype == HIPIE_F16)
+  if (dtype == HIPIE_HL8)
+    hipLaunchKernelGGL((add_cast_kernel<hl8_t>), dim3(grid), dim3(256), 0, st, a, (const hl8_t*)b, (hl8_t*)out, n4);
+  else if (dtype == HIPIE_F16)
     hipLaunchKernelGGL((add_cast_kernel<f16_t>), dim3(grid), dim3(256), 0, st, a, (const f16_t*)b, (f16_t*)out, n4);
   else
     hipLaunchKernelGGL((add_cast_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a, (const bf16_t*)b, (bf16_t*)out, n4);

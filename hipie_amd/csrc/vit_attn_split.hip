@@ -1,0 +1,416 @@
+// vit_attn_split.hip -- ViT attention (global and 14x14-windowed blocks, decomposed relative-position bias computed in the kernel)
+// on SPLIT fp16 operands: the fp32-class form of hipie_vit_attn_rel for the policy that has to match the reference's fp32
+// attention (hipie/backbone/vit.py:67-83 + hipie/backbone/utils.py:96-125) to 1e-3 through 32 blocks.
+//
+//     out[i,:] = softmax_j( q'_i.k_j + q'_i.Rh'[yi - yj + kh - 1] + q'_i.Rw'[xi - xj + kw - 1] ) . v_j        (exp2 domain)
+//
+// Operands (HIPIE_HL8: groups of 8 values as 8 fp16 hi + 8 fp16 lo, include/hipie_mi355.h): the packed qkv rows (B, N, 3, heads,
+// hd) with q' = scale * log2(e) * q, and the two tables R' = R / scale.  Every product that feeds a LOGIT is formed from both
+// halves of both operands,  a.b = a_lo.b_hi + a_hi.b_lo + a_hi.b_hi  (fp32 accumulation; fp16 x fp16 products are exact in
+// fp32), so the scores and both bias terms are fp32-class: a score error enters the probabilities multiplied by exp().  The
+// probabilities themselves are rounded to one fp16 (relative 2^-11 on values whose rounding errors average out over the keys),
+// V keeps both halves:  O += V_hi^T.P + V_lo^T.P.  Classic running maximum, fp32 row sums of the UNROUNDED probabilities.
+// tools/prec_sim.py: with single-fp16 q / k the a22 outputs of the full-depth fixture move by 1.4e-3, with single-fp16 V by 6e-4.
+//
+// Structure = vit_attn_kernel (vit_attn.hip): swapped products S^T = K.Q'^T (C operand = bias_w, -inf on padded key slots) and
+// O^T = V^T.P^T with P used in place as the B operand and V^T fetched by ds_read_b64_tr_b16; one key tile = R key rows of the token
+// grid.  Differences: the K / V tiles go L2 -> LDS by LDS-DMA with the hi / lo halves DE-INTERLEAVED into separate planes (the DMA
+// writes LDS lane-linearly but reads a per-lane source address), so every LDS read pattern is the conflict-free one of the
+// single-fp16 kernel; two tile buffers, one barrier per tile; the output is written as HL8 = the A operand of the projection GEMM.
+#include "common.h"
+#include "mfma.h"
+
+namespace hipie {
+
+struct VSParams {
+  const f16_t* qkv; f16_t* out; const f16_t* tab_h; const f16_t* tab_w;
+  int B, H, N, kh, kw;
+  long sb, st;                  // qkv strides in fp16 elements: batch, token (= 2 * 3C); q at +0, k at +2C, v at +4C (C = H * HD)
+  long o_sb, o_st;              // out strides in fp16 elements (token rows of 2C)
+  int nqt, swz;
+};
+
+__device__ __forceinline__ float vs_max3(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+__device__ __forceinline__ float vs_xhalf_max(float x) {
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  const unsigned int u = __builtin_bit_cast(unsigned int, x);
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__builtin_bit_cast(float, (unsigned int)r[0]), __builtin_bit_cast(float, (unsigned int)r[1]));
+}
+
+// LDS-DMA of 16 bytes per lane: LDS[lds_dst + 16 * lane] <- *(sbase + voff)  (see gemm.hip / vit_attn.hip for the inline-asm form)
+__device__ __forceinline__ void vs_dma16(const char* sbase, unsigned int voff, unsigned int lds_dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned int keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+#endif
+}
+
+// HD: head dim (80 | 64);  NB: 32-slot key blocks per tile;  R: key rows of the token grid per tile;  KW: compile-time grid width when R > 1
+template <int HD, int NB, int WAVES, int R, int KW>
+__global__ __launch_bounds__(WAVES * 64, 2) void vit_attn_split_kernel(const VSParams p) {
+  typedef f16_t T;
+  constexpr int KT = 32 * NB;                  // key slots per tile
+  constexpr int KS = HD / 16;                  // k16 steps of QK^T
+  constexpr int DB = (HD + 31) / 32;           // 32-row d blocks of O^T
+  constexpr int KSTR = HD + 8;                 // K plane row stride (elements): an odd number of 16-byte chunks -> conflict-free b128 reads
+  constexpr int VSTR = (DB * 32 == 96 || DB * 32 == 32) ? DB * 32 : DB * 32 + 32;     // V plane row stride (vit_attn.hip)
+  constexpr int CPR = HD / 8;                  // data chunks per plane row
+  constexpr int KCH = KSTR / 8, VCH = VSTR / 8;
+  constexpr int KBLK = (KT * KCH + 63) / 64, VBLK = (KT * VCH + 63) / 64;      // 1 KiB DMA blocks per plane
+  constexpr int KPL = KBLK * 512, VPL = VBLK * 512;                            // elements per plane
+  constexpr int BUF = 2 * KPL + 2 * VPL;                                       // elements per tile buffer: K_hi | K_lo | V_hi | V_lo
+  constexpr int NBLK = 2 * KBLK + 2 * VBLK;
+  constexpr int NDMA = (NBLK + WAVES - 1) / WAVES;
+  constexpr int QW = WAVES * 32;
+  constexpr int NT = WAVES * 64;
+  static_assert(R == 1 || (KW > 0 && R * KW <= KT), "R key rows of KW keys must fit the tile");
+  static_assert(KSTR % 8 == 0 && VSTR % 8 == 0, "plane rows are whole 16-byte chunks");
+  typedef Mfma32<T>::frag frag;
+  typedef Mfma32<T>::half_frag hfrag;
+
+  extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  constexpr size_t TILE_BYTES = ((size_t)2 * BUF * sizeof(T) > (size_t)WAVES * 4096) ? (size_t)2 * BUF * sizeof(T) : (size_t)WAVES * 4096;
+  float* bh_all = reinterpret_cast<float*>(smem_raw + TILE_BYTES);            // [kh][QW], log2 domain
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, hi = lane >> 5;
+  const int kw = (R > 1) ? KW : p.kw, kh = p.kh;
+
+  int bh, qt;
+  {
+    const int id = blockIdx.x;
+    if (p.swz) { bh = (id & 7) + 8 * ((id >> 3) / p.nqt); qt = (id >> 3) % p.nqt; }
+    else { bh = id / p.nqt; qt = id % p.nqt; }
+  }
+  const int b = bh / p.H, h = bh % p.H;
+  const long C2 = 2L * p.H * HD;                               // fp16 elements of one of q / k / v per token
+  const T* Qg = p.qkv + b * p.sb + (long)h * (2 * HD);
+  const T* Kg = Qg + C2;
+  T* Og = p.out + b * p.o_sb + (long)h * (2 * HD);
+
+  const int qi = qt * QW + wave * 32 + li;
+  const int qc = min(qi, p.N - 1);
+  const int qy = qc / kw, qx = qc - qy * kw;
+  const int nkt = R * kw;
+
+  // ---- Q fragments (B operand), both halves: lane (q = li, half hi) holds group 2 ks + hi of its query row ----
+  frag qh[KS], ql[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const T* s = Qg + (long)qc * p.st + 16 * (2 * ks + hi);
+    qh[ks] = *reinterpret_cast<const frag*>(s);
+    ql[ks] = *reinterpret_cast<const frag*>(s + 8);
+  }
+
+  // ---- decomposed rel-pos bias from the split tables (three products each), exactly as vit_attn_kernel lays it out ----
+  f32x16 bw[NB];
+#pragma unroll
+  for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bw[blk][r] = -INFINITY;
+  {
+    float* stage = reinterpret_cast<float*>(smem_raw) + wave * (32 * 32);      // aliases the (still unused) tile buffers
+    const int nbw = (2 * kw - 1 + 31) / 32, nbh = (2 * kh - 1 + 31) / 32;
+    auto table_block = [&](const T* tab, const int rows, const int jb) -> f32x16 {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const T* ap = tab + (long)min(32 * jb + li, rows - 1) * (2 * HD) + 16 * hi;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const frag th = *reinterpret_cast<const frag*>(ap + 32 * ks), tl = *reinterpret_cast<const frag*>(ap + 32 * ks + 8);
+        acc = Mfma32<T>::mma(tl, qh[ks], acc);
+        acc = Mfma32<T>::mma(th, ql[ks], acc);
+        acc = Mfma32<T>::mma(th, qh[ks], acc);
+      }
+      return acc;
+    };
+    for (int jb = 0; jb < nbw; ++jb) {
+      const f32x16 acc = table_block(p.tab_w, 2 * kw - 1, jb);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) stage[crow(r, hi) * 32 + li] = acc[r];
+      __syncthreads();
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int slot = 32 * blk + crow(r, hi);
+          const int kx = (R > 1) ? slot % kw : slot;
+          const int j = qx + kw - 1 - kx - 32 * jb;
+          if (slot < R * kw && j >= 0 && j < 32) bw[blk][r] = stage[j * 32 + li];
+        }
+      __syncthreads();
+    }
+    for (int jb = 0; jb < nbh; ++jb) {
+      const f32x16 acc = table_block(p.tab_h, 2 * kh - 1, jb);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ky = qy + kh - 1 - (32 * jb + crow(r, hi));
+        if (ky >= 0 && ky < kh) bh_all[ky * QW + wave * 32 + li] = acc[r];
+      }
+    }
+    __syncthreads();             // every wave is done with its stage before the tile buffers are filled
+  }
+
+  // ---- tile streaming by LDS-DMA.  Block j of a tile image: plane = K_hi, K_lo, V_hi, V_lo; chunk c = 64 * (block in plane) + lane ->
+  //      plane row c / (K|V)CH, column c % (K|V)CH; columns >= CPR are padding (never read for K; they feed the discarded d rows of
+  //      O^T for V) and fetch the row's chunk 0.  Source = hl8 chunk 2 * column + (lo plane) of the key's k / v row. ----
+  const int nt = (kh + R - 1) / R;
+  const bool ragged = (R > 1) && (nt * nkt > p.N);           // odd number of key rows: the last tile has fewer
+  auto dma_voff = [&](const int r, const int maxrow) -> unsigned int {
+    const int j = wave + WAVES * r;
+    const int jj = min(j, NBLK - 1);
+    const bool isk = jj < 2 * KBLK;
+    const int pl = isk ? jj / KBLK : (jj - 2 * KBLK) / VBLK;                  // 0 hi, 1 lo
+    const int c = 64 * (isk ? jj - pl * KBLK : jj - 2 * KBLK - pl * VBLK) + lane;
+    const int nch = isk ? KCH : VCH;
+    const int row = min(min(c / nch, KT - 1), maxrow);
+    int col = c % nch;
+    if (col >= CPR) col = 0;
+    return (unsigned int)(((long)row * p.st + (isk ? 0 : C2) + 16 * col + 8 * pl) * (long)sizeof(T));
+  };
+  unsigned int dvoff[NDMA];
+#pragma unroll
+  for (int r = 0; r < NDMA; ++r) dvoff[r] = dma_voff(r, nkt - 1);
+  const unsigned int lds0 = (unsigned int)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem_raw);
+  const char* kbase0 = reinterpret_cast<const char*>(Kg);
+  const long tile_bytes = (long)nkt * p.st * (long)sizeof(T);
+  auto dma_tile = [&](const int t, const int buf, const int r) {
+    const int j = wave + WAVES * r;
+    if (j >= NBLK) return;
+    const bool last_ragged = ragged && (t == nt - 1);
+    const unsigned int vo = last_ragged ? dma_voff(r, p.N - t * nkt - 1) : dvoff[r];
+    vs_dma16(kbase0 + (long)t * tile_bytes, vo, __builtin_amdgcn_readfirstlane(lds0 + (unsigned int)(buf * BUF * (int)sizeof(T) + 1024 * j)));
+  };
+
+  f32x16 O[DB];
+  float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[d][r] = 0.f;
+
+#pragma unroll
+  for (int r = 0; r < NDMA; ++r) dma_tile(0, 0, r);
+  __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
+  __syncthreads();
+
+  const int l16 = lane & 15, g1 = (lane >> 4) & 1;
+  const int vlane = (4 * hi + (l16 >> 2)) * VSTR + 16 * g1 + 4 * (l16 & 3);   // this lane's V^T read offset inside a (step, d) block
+  const int klane = li * KSTR + 8 * hi;
+
+  for (int t = 0; t < nt; ++t) {
+    const T* Kh = smem + (t & 1) * BUF;
+    const T* Kl = Kh + KPL;
+    const T* Vh = Kh + 2 * KPL;
+    const T* Vl = Vh + VPL;
+    const bool more = t + 1 < nt;
+    float bh0 = bh_all[(R * t) * QW + wave * 32 + li], bh1 = 0.f;
+    if (R > 1) bh1 = (R * t + 1 < kh) ? bh_all[(R * t + 1) * QW + wave * 32 + li] : -INFINITY;
+
+    // ---- S^T = K . Q'^T + bias_w (three products per k-step); the fragments of k-step ks + 1 are requested before the MFMAs of ks;
+    //      the DMA instructions of tile t + 1 are spread over the k-steps ----
+    f32x16 S[NB];
+    {
+      frag kfh[2][NB], kfl[2][NB];
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk) {
+        kfh[0][blk] = *reinterpret_cast<const frag*>(Kh + klane + 32 * blk * KSTR);
+        kfl[0][blk] = *reinterpret_cast<const frag*>(Kl + klane + 32 * blk * KSTR);
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) {
+#pragma unroll
+          for (int blk = 0; blk < NB; ++blk) {
+            kfh[(ks + 1) & 1][blk] = *reinterpret_cast<const frag*>(Kh + klane + 32 * blk * KSTR + 16 * (ks + 1));
+            kfl[(ks + 1) & 1][blk] = *reinterpret_cast<const frag*>(Kl + klane + 32 * blk * KSTR + 16 * (ks + 1));
+          }
+        }
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+          S[blk] = Mfma32<T>::mma(kfl[ks & 1][blk], qh[ks], (ks == 0) ? bw[blk] : S[blk]);
+          S[blk] = Mfma32<T>::mma(kfh[ks & 1][blk], ql[ks], S[blk]);
+          S[blk] = Mfma32<T>::mma(kfh[ks & 1][blk], qh[ks], S[blk]);
+        }
+        if (more && ks < NDMA) dma_tile(t + 1, (t + 1) & 1, ks);
+      }
+      if (more) {
+#pragma unroll
+        for (int r = KS; r < NDMA; ++r) dma_tile(t + 1, (t + 1) & 1, r);
+      }
+    }
+    // V^T fragments of the first PV product (step 0, hi plane): in flight while the softmax statistics are computed
+    hfrag va[2][DB], vb[2][DB];                 // [parity][d]: rows 0-3 / 8-11 of the 16-key step for this lane half
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+      va[0][d] = Mfma32<T>::tr_read(Vh + vlane + 32 * d);
+      vb[0][d] = Mfma32<T>::tr_read(Vh + vlane + 32 * d + 8 * VSTR);
+    }
+
+    // ---- row maximum; R > 1: add the key row's bias_h first ----
+    if (R > 1) {
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[blk][r] += (32 * blk + crow(r, hi) < kw) ? bh0 : bh1;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) mx = vs_max3(mx, S[blk][r], S[blk][r + 1]);
+    mx = vs_xhalf_max(mx);
+    mx += (R > 1 ? 0.f : bh0);
+    if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0ull) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // m_run = -inf -> 0 (every tile has a valid key)
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[d][r] *= alpha;
+    }
+    const float off = (R > 1 ? 0.f : bh0) - m_run;
+
+    // ---- P = exp2(S + off) (one fp16);  O^T += V_hi^T . P^T + V_lo^T . P^T.  Product u = (step, plane): the V^T reads of product
+    //      u + 1 and (before a new step) the exps / packs of the next P fragment are issued ahead of the MFMAs of product u ----
+    frag pf;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float pv = __builtin_amdgcn_exp2f(S[0][j] + off);
+      l_run += pv;
+      pf[j] = (T)pv;
+    }
+#pragma unroll
+    for (int u = 0; u < 4 * NB; ++u) {
+      const int step = u >> 1, pl = u & 1;
+      frag vf[DB];
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { vf[d][j] = va[u & 1][d][j]; vf[d][4 + j] = vb[u & 1][d][j]; }
+      frag pn = pf;
+      if (u + 1 < 4 * NB) {
+        const int nstep = (u + 1) >> 1, npl = (u + 1) & 1;
+        const T* vbp = (npl ? Vl : Vh) + (16 * nstep) * VSTR + vlane;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          va[(u + 1) & 1][d] = Mfma32<T>::tr_read(vbp + 32 * d);
+          vb[(u + 1) & 1][d] = Mfma32<T>::tr_read(vbp + 32 * d + 8 * VSTR);
+        }
+        if (npl == 0) {           // a new step follows: its probabilities
+          const int nb_ = nstep >> 1, ns_ = nstep & 1;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float pv = __builtin_amdgcn_exp2f(S[nb_][8 * ns_ + j] + off);
+            l_run += pv;
+            pn[j] = (T)pv;
+          }
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < DB; ++d) O[d] = Mfma32<T>::mma(vf[d], pf, O[d]);
+      pf = pn;
+      (void)step; (void)pl;
+    }
+
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's DMA writes of tile t + 1 have landed
+    __syncthreads();                          // ... and everybody's; all reads of tile t are done
+  }
+
+  // ---- epilogue: O^T / l as HL8: a lane owns 4 consecutive d = one half of a group of 8 ----
+  {
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.f / l_tot;
+    if (qi < p.N) {
+      T* orow = Og + (long)qi * p.o_st;
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int d0 = 32 * d + 8 * rr + 4 * hi;
+          if (d0 < HD) {
+            f16x4 oh, ol;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              T hh, ll;
+              hl_split(O[d][4 * rr + e] * inv, hh, ll);
+              oh[e] = hh;
+              ol[e] = ll;
+            }
+            T* dst = orow + 16 * (d0 >> 3) + 4 * hi;
+            *reinterpret_cast<f16x4*>(dst) = oh;
+            *reinterpret_cast<f16x4*>(dst + 8) = ol;
+          }
+        }
+    }
+  }
+}
+
+template <int HD, int NB, int WAVES, int R, int KW>
+static int launch_vs(VSParams& p, hipStream_t st) {
+  constexpr int KT = 32 * NB, DB = (HD + 31) / 32;
+  constexpr int KSTR = HD + 8, VSTR = (DB * 32 == 96 || DB * 32 == 32) ? DB * 32 : DB * 32 + 32;
+  constexpr int KBLK = (KT * (KSTR / 8) + 63) / 64, VBLK = (KT * (VSTR / 8) + 63) / 64;
+  size_t lds = (size_t)2 * (2 * KBLK + 2 * VBLK) * 1024;
+  const size_t stage = (size_t)WAVES * 32 * 32 * sizeof(float);
+  if (lds < stage) lds = stage;
+  lds += (size_t)p.kh * WAVES * 32 * sizeof(float);
+  if (lds > 160 * 1024) return set_err(HIPIE_EINVAL, "vit_attn(split): %zu bytes of LDS needed (grid %dx%d) > 160 KiB", lds, p.kh, p.kw);
+  p.nqt = (p.N + WAVES * 32 - 1) / (WAVES * 32);
+  p.swz = ((p.B * p.H) % 8 == 0) ? 1 : 0;
+  const unsigned grid = (unsigned)(p.nqt * p.B * p.H);
+  auto kern = vit_attn_split_kernel<HD, NB, WAVES, R, KW>;
+  if (lds > 64 * 1024) {
+    static size_t lds_set[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || lds > lds_set[dev]) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (dev >= 0 && dev < 64) lds_set[dev] = lds;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds, st, p);
+  return check_launch("vit_attn(split)");
+}
+
+template <int HD>
+static int dispatch_vs(VSParams& p, hipStream_t st) {
+  if (p.kw == 14 && p.kh <= 96) return launch_vs<HD, 1, 7, 2, 14>(p, st);     // the 14x14 windows: 196 queries = 7 waves
+  if (p.kw <= 32) return launch_vs<HD, 1, 4, 1, 0>(p, st);
+  if (p.kw <= 64 && p.kh <= 64) return launch_vs<HD, 2, 8, 1, 0>(p, st);
+  if (p.kw <= 64) return launch_vs<HD, 2, 4, 1, 0>(p, st);
+  return set_err(HIPIE_EINVAL, "vit_attn(split): token grids wider than 64 are not supported (got %dx%d)", p.kh, p.kw);
+}
+
+}  // namespace hipie
+
+extern "C" int hipie_vit_attn_split(const void* qkv, const void* tab_h, const void* tab_w, void* out, int B, int gh, int gw,
+                                    int heads, int hd, void* stream) {
+  using namespace hipie;
+  HIPIE_REQUIRE(qkv && out && tab_h && tab_w, "vit_attn_split: null pointer");
+  HIPIE_REQUIRE((((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)tab_h | (uintptr_t)tab_w) & 15) == 0, "vit_attn_split: pointers must be 16-byte aligned");
+  HIPIE_REQUIRE(B > 0 && gh > 0 && gw > 0 && heads > 0, "vit_attn_split: bad shape B=%d grid %dx%d heads=%d", B, gh, gw, heads);
+  HIPIE_REQUIRE(gh <= 160, "vit_attn_split: more than 160 key rows (%d) are not supported", gh);
+  const long N = (long)gh * gw, C = (long)heads * hd;
+  HIPIE_REQUIRE(N * 6 * C * 2 < (1L << 31), "vit_attn_split: an image's qkv block must stay below 2 GiB");
+  VSParams p{};
+  p.qkv = (const f16_t*)qkv; p.out = (f16_t*)out; p.tab_h = (const f16_t*)tab_h; p.tab_w = (const f16_t*)tab_w;
+  p.B = B; p.H = heads; p.N = (int)N; p.kh = gh; p.kw = gw;
+  p.sb = N * 6 * C; p.st = 6 * C; p.o_sb = N * 2 * C; p.o_st = 2 * C;
+  hipStream_t st = (hipStream_t)stream;
+  if (hd == 80) return dispatch_vs<80>(p, st);
+  if (hd == 64) return dispatch_vs<64>(p, st);
+  return set_err(HIPIE_EINVAL, "vit_attn_split: head_dim 64 / 80 only (got %d)", hd);
+}

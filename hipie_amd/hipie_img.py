@@ -18,7 +18,7 @@ from .config import HipieConfig, Precision
 from .modeling.ddetrs_dn import DDETRSegmUniDN
 from .modeling.text import BertEncoder
 from .modeling.transformer import (DeformableDETRDINO, DeformableTransformerVLDINO, Joiner, MaskedBackbone,
-                                   PositionEmbeddingSine, cast_head)
+                                   PositionEmbeddingSine, cast_head, set_split)
 from .modeling.vit import D2ViT
 
 
@@ -117,6 +117,10 @@ class HIPIE_IMG(nn.Module):
         cast_head(self.detr.mask_dino.predictor.decoder.ref_point_head, hd)
         cast_head(self.detr.mask_head, hd, ad)
         self.text_encoder[0].model.set_compute_dtype(self.precision.text)
+        # Precision.split3: every linear of the path on the split-fp16 GEMM (the weights stay fp32 parameters; their HL8 copies are
+        # built lazily and cached per parameter version).  The flag is also cleared here, so one process can hold several policies.
+        set_split(self, self.precision.split)
+        self.text_encoder[0].model.split = self.precision.split
         return self
 
     # ---- hipie_img.py:880-898 -------------------------------------------------------------------------------

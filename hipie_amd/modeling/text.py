@@ -145,7 +145,42 @@ class BertModel(nn.Module):
                                               oo.LayerNorm.bias, oo.LayerNorm.eps, dt, want16=True)
         return x
 
+    def _forward_split(self, input_ids, attention_mask):
+        """Precision.split3: every dense layer as the split-fp16 GEMM (fused QKV, fp32-class), the attention core on fp16 operands
+        (hipie_flash_attn; tools/prec_sim.py: BERT's attention products may be single fp16, its linears may not), the post-norm
+        stream fp32; the LayerNorm passes emit the next GEMM operand as HL8, the intermediate GEMM applies the exact-erf GELU and
+        writes HL8 for the output GEMM.  8 launches per layer."""
+        emb = self.embeddings
+        L = input_ids.shape[1]
+        x = emb.word_embeddings(input_ids) + emb.position_embeddings.weight[:L][None] + emb.token_type_embeddings.weight[0][None, None]
+        ln = emb.LayerNorm
+        x, xh = ops.add_layernorm(x.float().contiguous(), None, ln.weight, ln.bias, ln.eps, torch.float32)[1], None
+        B, L, C = x.shape
+        heads = self.encoder.layer[0].attention.self.heads
+        hd = C // heads
+        kmask = attention_mask.to(torch.uint8).contiguous()
+        xh = ops.to_hl8(x)
+        for layer in self.encoder.layer:
+            at = layer.attention.self
+            qkv = ops.split_linear(xh, at, "qkv", at.query.weight, None, out_fmt=ops.F16, x_hl8=True,
+                                   weight_fn=lambda at=at: torch.cat([at.query.weight, at.key.weight, at.value.weight]),
+                                   bias_fn=lambda at=at: torch.cat([at.query.bias, at.key.bias, at.value.bias]),
+                                   params=(at.query.weight, at.key.weight, at.value.weight, at.query.bias, at.key.bias, at.value.bias)
+                                   ).view(B, L, 3, heads, hd)
+            ctx = ops.flash_attn(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 1.0 / math.sqrt(hd), key_mask=kmask, out_f32=True)
+            so = layer.attention.output
+            d = ops.split_linear(ctx, so, "dense", so.dense.weight, so.dense.bias)
+            x, xh, _ = ops.add_layernorm_dec(x, d, so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.eps, "hl8", want16=True)
+            oo = layer.output
+            mid = ops.split_linear(xh, layer.intermediate, "dense", layer.intermediate.dense.weight, layer.intermediate.dense.bias,
+                                   act=ops.ACT_GELU, out_fmt=ops.HL8, x_hl8=True)
+            d = ops.split_linear(mid, oo, "dense", oo.dense.weight, oo.dense.bias, x_hl8=True)
+            x, xh, _ = ops.add_layernorm_dec(x, d, oo.LayerNorm.weight, oo.LayerNorm.bias, oo.LayerNorm.eps, "hl8", want16=True)
+        return x
+
     def forward(self, input_ids, attention_mask):
+        if getattr(self, "split", False) and input_ids.is_cuda and self.compute_dtype == torch.float32:
+            return self._forward_split(input_ids, attention_mask)
         if self.compute_dtype != torch.float32:
             return self._forward16(input_ids, attention_mask)
         x = self.embeddings(input_ids)

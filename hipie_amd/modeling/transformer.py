@@ -23,17 +23,38 @@ from .. import ops
 
 
 # --------------------------------------------------------------------------- policy-aware primitives
+def _lin(owner, key, x, w, b, act=ops.ACT_NONE, out_fmt=ops.F32, x_hl8=False):
+    """F.linear(x, w, b) in the weight's dtype -- or, when ``owner.split`` is set (Precision.split3: set_split below), the same product
+    at fp32-class accuracy on hipie_gemm's split-fp16 operands (the HL8 copy of ``w`` is cached on ``owner`` under ``key``)."""
+    if getattr(owner, "split", False) and x.is_cuda and w.dtype == torch.float32 and ops.split_ok(w.shape[1] if not x_hl8 else w.shape[1]):
+        return ops.split_linear(x, owner, key, w, b, act=act, out_fmt=out_fmt, x_hl8=x_hl8)
+    y = F.linear(x.to(w.dtype), w, b)
+    return F.relu(y) if act == ops.ACT_RELU else y
+
+
+def set_split(module, on=True):
+    """Precision.split3: every linear of ``module`` runs as the split-fp16 GEMM (weights stay fp32 parameters)."""
+    for m in module.modules():
+        m.split = bool(on)
+    return module
+
+
 class PLinear(nn.Linear):
     """nn.Linear whose GEMM runs in the weight's dtype; input is cast in, output returned in ``out_dtype`` (fp32 unless
-    the policy stores activations in 16 bit)."""
+    the policy stores activations in 16 bit).  With ``split`` set: hipie_gemm on split-fp16 operands (fp32-class, fp32 out)."""
     out_dtype = torch.float32
+    split = False
 
-    def forward(self, x):
+    def forward(self, x, x_hl8=False, out_fmt=ops.F32):
+        if self.split and x.is_cuda and self.weight.dtype == torch.float32 and ops.split_ok(self.in_features):
+            return ops.split_linear(x, self, "w", self.weight, self.bias, out_fmt=out_fmt, x_hl8=x_hl8)
         return F.linear(x.to(self.weight.dtype), self.weight, self.bias).to(self.out_dtype)
 
-    def forward_relu(self, x):
-        """relu(linear(x)) with the ReLU in the library GEMM's epilogue (exact: ReLU commutes with the output rounding);
+    def forward_relu(self, x, out_fmt=ops.F32):
+        """relu(linear(x)) with the ReLU in the GEMM's epilogue (exact: ReLU commutes with the output rounding);
         removes one read+write of the (tokens, d_ffn) hidden tensor per FFN."""
+        if self.split and x.is_cuda and self.weight.dtype == torch.float32 and ops.split_ok(self.in_features):
+            return ops.split_linear(x, self, "w", self.weight, self.bias, act=ops.ACT_RELU, out_fmt=out_fmt)
         x = x.to(self.weight.dtype)
         if x.is_cuda and self.bias is not None:
             y = torch._addmm_activation(self.bias, x.reshape(-1, x.shape[-1]), self.weight.t(), use_gelu=False)
@@ -277,7 +298,7 @@ class MSDeformAttn(nn.Module):
     def project_value(self, input_flatten, input_padding_mask=None):
         N, S, _ = input_flatten.shape
         vp = self.value_proj                       # GEMM output stays in the weight dtype: no fp32 round trip, mask in place
-        value = F.linear(input_flatten.to(vp.weight.dtype), vp.weight, vp.bias)
+        value = _lin(vp, "w", input_flatten, vp.weight, vp.bias)
         if input_padding_mask is not None:
             value.masked_fill_(input_padding_mask[..., None], 0.0)
         return value.to(self.value_dtype).view(N, S, self.n_heads, self.d_model // self.n_heads)
@@ -292,7 +313,7 @@ class MSDeformAttn(nn.Module):
         # reads both column blocks of that single output in place (row strides), in whatever dtype the GEMM produced
         w, b = self._fused_proj()
         no = self.n_heads * self.n_levels * self.n_points * 2
-        proj = F.linear(query.to(w.dtype), w, b)
+        proj = _lin(self, "offlog", query, w, b)
         off = proj[..., :no].unflatten(-1, (self.n_heads, self.n_levels, self.n_points, 2))
         logits = proj[..., no:].unflatten(-1, (self.n_heads, self.n_levels * self.n_points))
         out = ops.msda_fused(value.contiguous(), input_spatial_shapes, input_level_start_index,
@@ -304,7 +325,7 @@ class MSDeformAttn(nn.Module):
         dense or a column block of the batched projection (sampled in place through its row stride)."""
         w, b = self._fused_proj()
         no = self.n_heads * self.n_levels * self.n_points * 2
-        proj = F.linear(query.to(w.dtype), w, b)
+        proj = _lin(self, "offlog", query, w, b)
         off = proj[..., :no].unflatten(-1, (self.n_heads, self.n_levels, self.n_points, 2))
         logits = proj[..., no:].unflatten(-1, (self.n_heads, self.n_levels * self.n_points))
         out = ops.msda_fused(value, input_spatial_shapes, input_level_start_index, reference_points.float().contiguous(), off, logits)
@@ -337,17 +358,17 @@ class BiMultiHeadAttention(nn.Module):
         L = l.shape[1]
         H, hd, dt = self.num_heads, self.head_dim, self.attn_dtype
         wq, bq = self._scaled_q()                              # v_proj with the 1/sqrt(head_dim) folded in: no (B, Nv, 2048) multiply pass
-        q = F.linear(v.to(wq.dtype), wq, bq).to(dt).view(B, Nv, H, hd)
+        q = _lin(self, "q_scaled", v, wq, bq).to(dt).view(B, Nv, H, hd)
         k = self.l_proj(l).to(dt).view(B, L, H, hd)
         vv = self.values_v_proj(v).to(dt).view(B, Nv, H, hd)
         vl = self.values_l_proj(l).to(dt).view(B, L, H, hd)
         if attention_mask_l is None:
             attention_mask_l = torch.ones(B, L, dtype=torch.uint8, device=v.device)
-        ov, ol = ops.bi_xattn(q, k, vv, vl, attention_mask_l != 0, clamp=50000.0)
+        ov, ol = ops.bi_xattn(q, k, vv, vl, attention_mask_l != 0, clamp=50000.0, out_f32=getattr(self, "split", False))
         if gamma_v is None:
             return self.out_v_proj(ov), self.out_l_proj(ol)
         wo, bo = self._scaled_out(gamma_v)
-        return F.linear(ov.to(wo.dtype), wo, bo).to(self.out_v_proj.out_dtype), self.out_l_proj(ol)
+        return _lin(self, "out_scaled", ov, wo, bo).to(self.out_v_proj.out_dtype), self.out_l_proj(ol)
 
     def _scaled_out(self, gamma):
         p = self.out_v_proj
@@ -479,9 +500,9 @@ class MultiheadAttention(nn.Module):
         B, N, C = x_qk.shape
         w, b = self.in_proj_weight, self.in_proj_bias
         hd = C // self.n_heads
-        qk = F.linear(x_qk.to(w.dtype), w[:2 * C], b[:2 * C]).to(self.attn_dtype).view(B, N, 2, self.n_heads, hd)
-        v = F.linear(x_v.to(w.dtype), w[2 * C:], b[2 * C:]).to(self.attn_dtype).view(B, N, self.n_heads, hd)
-        o = ops.flash_attn(qk[:, :, 0], qk[:, :, 1], v, hd ** -0.5)              # strided q / k views of one GEMM output
+        qk = _lin(self, "in_qk", x_qk, w[:2 * C], b[:2 * C]).to(self.attn_dtype).view(B, N, 2, self.n_heads, hd)
+        v = _lin(self, "in_v", x_v, w[2 * C:], b[2 * C:]).to(self.attn_dtype).view(B, N, self.n_heads, hd)
+        o = ops.flash_attn(qk[:, :, 0], qk[:, :, 1], v, hd ** -0.5, out_f32=getattr(self, "split", False))   # strided q / k views of one GEMM output
         return self.out_proj(o)
 
 

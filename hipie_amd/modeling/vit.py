@@ -105,6 +105,8 @@ class PatchEmbed(nn.Module):
         p = self.patch
         w = self.proj.weight
         x = x.reshape(B, C, H // p, p, W // p, p).permute(0, 2, 4, 1, 3, 5).reshape(B, H // p, W // p, C * p * p)
+        if getattr(self, "split", False) and x.is_cuda and ops.split_ok(x.shape[-1]):
+            return ops.split_linear(x.contiguous(), self, "proj", w, self.proj.bias, weight_fn=lambda: w.reshape(w.shape[0], -1))
         return F.linear(x.to(w.dtype), w.reshape(w.shape[0], -1), self.proj.bias)
 
 
@@ -138,6 +140,33 @@ class Attention(nn.Module):
             rel_h, rel_w = ops.vit_relpos(qkv16, th, tw, (H, W), nh)
             o = ops.vit_attn(qkv16, rel_h, rel_w, (H, W), nh, self.scale)
         return self.proj(o.to(x.dtype)).view(B, H, W, C)
+
+    def forward_split(self, y, B, H, W):
+        """the split policy: y (B*H*W, 2C) HL8 (LayerNorm output) -> (B*H*W, C) fp32 = proj(attention(qkv(y))).  qkv leaves its GEMM
+        as HL8 (q rows pre-scaled, fold cached per parameter version), the attention forms logits and bias from both halves of
+        both operands (hipie_vit_attn_split) and writes HL8, which the projection GEMM consumes."""
+        C = self.qkv.weight.shape[1]
+        nh = self.num_heads
+        c1 = self.scale * ops.LOG2E
+
+        def wq():
+            w = self.qkv.weight.detach().float().clone()
+            w[:C] *= c1
+            return w
+
+        def bq():
+            b = self.qkv.bias.detach().float().clone()
+            b[:C] *= c1
+            return b
+        qkv = ops.split_linear(y, self, "qkv", self.qkv.weight, self.qkv.bias, out_fmt=ops.HL8, x_hl8=True, weight_fn=wq, bias_fn=bq,
+                               tag="gemm_qkv")
+        key = (H, W, self._versions())
+        if getattr(self, "_tabs_key", None) != key:
+            self._tabs = (ops.hl8_pack(resize_rel_pos(H, self.rel_pos_h.detach().float()) / self.scale),
+                          ops.hl8_pack(resize_rel_pos(W, self.rel_pos_w.detach().float()) / self.scale))
+            self._tabs_key = key
+        o = ops.vit_attn_split(qkv.view(B, H * W, 6 * C), self._tabs[0], self._tabs[1], (H, W), nh)
+        return ops.split_linear(o.view(B * H * W, 2 * C), self, "proj", self.proj.weight, self.proj.bias, x_hl8=True, tag="gemm_proj")
 
     def _versions(self):
         ps = (self.qkv.weight, self.qkv.bias, self.rel_pos_h, self.rel_pos_w)
@@ -186,6 +215,11 @@ class Mlp(nn.Module):
     def forward(self, x):
         return self.fc2(self.act(self.fc1(x)))
 
+    def forward_split(self, h):
+        """h (rows, 2C) HL8 -> (rows, C) fp32: fc1 with the exact-erf GELU and the HL8 split in its epilogue, fc2 on that operand."""
+        mid = ops.split_linear(h, self, "fc1", self.fc1.weight, self.fc1.bias, act=ops.ACT_GELU, out_fmt=ops.HL8, x_hl8=True, tag="gemm_fc1")
+        return ops.split_linear(mid, self, "fc2", self.fc2.weight, self.fc2.bias, x_hl8=True, tag="gemm_fc2")
+
 
 class Block(nn.Module):
     """hipie/backbone/vit.py:147-230; LayerNorm eps 1e-6."""
@@ -205,6 +239,8 @@ class Block(nn.Module):
         (hipie_add_layernorm), so the stream is read and written once per half-block."""
         gd = self.precision.gemm
         ws = self.window_size
+        if self.precision.split and x.is_cuda:
+            return self._forward_split(x, delta)
         if ws == 0:
             x, y = ops.add_layernorm(x, delta, self.norm1.weight, self.norm1.bias, self.norm1.eps, gd)
             y = self.attn(y)
@@ -218,6 +254,29 @@ class Block(nn.Module):
         y = self.attn(y.view(nwin, ws, ws, C))
         x, h = ops.add_layernorm(x, y.reshape(-1, C), self.norm2.weight, self.norm2.bias, self.norm2.eps, gd, delta_row=delta_row)
         return x, self.mlp(h)
+
+
+def _block_forward_split(self, x, delta):
+    """Block.forward of the split policy: the fused add + LayerNorm passes emit the GEMM operand as HL8, every linear is the
+    three-product GEMM, the window partition / un-partition are the row maps of the LayerNorm passes as in the 16-bit path."""
+    B, H, W, C = x.shape
+    ws = self.window_size
+    n1, n2 = self.norm1, self.norm2
+    if ws == 0:
+        x, y = ops.add_layernorm(x, delta, n1.weight, n1.bias, n1.eps, "hl8")
+        a = self.attn.forward_split(y.view(B * H * W, 2 * C), B, H, W)
+        x, h = ops.add_layernorm(x, a.view(B, H, W, C), n2.weight, n2.bias, n2.eps, "hl8")
+        return x, self.mlp.forward_split(h.view(B * H * W, 2 * C)).view(B, H, W, C)
+    if not ops.vit_attn_split_ok((ws, ws), C // self.attn.num_heads):
+        raise NotImplementedError("split policy: window size %d" % ws)
+    out_src, delta_row, nwin = window_row_maps(B, H, W, ws, x.device)
+    x, y = ops.add_layernorm(x, delta, n1.weight, n1.bias, n1.eps, "hl8", out_src=out_src)
+    a = self.attn.forward_split(y, nwin, ws, ws)
+    x, h = ops.add_layernorm(x, a, n2.weight, n2.bias, n2.eps, "hl8", delta_row=delta_row)
+    return x, self.mlp.forward_split(h.view(B * H * W, 2 * C)).view(B, H, W, C)
+
+
+Block._forward_split = _block_forward_split
 
 
 class ViT(nn.Module):
@@ -246,6 +305,7 @@ class ViT(nn.Module):
     def forward(self, x):
         """x (B,3,H,W) fp32 normalised image -> {"res3","res4","res5"}: logical NCHW, channels-last memory, activation dtype."""
         gd, ad, rd = self.precision.gemm, self.precision.act, self.precision.resid
+        self.patch_embed.split = self.precision.split
         x = self.patch_embed(x).float()
         x = (x + self._abs_pos((x.shape[1], x.shape[2]))).to(rd)
         x, delta = x.contiguous(), None
@@ -258,7 +318,11 @@ class ViT(nn.Module):
         B, H, W, E = x.shape
         wt = self.fpn1[0].weight                                           # (E, E/2, 2, 2)
         b4 = self.fpn1[0].bias.to(wt.dtype).repeat_interleave(4)
-        y = F.linear(x.to(wt.dtype), wt.reshape(E, -1).t(), b4).view(B, H, W, E // 2, 2, 2)
+        if self.precision.split and x.is_cuda and ops.split_ok(E):
+            y = ops.split_linear(x.float().contiguous(), self, "fpn1", wt, self.fpn1[0].bias, weight_fn=lambda: wt.reshape(E, -1).t(),
+                                 bias_fn=lambda: b4).view(B, H, W, E // 2, 2, 2)
+        else:
+            y = F.linear(x.to(wt.dtype), wt.reshape(E, -1).t(), b4).view(B, H, W, E // 2, 2, 2)
         res3 = y.permute(0, 1, 4, 2, 5, 3).reshape(B, 2 * H, 2 * W, E // 2).to(ad).permute(0, 3, 1, 2)
         xp = x.permute(0, 3, 1, 2)
         return {"res3": res3, "res4": xp, "res5": self.fpn3(xp)}

@@ -10,6 +10,7 @@ from . import _lib
 
 _DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 F32, F16, BF16, HL8 = 0, 1, 2, 4          # include/hipie_mi355.h: HIPIE_F32 / F16 / BF16 / HL8
+OUT_F32 = 0x100                           # HIPIE_OUT_F32
 
 
 class _Profile(object):
@@ -79,6 +80,18 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _code(dtype):
+    """C-ABI element code of an output type: a torch dtype, or the string "hl8" (split fp16, HIPIE_HL8)."""
+    return HL8 if dtype == "hl8" else _DT[dtype]
+
+
+def _alloc(shape, dtype, device):
+    """output buffer of logical ``shape`` in ``dtype``; "hl8": fp16 with the last dimension doubled."""
+    if dtype == "hl8":
+        return torch.empty(*shape[:-1], 2 * shape[-1], dtype=torch.float16, device=device)
+    return torch.empty(shape, dtype=dtype, device=device)
+
+
 def _chk(t, name, dtype=None):
     if not t.is_cuda:
         raise RuntimeError("Not implemented on the CPU (%s must be a CUDA/HIP tensor)" % name)
@@ -145,9 +158,9 @@ def msda_fused(value, spatial_shapes, level_start_index, ref, offsets, logits):
 
 
 @_timed("flash_attn")
-def flash_attn(q, k, v, scale, bias_h=None, bias_w=None, key_mask=None, clamp=0.0):
-    """q (B,Nq,H,hd), k,v (B,Nk,H,hd) 16-bit (may be strided views with hd contiguous) -> (B,Nq,H*hd).
-    bias_h (B*H,kh,Nq) / bias_w (B*H,Nq,kw) f32 decomposed rel-pos bias; key_mask (B,Nk) uint8/bool."""
+def flash_attn(q, k, v, scale, bias_h=None, bias_w=None, key_mask=None, clamp=0.0, out_f32=False):
+    """q (B,Nq,H,hd), k,v (B,Nk,H,hd) 16-bit (may be strided views with hd contiguous) -> (B,Nq,H*hd) in the operand dtype, or
+    fp32 with out_f32.  bias_h (B*H,kh,Nq) / bias_w (B*H,Nq,kw) f32 decomposed rel-pos bias; key_mask (B,Nk) uint8/bool."""
     lib = _lib.load()
     B, Nq, H, hd = q.shape
     Nk = k.shape[1]
@@ -156,7 +169,7 @@ def flash_attn(q, k, v, scale, bias_h=None, bias_w=None, key_mask=None, clamp=0.
             raise RuntimeError("Not implemented on the CPU (%s)" % n)
         if t.stride(-1) != 1 or t.dtype != q.dtype or t.dtype not in (torch.float16, torch.bfloat16):
             raise RuntimeError("flash_attn: %s must be fp16/bf16 with contiguous head_dim" % n)
-    out = torch.empty(B, Nq, H * hd, dtype=q.dtype, device=q.device)
+    out = torch.empty(B, Nq, H * hd, dtype=torch.float32 if out_f32 else q.dtype, device=q.device)
     kh = kw = 0
     bhp = bwp = mp = None
     if bias_h is not None:
@@ -168,7 +181,7 @@ def flash_attn(q, k, v, scale, bias_h=None, bias_w=None, key_mask=None, clamp=0.
     rc = lib.hipie_flash_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, Nq, Nk, hd,
                               q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
                               v.stride(0), v.stride(1), v.stride(2), Nq * H * hd, H * hd, hd,
-                              bhp, bwp, kh, kw, mp, float(scale), float(clamp), _DT[q.dtype], _stream())
+                              bhp, bwp, kh, kw, mp, float(scale), float(clamp), _DT[q.dtype] | (OUT_F32 if out_f32 else 0), _stream())
     _lib.check(rc, "hipie_flash_attn")
     return out
 
@@ -238,15 +251,17 @@ _XA_WS = {}
 
 
 @_timed("bi_xattn")
-def bi_xattn(q, k, vv, vl, text_mask, clamp=50000.0):
-    """q, vv (B,Nv,H,hd); k, vl (B,L,H,hd) 16-bit contiguous; text_mask (B,L) -> out_v (B,Nv,H*hd), out_l (B,L,H*hd)."""
+def bi_xattn(q, k, vv, vl, text_mask, clamp=50000.0, out_f32=False):
+    """q, vv (B,Nv,H,hd); k, vl (B,L,H,hd) 16-bit contiguous; text_mask (B,L) -> out_v (B,Nv,H*hd), out_l (B,L,H*hd) (operand dtype,
+    or fp32 with out_f32: the generic flash kernel then runs both directions)."""
     lib = _lib.load()
     B, Nv, H, hd = q.shape
     L = k.shape[1]
     text_mask = text_mask.to(torch.uint8).contiguous()
-    out_v = torch.empty(B, Nv, H * hd, dtype=q.dtype, device=q.device)
-    out_l = torch.empty(B, L, H * hd, dtype=q.dtype, device=q.device)
-    need = int(lib.hipie_bi_xattn_workspace(B, H, Nv, L, hd))          # split partials of the text -> image direction (0: none)
+    odt = torch.float32 if out_f32 else q.dtype
+    out_v = torch.empty(B, Nv, H * hd, dtype=odt, device=q.device)
+    out_l = torch.empty(B, L, H * hd, dtype=odt, device=q.device)
+    need = 0 if out_f32 else int(lib.hipie_bi_xattn_workspace(B, H, Nv, L, hd))          # split partials of the text -> image direction (0: none)
     ws = None
     if need > 0:
         key = str(q.device)
@@ -255,7 +270,7 @@ def bi_xattn(q, k, vv, vl, text_mask, clamp=50000.0):
             ws = _XA_WS[key] = torch.empty((need + 3) // 4, dtype=torch.float32, device=q.device)
     rc = lib.hipie_bi_xattn_ws(_chk(q, "q"), _chk(k, "k"), _chk(vv, "vv"), _chk(vl, "vl"), _chk(text_mask, "text_mask"),
                                out_v.data_ptr(), out_l.data_ptr(), None if ws is None else ws.data_ptr(), need, B, H, Nv, L, hd,
-                               float(clamp), _DT[q.dtype], _stream())
+                               float(clamp), _DT[q.dtype] | (OUT_F32 if out_f32 else 0), _stream())
     _lib.check(rc, "hipie_bi_xattn")
     return out_v, out_l
 
@@ -345,15 +360,15 @@ def add_layernorm(x, delta, weight, bias, eps, norm_dtype, want_res=True, delta_
     rows = x.numel() // C
     res = torch.empty_like(x) if (want_res and delta is not None) else None
     if out_src is None:
-        out = torch.empty(x.shape, dtype=norm_dtype, device=x.device)
+        out = _alloc(tuple(x.shape), norm_dtype, x.device)
         out_rows = rows
     else:
         out_rows = int(out_src.shape[0])
-        out = torch.empty(out_rows, C, dtype=norm_dtype, device=x.device)
+        out = _alloc((out_rows, C), norm_dtype, x.device)
     args = (_chk(x, "x"), None if delta is None else _chk(delta, "delta"),
             _chk(weight, "weight", torch.float32), _chk(bias, "bias", torch.float32),
             None if res is None else res.data_ptr(), out.data_ptr(), out_rows, C, float(eps),
-            _DT[x.dtype], _DT[x.dtype if delta is None else delta.dtype], _DT[norm_dtype])
+            _DT[x.dtype], _DT[x.dtype if delta is None else delta.dtype], _code(norm_dtype))
     if delta_row is None and out_src is None:
         rc = lib.hipie_add_layernorm(*args, _stream())
     else:
@@ -387,14 +402,15 @@ def add_layernorm_dec(x, delta, weight, bias, eps, aux_dtype, want16=False, adde
     C = x.shape[-1]
     rows = x.numel() // C
     out = torch.empty_like(x)
-    n16 = torch.empty(x.shape, dtype=aux_dtype, device=x.device) if want16 else None
-    s16 = torch.empty(x.shape, dtype=aux_dtype, device=x.device) if addend is not None else None
-    if addend is not None and (addend.dtype != aux_dtype or addend.shape != x.shape):
+    n16 = _alloc(tuple(x.shape), aux_dtype, x.device) if want16 else None
+    s16 = _alloc(tuple(x.shape), aux_dtype, x.device) if addend is not None else None
+    if addend is not None and ((addend.dtype != aux_dtype or addend.shape != x.shape) if aux_dtype != "hl8" else
+                               (addend.dtype != torch.float16 or addend.numel() != 2 * x.numel())):
         raise RuntimeError("add_layernorm_dec: addend must match x's shape in aux_dtype")
     rc = lib.hipie_add_layernorm_dec(_chk(x, "x", torch.float32), _chk(delta, "delta"), _chk(weight, "weight", torch.float32),
                                      _chk(bias, "bias", torch.float32), out.data_ptr(), None if n16 is None else n16.data_ptr(),
                                      None if addend is None else _chk(addend, "addend"), None if s16 is None else s16.data_ptr(),
-                                     rows, C, float(eps), _DT[delta.dtype], _DT[aux_dtype], _stream())
+                                     rows, C, float(eps), _DT[delta.dtype], _code(aux_dtype), _stream())
     _lib.check(rc, "hipie_add_layernorm_dec")
     return out, n16, s16
 
@@ -714,4 +730,66 @@ def gemm(a, w, bias=None, resid=None, out_fmt=F32, act=ACT_NONE, alpha=1.0, osca
                         None if r2 is None else r2.data_ptr(), 0 if r2 is None else r2.stride(0), o2.data_ptr(), o2.stride(0),
                         M, N, Kw, HL8 if split else F16, int(out_fmt), int(act), float(alpha), float(oscale), _stream())
     _lib.check(rc, "hipie_gemm")
+    return out
+
+
+@_timed(lambda qkv, tab_h, tab_w, grid_hw, heads: "vit_attn_global" if grid_hw[0] * grid_hw[1] > 256 else "vit_attn_window")
+def vit_attn_split(qkv, tab_h, tab_w, grid_hw, heads):
+    """hipie_vit_attn_split: qkv (B, gh*gw, 2 * 3*heads*hd) fp16 HL8 rows (q pre-scaled by scale*log2 e), tab_h (2*gh-1, 2*hd),
+    tab_w (2*gw-1, 2*hd) HL8 (tables / scale) -> (B, N, 2 * heads*hd) HL8."""
+    lib = _lib.load()
+    gh, gw = grid_hw
+    B, N, C6 = qkv.shape
+    hd = C6 // (6 * heads)
+    if qkv.dtype != torch.float16 or tab_h.dtype != torch.float16 or tab_w.dtype != torch.float16:
+        raise RuntimeError("vit_attn_split: HL8 (fp16) operands expected")
+    out = torch.empty(B, N, 2 * heads * hd, dtype=torch.float16, device=qkv.device)
+    rc = lib.hipie_vit_attn_split(_chk(qkv, "qkv"), _chk(tab_h, "tab_h"), _chk(tab_w, "tab_w"), out.data_ptr(), B, gh, gw, heads, hd, _stream())
+    _lib.check(rc, "hipie_vit_attn_split")
+    return out
+
+
+def vit_attn_split_ok(grid_hw, hd):
+    """geometry hipie_vit_attn_split covers: head_dim 64 / 80, 14-wide windows or token grids up to 64 x 64."""
+    gh, gw = grid_hw
+    return hd in (64, 80) and ((gw == 14 and gh <= 96) or (gw <= 64 and gh <= 64))
+
+
+# ---- split ("fp32-class") linears: cached HL8 copies of (derived) weights + the GEMM call ----------------------------------
+def split_weight(owner, key, params, weight_fn, bias_fn=None):
+    """HL8 copy of a weight (N, K) -> ((Np, 2K) fp16, bias (Np,) f32 | None, N), N padded to a multiple of 8 with zero rows.
+    Cached on ``owner`` under ``key``; the cache entry carries (data_ptr, version) of ``params``, so load_state_dict / .to() /
+    in-place updates invalidate it.  weight_fn / bias_fn build the (possibly folded / concatenated) fp32 tensors."""
+    ver = tuple((q.data_ptr(), q._version, str(q.device)) for q in params)
+    cache = owner.__dict__.setdefault("_hl8_cache", {})
+    e = cache.get(key)
+    if e is None or e[0] != ver:
+        w = weight_fn().detach().float()
+        b = None if bias_fn is None else bias_fn()
+        b = None if b is None else b.detach().float()
+        N = w.shape[0]
+        Np = (N + 7) // 8 * 8
+        if Np != N:
+            w = torch.nn.functional.pad(w, (0, 0, 0, Np - N))
+            b = None if b is None else torch.nn.functional.pad(b, (0, Np - N))
+        e = (ver, hl8_pack(w), None if b is None else b.contiguous(), N)
+        cache[key] = e
+    return e[1], e[2], e[3]
+
+
+def split_ok(K):
+    return K % 32 == 0
+
+
+def split_linear(x, owner, key, weight, bias=None, act=ACT_NONE, out_fmt=F32, resid=None, x_hl8=False, weight_fn=None, bias_fn=None,
+                 tag="gemm", params=None):
+    """F.linear(x, weight, bias) at fp32-class accuracy on hipie_gemm's split operands.  x fp32 / fp16 (converted with hipie_to_hl8)
+    or already HL8 (x_hl8).  weight_fn / bias_fn: derived weights (folded constants, concatenations) built once per parameter version."""
+    if params is None:
+        params = [weight] + ([bias] if bias is not None else [])
+    w, b, N = split_weight(owner, key, params, weight_fn or (lambda: weight), bias_fn or ((lambda: bias) if bias is not None else None))
+    a = x if x_hl8 else to_hl8(x if x.dtype in (torch.float32, torch.float16) else x.float())
+    out = gemm(a, w, b, resid, out_fmt=out_fmt, act=act, split=True, tag=tag)
+    if N != w.shape[0]:
+        out = out[..., :(2 * N if out_fmt == HL8 else N)].contiguous()
     return out

@@ -33,6 +33,9 @@ extern "C" {
                                 Same bytes as fp32; the operand format of the fp32-class products on the 16-bit matrix pipe
                                 (hipie_gemm, hipie_vit_attn_rel with HIPIE_ATTN_SPLIT).  Row strides are given in fp16 elements (>= 2K). */
 
+#define HIPIE_OUT_F32 0x100   /* or-ed into the `dtype` of hipie_flash_attn / hipie_bi_xattn(_ws): q, k, v stay 16 bit, the OUTPUT(S) are written as
+                                fp32 (output strides in fp32 elements): the attention result enters the next linear unrounded */
+
 /* flags of the attention entry points that take a `flags` argument */
 #define HIPIE_ATTN_FAST 1    /* deferred running max (rescale only when a row maximum grows by > 2^8) and, where the head dim
                                 leaves a padded MFMA row, softmax denominators from a ones column of V (same 16-bit-rounded
@@ -375,6 +378,17 @@ int hipie_box_refine(const void* delta, const float* ref, float* out, int64_t n,
 int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* resid, int64_t ldr,
                void* out, int64_t ldo, int M, int N, int K, int in_fmt, int out_fmt, int act, float alpha, float oscale,
                void* stream);
+
+/*
+ * hipie_vit_attn_rel on SPLIT operands (fp32-class logits): qkv (B, gh*gw, 3, heads, hd) as HIPIE_HL8 rows (2 * 3 * heads * hd fp16
+ * per token) with the q rows pre-scaled by scale * log2(e); tab_h (2*gh-1, hd), tab_w (2*gw-1, hd) = the rel-pos tables / scale, HL8.
+ * Scores and both bias terms are three-product sums (q_lo.k_hi + q_hi.k_lo + q_hi.k_hi), the probabilities one fp16, V both halves;
+ * classic running maximum, fp32 row sums.  out (B, gh*gw, heads*hd) as HIPIE_HL8: the A operand of the projection hipie_gemm.
+ * Replaces: Attention.forward between the qkv and proj Linears (hipie/backbone/vit.py:69-80) + add_decomposed_rel_pos / get_rel_pos
+ * (hipie/backbone/utils.py:63-125) at the reference's fp32 accuracy.  Geometry: head_dim 64 | 80; 14-wide windows, grids up to 64 wide.
+ */
+int hipie_vit_attn_split(const void* qkv, const void* tab_h, const void* tab_w, void* out, int B, int gh, int gw, int heads,
+                         int hd, void* stream);
 
 /* rows of `x_dtype` (HIPIE_F32 | HIPIE_F16) values -> HIPIE_HL8 rows of scale * x (K a multiple of 8; ldx in elements of x, ldo in
  * fp16 elements >= 2K): the generic producer of split operands (the LayerNorm / GEMM epilogues emit HL8 directly). */

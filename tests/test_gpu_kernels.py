@@ -788,3 +788,94 @@ def test_decoder_heads_fused(dt, tol):
         want_b = torch.sigmoid(om.mlp(x, sd, "bb.", 3) + om.inverse_sigmoid(ref))
         got_b = ops.box_head(x.to(DEV), ref.to(DEV), bb)
         assert rel_err(got_b.cpu(), want_b) < 5e-6
+
+
+# ------------------------------------------------------------------------------------------------ split-fp16 ("HL8") kernels
+@pytest.mark.parametrize("name", ["window14", "global16", "global64", "global_rect"])
+def test_vit_attention_split_golden(name):
+    """hipie_vit_attn_split on the reference-generated cases, fed the UNROUNDED fp32 qkv / tables as HL8 pairs: vs the fp32 oracle
+    (the only 16-bit rounding left is the probability operand: 3e-4) and, through the projection, vs the reference golden."""
+    import torch.nn.functional as F
+    from hipie_amd import ops
+    from hipie_amd.modeling.vit import resize_rel_pos
+    g = Golden("vit_attn")
+    c, sd, x = vit_attn_case(g, name)
+    B, H, W, C = x.shape
+    heads = c["heads"]
+    hd = C // heads
+    assert ops.vit_attn_split_ok((H, W), hd)
+    scale = hd ** -0.5
+    c1 = scale * ops.LOG2E
+    qkv32 = _vit_qkv(c, sd, x)
+    f = qkv32.clone()
+    f[..., :C] *= c1
+    th32, tw32 = resize_rel_pos(H, sd["rel_pos_h"]), resize_rel_pos(W, sd["rel_pos_w"])
+    got = ops.vit_attn_split(ops.hl8_pack(f).to(DEV), ops.hl8_pack(th32 / scale).to(DEV), ops.hl8_pack(tw32 / scale).to(DEV), (H, W), heads)
+    got = ops.hl8_unpack(got).cpu()
+    q, k, v = qkv32.reshape(B, H * W, 3, heads, hd).permute(2, 0, 3, 1, 4).reshape(3, B * heads, H * W, hd).unbind(0)
+    want = oo.vit_attention_core(q, k, v, th32, tw32, (H, W), scale)
+    want = want.view(B, heads, H * W, hd).permute(0, 2, 1, 3).reshape(B, H * W, C)
+    e1 = rel_err(got, want)
+    out = F.linear(got, sd["proj.weight"], sd["proj.bias"]).view(B, H, W, C)
+    e2 = rel_err(g.like(name + "_out", out), g[name + "_out"])
+    print("vit_attn_split %s: vs fp32 oracle %.2e, vs golden (after proj) %.2e" % (name, e1, e2))
+    assert e1 < 1.5e-4 and e2 < 2e-4
+
+
+@pytest.mark.parametrize("B,gh,gw,heads,hd", [
+    (1, 64, 64, 16, 80),         # the ViT-H global block at 1024^2
+    (2, 40, 64, 8, 64),          # ViT-B/L head dim, fewer rows than columns, batch/head swizzle on
+    (3, 14, 14, 5, 80),          # windows: 7-wave workgroups, odd batch*heads (no swizzle)
+    (2, 7, 14, 2, 80),           # odd number of key rows with two rows per tile (ragged last tile)
+    (1, 33, 50, 3, 64)])
+def test_vit_attention_split_against_materialised_scores(B, gh, gw, heads, hd):
+    """the reference's own formulation with the (N x N) score tensor materialised in fp64 on the device, random fp32 operands with
+    LARGE logits (|q.k| up to ~25: a single-fp16 q or k would move the probabilities by 1e-2)."""
+    from hipie_amd import ops
+    gen = torch.Generator().manual_seed(21 + gh + gw)
+    N, C = gh * gw, heads * hd
+    scale = hd ** -0.5
+    c1 = scale * ops.LOG2E
+    qkv = torch.randn(B, N, 3 * C, generator=gen) * 1.6
+    th32, tw32 = torch.randn(2 * gh - 1, hd, generator=gen) * 0.2, torch.randn(2 * gw - 1, hd, generator=gen) * 0.2
+    f = qkv.clone()
+    f[..., :C] *= c1
+    q, k, v = (t.to(DEV).double().view(B, heads, N, hd) for t in qkv.reshape(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4))
+    idx_h = torch.arange(gh, device=DEV)[:, None] - torch.arange(gh, device=DEV)[None, :] + gh - 1
+    idx_w = torch.arange(gw, device=DEV)[:, None] - torch.arange(gw, device=DEV)[None, :] + gw - 1
+    Rh, Rw = th32.to(DEV).double()[idx_h], tw32.to(DEV).double()[idx_w]
+    rq = q.reshape(B, heads, gh, gw, hd)
+    rel_h = torch.einsum("bmhwc,hkc->bmhwk", rq, Rh)
+    rel_w = torch.einsum("bmhwc,wkc->bmhwk", rq, Rw)
+    attn = (q * scale) @ k.transpose(-2, -1)
+    attn = (attn.view(B, heads, gh, gw, gh, gw) + rel_h[..., :, None] + rel_w[..., None, :]).view(B, heads, N, N)
+    want = (attn.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B, N, C)
+    got = ops.hl8_unpack(ops.vit_attn_split(ops.hl8_pack(f).to(DEV), ops.hl8_pack(th32 / scale).to(DEV), ops.hl8_pack(tw32 / scale).to(DEV),
+                                            (gh, gw), heads))
+    e = rel_err(got.cpu(), want.float().cpu())
+    print("vit_attn_split %dx%d hd %d: %.2e" % (gh, gw, hd, e))
+    assert e < 4e-4
+
+
+def test_layernorm_hl8_outputs():
+    """hipie_add_layernorm / _rows / _dec with HIPIE_HL8 outputs == the fp32 outputs split by hl8_pack (bit for bit)."""
+    from hipie_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    x = (torch.randn(2, 9, 9, 160, generator=gen) * 3).to(DEV)
+    d = torch.randn(2, 9, 9, 160, generator=gen).to(DEV)
+    w, b = (1 + 0.1 * torch.randn(160, generator=gen)).to(DEV), (0.1 * torch.randn(160, generator=gen)).to(DEV)
+    r32, n32 = ops.add_layernorm(x, d, w, b, 1e-6, torch.float32)
+    r, n = ops.add_layernorm(x, d, w, b, 1e-6, "hl8")
+    assert torch.equal(r, r32) and n.shape == (2, 9, 9, 320) and torch.equal(n, ops.hl8_pack(n32))
+    # window row maps (zero rows for the padding) with the HL8 output
+    from hipie_amd.modeling.vit import window_row_maps
+    out_src, delta_row, nwin = window_row_maps(2, 9, 9, 7, x.device)
+    _, nw32 = ops.add_layernorm(x, d, w, b, 1e-6, torch.float32, out_src=out_src)
+    _, nw = ops.add_layernorm(x, d, w, b, 1e-6, "hl8", out_src=out_src)
+    assert torch.equal(nw, ops.hl8_pack(nw32))
+    # decoder form: fp32 + HL8 + (n + addend) as HL8
+    xs, ds = x.view(-1, 160).contiguous(), d.view(-1, 160).contiguous()
+    add32 = torch.randn(xs.shape, generator=gen).to(DEV)
+    o32, n16, s16 = ops.add_layernorm_dec(xs, ds, w, b, 1e-5, "hl8", want16=True, addend=ops.hl8_pack(add32))
+    assert torch.equal(n16, ops.hl8_pack(o32))
+    assert torch.equal(s16, ops.hl8_pack(o32 + ops.hl8_unpack(ops.hl8_pack(add32))))

@@ -95,6 +95,10 @@ def p_matmul(x, y):
     a, c = Sim.modes()
     if Sim.region in ("bert", "mha"):     # the attention products of BERT / nn.MultiheadAttention (their linears go through F.linear)
         a, c = Sim.policy.get(Sim.region + "_attn", (a, c))
+        r = _matmul(rnd(x, a), rnd(y, c))
+        if x.shape[-1] == x.shape[-2] and x.dim() >= 3:      # probabilities @ values: the kernel's OUTPUT type (attn_out)
+            r = rnd(r, Sim.policy.get("attn_out", "f"))
+        return r
     return _matmul(rnd(x, a), rnd(y, c))
 
 
@@ -102,6 +106,10 @@ def p_bmm(x, y):
     a, c = Sim.modes()
     if Sim.region == "bi":                # the two score / two value products of the fusion attention
         a, c = Sim.policy.get("bi_attn", (a, c))
+        r = _bmm(rnd(x, a), rnd(y, c))
+        if y.shape[-1] == 256 and x.shape[-1] != 256:
+            r = rnd(r, Sim.policy.get("attn_out", "f"))
+        return r
     return _bmm(rnd(x, a), rnd(y, c))
 
 
@@ -190,6 +198,7 @@ POLICIES = {
     "cand_einsum_h": {"default": S3, "vit_attn_pv": ("u", "h"), "einsum": H2},
     "cand_einsum_sa": {"default": S3, "vit_attn_pv": ("u", "h"), "einsum": ("s", "h")},
     "cand_b": {"default": S3, "vit_attn_pv": ("u", "s"), "bert_attn": H2, "mha_attn": H2, "bi_attn": H2},
+    "cand_b_out_h": {"default": S3, "vit_attn_pv": ("u", "s"), "bert_attn": H2, "mha_attn": H2, "bi_attn": H2, "attn_out": "h"},
     "cand_b_conv_h": {"default": S3, "vit_attn_pv": ("u", "s"), "bert_attn": H2, "mha_attn": H2, "bi_attn": H2, "conv": H2},
     "split3_vit_head_h": {"default": H2, "vit_lin": S3, "vit_attn_qk": S3, "vit_attn_rel": S3, "vit_attn_pv": ("u", "s")},
 }
