@@ -8,11 +8,18 @@ A "step" is one pass of the hot path (HIPIE_IMG.forward_raw: preprocess -> BERT 
 MaskDINO -> a22 output dict, then the compact per-image top-100 predictions and -- for N > 1 -- their RCCL all-gather)
 over one batch of synthetic images that is already resident in HBM.  Workload (BASELINE.json configs[2], the one the
 metric is quoted on): ViT-H backbone, 1024x1024, batch 8 per GPU, COCO-80 class prompt (L = 194 tokens), task "detection".
-Data-parallel weak scaling: every rank processes its own batch of 8.
+Data parallel (weak scaling): ONE global batch of 8 * N images (image i is seeded by i) is cut into contiguous index ranges with
+parallel.shard_range -- configs[3] literally at N = 8: 64 images, 8 per rank -- and every rank's compact predictions are
+all-gathered (RCCL over xGMI); the JSON line carries the number of ranks the collective really saw and the gathered block's shape.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant hand-written kernel (global ViT attention,
-flash_attn_kernel<bf16, 80, 2, bias>), timed live with HIP events on the launch stream inside the timed steps;
-`cpu_baseline` times the oracle (CPU restatement of the reference) on a bounded sample on this host.
+The timed arithmetic is Precision.split3 ("split"): every linear and the ViT attention logits on split-fp16 operands (three MFMA
+products, fp32 accumulation = fp32-class), the policy whose a22 outputs stay within BASELINE.json's 1e-3 of the reference at the
+shipped depths (`parity_err`, measured by this script on tests/golden/e2e_deep.npz and e2e_tiny.npz).  `fast_policy` is the
+out-of-tolerance fp16 throughput mode, timed beside it for reference only.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant hand-written kernel (gemm_kernel<320, split>: the four ViT
+linears, 128 launches per step), timed live with HIP events on the launch stream; `roofline_attention` the same for the global
+ViT attention kernel; `cpu_baseline` times the oracle (CPU restatement of the reference) on this host.
 """
 import argparse
 import json
@@ -26,14 +33,22 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 
-def synth_batch(cfg, batch, size, n_classes, L, device, seed=0, task="detection"):
+def synth_image(index, size, device, seed=0):
+    """image `index` of the global synthetic batch: uint8-valued, seeded by its GLOBAL index (every rank can build any image)."""
+    gi = torch.Generator().manual_seed(1000003 * seed + 7919 * index + 13)
+    return torch.randint(0, 256, (3, size, size), generator=gi).float().to(device)
+
+
+def synth_batch(cfg, batch, size, n_classes, L, device, seed=0, task="detection", indices=None):
+    """`batch` inputs; images are those of the global indices `indices` (default 0 .. batch-1), the prompt is shared."""
     g = torch.Generator().manual_seed(seed)
+    indices = list(range(batch)) if indices is None else list(indices)
     if task == "grounding":                     # one referring expression of ~10 tokens (BASELINE configs[2], second call)
         n = 10
         ids = torch.tensor([101] + torch.randint(1996, 29000, (n,), generator=g).tolist() + [102])
         mask = torch.ones_like(ids)
-        return [{"image": torch.randint(0, 256, (3, size, size), generator=g).float().to(device), "task": "grounding",
-                 "input_ids": ids.to(device), "attention_mask": mask.to(device)} for _ in range(batch)]
+        return [{"image": synth_image(i, size, device, seed), "task": "grounding",
+                 "input_ids": ids.to(device), "attention_mask": mask.to(device)} for i in indices]
     ids = torch.zeros(L, dtype=torch.long)
     mask = torch.zeros(L, dtype=torch.long)
     row, pmap = [101], {}
@@ -51,8 +66,8 @@ def synth_batch(cfg, batch, size, n_classes, L, device, seed=0, task="detection"
     ids[:len(row)] = torch.tensor(row)
     mask[:len(row)] = 1
     out = []
-    for b in range(batch):
-        img = torch.randint(0, 256, (3, size, size), generator=g).float().to(device)      # resident in HBM before timing
+    for i in indices:
+        img = synth_image(i, size, device, seed)                                          # resident in HBM before timing
         out.append({"image": img, "task": "detection", "input_ids": ids.to(device), "attention_mask": mask.to(device),
                     "positive_map_label_to_token": pmap, "is_thing": {c: (c <= 60) for c in pmap}})
     return out
@@ -84,16 +99,17 @@ def _median_time(fn, runs=3, warmup=1):
     return sorted(ts)[len(ts) // 2]
 
 
-def cpu_baseline(cfg_dict, size, L, n_classes):
-    """oracle (kind "port") on the host cores, bounded, 1 warm-up + 3 timed runs each (median):
-      (1) BASELINE configs[0] in full: ResNet-50 configuration, one 512x512 image + one referring expression;
-      (2) the timed workload's own configuration on ONE image: text encoder + everything after the backbone in full, plus one
-          windowed and one global ViT block, s/img = t_rest + n_win t_win + n_glob t_glob (a full 32-block ViT-H forward per
-          run would take minutes per repetition)."""
+def cpu_baseline(cfg_dict, size, L, n_classes, budget_s=300.0):
+    """oracle (kind "port") on the host cores with torch.set_num_threads(os.cpu_count()):
+      (1) BASELINE configs[0] in full: ResNet-50 configuration, one 512x512 image + one referring expression, 1 warm-up + 3 runs;
+      (2) the timed workload's own configuration on ONE image, IN FULL (all 32 ViT-H blocks, text encoder, both heads), one run
+          after a warm-up of the text encoder -- if a sampled estimate (one windowed + one global block measured and scaled) says the
+          full forward would not fit the time budget, that sampled figure is reported instead and labelled as such."""
     from oracle import model as om
     from hipie_amd.config import HipieConfig, Precision
     from hipie_amd.hipie_img import HIPIE_IMG
-    threads = min(os.cpu_count(), 32)       # more threads than this makes the many small fp32 ops slower, not faster
+    t_start = time.time()
+    threads = os.cpu_count()
     torch.set_num_threads(threads)
     torch.set_grad_enabled(False)
     # (1) R50, 512x512, grounding
@@ -110,57 +126,90 @@ def cpu_baseline(cfg_dict, size, L, n_classes):
         om.coco_inference([gb[0]["image"]], lang, sd, rc, task="grounding")
     t_r50 = _median_time(r50_forward)
     del sd
-    # (2) the timed configuration, ViT truncated to 1 windowed + 1 global block for the "rest" measurement
+    # (2) the timed configuration
     c = dict(cfg_dict)
     nwin = len(cfg_dict["vit_window_blocks"])
     nglob = cfg_dict["vit_depth"] - nwin
-    c.update(vit_depth=2, vit_window_blocks=[0])
     m = HIPIE_IMG(HipieConfig.from_dict(c), Precision.parity(), device="cpu")
     randomize_degenerate_inits(m)
     sd = {k: v.float() for k, v in m.state_dict().items()}
     del m
     batch = synth_batch(None, 1, size, n_classes, L, "cpu", seed=1)
     ids, mask = batch[0]["input_ids"][None], batch[0]["attention_mask"][None]
-
-    def rest_forward():
-        lang = om.bert_encoder(ids, mask, sd, "text_encoder.body.model.", c)
-        om.coco_inference([batch[0]["image"]], lang, sd, c, task="detection")
-    t_total2 = _median_time(rest_forward, runs=3, warmup=1)
     x = torch.randn(1, size // 16, size // 16, c["vit_embed_dim"])
     p = "detr.detr.backbone.0.backbone.blocks."
-    t_win = _median_time(lambda: om.vit_block(x, sd, p + "0.", c["vit_heads"], c["vit_window"]))
-    t_glob = _median_time(lambda: om.vit_block(x, sd, p + "1.", c["vit_heads"], 0))
+    wb = cfg_dict["vit_window_blocks"]
+    gblk = [i for i in range(cfg_dict["vit_depth"]) if i not in wb][0]
+    t_win = _median_time(lambda: om.vit_block(x, sd, p + "%d." % wb[0], c["vit_heads"], c["vit_window"]), runs=2)
+    t_glob = _median_time(lambda: om.vit_block(x, sd, p + "%d." % gblk, c["vit_heads"], 0), runs=2)
+    est_vit = nwin * t_win + nglob * t_glob
+    r50 = {"value": round(1.0 / t_r50, 4), "unit": "images/sec", "s_per_image": round(t_r50, 3),
+           "what": "BASELINE configs[0]: ResNet-50, one 512x512 image + one referring expression, full forward"}
+    spent = time.time() - t_start
+    if spent + 2.2 * est_vit < budget_s:                 # full forward: ViT estimate + the heads (about as long again at most)
+        def full_forward():
+            lang = om.bert_encoder(ids, mask, sd, "text_encoder.body.model.", c)
+            om.coco_inference([batch[0]["image"]], lang, sd, c, task="detection")
+        om.bert_encoder(ids, mask, sd, "text_encoder.body.model.", c)          # warm-up of the allocator / thread pool
+        t0 = time.time()
+        full_forward()
+        s_img = time.time() - t0
+        return {"value": round(1.0 / s_img, 5), "unit": "images/sec", "cores": threads, "kind": "port", "extrapolated": False,
+                "sample": "oracle/ (fp32 PyTorch CPU restatement of the reference), torch.set_num_threads(%d): ONE full forward of one "
+                          "image %dx%d, L=%d (all %d ViT-H blocks + text encoder + both heads): %.1f s  (single blocks: windowed %.2f s, "
+                          "global %.2f s)" % (threads, size, size, L, cfg_dict["vit_depth"], s_img, t_win, t_glob),
+                "r50_512_grounding_full": r50}
+    # fallback: heads in full on a 2-block ViT, blocks scaled
+    c2 = dict(c)
+    c2.update(vit_depth=2, vit_window_blocks=[0])
+    m = HIPIE_IMG(HipieConfig.from_dict(c2), Precision.parity(), device="cpu")
+    randomize_degenerate_inits(m)
+    sd2 = {k: v.float() for k, v in m.state_dict().items()}
+    del m
+
+    def rest_forward():
+        lang = om.bert_encoder(ids, mask, sd2, "text_encoder.body.model.", c2)
+        om.coco_inference([batch[0]["image"]], lang, sd2, c2, task="detection")
+    t_total2 = _median_time(rest_forward, runs=1, warmup=1)
     s_img = t_total2 + (nwin - 1) * t_win + (nglob - 1) * t_glob
-    return {"value": round(1.0 / s_img, 5), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "oracle/ (fp32 PyTorch CPU restatement), 1 warm-up + 3 runs, median: 1 image %dx%d, L=%d: text encoder + "
-                      "everything after the backbone %.2fs (incl. 1 windowed + 1 global ViT block), windowed block %.2fs, global "
-                      "block %.2fs, scaled to %d+%d blocks = %.1fs/image" % (size, size, L, t_total2, t_win, t_glob, nwin, nglob, s_img),
-            "r50_512_grounding_full": {"value": round(1.0 / t_r50, 4), "unit": "images/sec", "s_per_image": round(t_r50, 3),
-                                       "what": "BASELINE configs[0]: ResNet-50, one 512x512 image + one referring expression, full forward"}}
+    return {"value": round(1.0 / s_img, 5), "unit": "images/sec", "cores": threads, "kind": "port", "extrapolated": True,
+            "sample": "oracle/ (fp32 PyTorch CPU restatement), torch.set_num_threads(%d); the full forward was estimated beyond the %.0f s "
+                      "budget, so SAMPLED: 1 image %dx%d, L=%d: text encoder + everything after the backbone %.2fs (incl. 1 windowed + 1 "
+                      "global ViT block), windowed block %.2fs, global block %.2fs, scaled to %d+%d blocks = %.1fs/image"
+                      % (threads, budget_s, size, size, L, t_total2, t_win, t_glob, nwin, nglob, s_img),
+            "r50_512_grounding_full": r50}
 
 
 def parity_error(policy, device):
-    """max|a-b| / max|b| of every a22 output of the tiny end-to-end model under `policy` against the fixture produced by the
-    reference's own DDETRSegmUniDN.coco_inference (tests/golden/e2e_tiny.npz; top-k pinned) -- the same check as
-    tests/test_gpu_e2e.py, run by the bench so that the timed arithmetic carries its own error."""
+    """max|a-b| / max|b| of every a22 output under `policy` against the fixtures produced by the reference's own
+    DDETRSegmUniDN.coco_inference (top-k pinned): tests/golden/e2e_deep.npz (the SHIPPED depths: 32 ViT blocks, 6 + 6 + 6 + 9
+    layers, 12-layer BERT) and e2e_tiny.npz -- the same checks as tests/test_gpu_e2e.py, run by the bench so that the timed
+    arithmetic carries its own error."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import _synth
     from util import Golden, rel_err
     from hipie_amd.config import HipieConfig
     from hipie_amd.hipie_img import HIPIE_IMG
-    g = Golden("e2e_tiny")
-    model = HIPIE_IMG(HipieConfig.from_dict(g.meta["cfg"]), policy, device=device)
-    model.load_state_dict(_synth.synth_full_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}), strict=True)
-    imgs = _synth.synth_images([tuple(s) for s in g.meta["sizes"]], seed=73)
-    ids, mask, pmap = _synth.synth_token_ids(2, g.meta["detection"]["n_classes"], 64, seed=74)
-    model.pin_topk(g["detection_topk_fg"], g["detection_topk_md"])
-    out = model.forward_raw([{"image": im, "task": "detection", "input_ids": ids[i], "attention_mask": mask[i],
-                              "positive_map_label_to_token": pmap} for i, im in enumerate(imgs)])
-    keys = ["pred_logits", "pred_boxes", "pred_boxious", "pred_masks", "pred_masks_maskdino", "pred_logits_maskdino", "pred_boxes_maskdino"]
-    errs = {k: rel_err(g.like("detection_" + k, out[k].float().cpu()), g["detection_" + k]) for k in keys}
-    return {"max": float("%.2e" % max(errs.values())), "per_output": {k: float("%.1e" % v) for k, v in errs.items()},
-            "against": "tests/golden/e2e_tiny.npz (reference coco_inference, tiny model, pinned top-k)"}
+    keys = ["pred_logits", "pred_boxes", "pred_boxious", "pred_masks", "reference_points", "pred_masks_maskdino", "pred_logits_maskdino",
+            "pred_boxes_maskdino"]
+    res, worst = {}, 0.0
+    for fixture in ("e2e_deep", "e2e_tiny"):
+        g = Golden(fixture)
+        model = HIPIE_IMG(HipieConfig.from_dict(g.meta["cfg"]), policy, device=device)
+        model.load_state_dict(_synth.synth_full_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}), strict=True)
+        imgs = _synth.synth_images([tuple(s) for s in g.meta["sizes"]], seed=73)
+        ids, mask, pmap = _synth.synth_token_ids(2, g.meta["detection"]["n_classes"], 64, seed=74)
+        model.pin_topk(g["detection_topk_fg"], g["detection_topk_md"])
+        out = model.forward_raw([{"image": im, "task": "detection", "input_ids": ids[i], "attention_mask": mask[i],
+                                  "positive_map_label_to_token": pmap} for i, im in enumerate(imgs)])
+        errs = {k: rel_err(g.like("detection_" + k, out[k].float().cpu()), g["detection_" + k]) for k in keys}
+        res[fixture] = {"max": float("%.2e" % max(errs.values())), "per_output": {k: float("%.1e" % v) for k, v in errs.items()}}
+        worst = max(worst, max(errs.values()))
+        del model
+        torch.cuda.empty_cache()
+    return {"max": float("%.2e" % worst), "tolerance": 1e-3, "within_tolerance": bool(worst <= 1e-3), "fixtures": res,
+            "against": "tests/golden/e2e_deep.npz (full depth) and e2e_tiny.npz: the reference's own coco_inference, pinned top-k"}
 
 
 def main():
@@ -179,9 +228,11 @@ def main():
                     "--classes 1203 --text-len 4096 --size 1344 the LVIS shape of configs[4]")
     ap.add_argument("--task", default="detection", choices=["detection", "grounding"],
                     help="grounding = the referring-expression call of BASELINE configs[2] (one ~12-token expression)")
-    ap.add_argument("--precision", default="fast", choices=["fast", "parity", "bf16", "default"])
+    ap.add_argument("--precision", default="split", choices=["split", "fast", "parity", "bf16", "default"],
+                    help="split (default, the timed policy): split-fp16 GEMMs and attention logits, within 1e-3 of the reference at the "
+                         "shipped depths; fast: single-fp16 operands (out of tolerance); parity: fp32 library GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-parity-leg", action="store_true", help="skip parity_err and the parity-policy timing (rank 0, N = 1)")
+    ap.add_argument("--no-parity-leg", action="store_true", help="skip parity_err and the fast-policy timing (rank 0, N = 1)")
     ap.add_argument("--graph", action="store_true", help="capture the forward once into a hipGraph and replay it (experimental: "
                     "after the launch-count reductions the eager path is no longer host-bound, and whole-model replay "
                     "showed an unexplained GPU memory fault -- DESIGN.md section 9)")
@@ -236,13 +287,17 @@ def main():
         torch.cuda.tunable.tuning_enable(False)
 
     cfg = getattr(HipieConfig, args.model)()
-    prec = {"fast": Precision.fast(), "parity": Precision.parity(), "bf16": Precision.bf16(), "default": Precision()}[args.precision]
+    prec = {"split": Precision.split3(), "fast": Precision.fast(), "parity": Precision.parity(), "bf16": Precision.bf16(),
+            "default": Precision()}[args.precision]
     torch.manual_seed(0)
     model = HIPIE_IMG(cfg, prec, device=dev)
     randomize_degenerate_inits(model)
     model.finalize()
     L, n_classes = args.text_len, args.classes
-    batch = synth_batch(cfg, args.batch, args.size, n_classes, L, dev, seed=rank, task=args.task)
+    # ONE global batch of batch * world images (image i seeded by i), cut like detectron2's InferenceSampler: rank r owns a contiguous
+    # index range (BASELINE configs[3] at --gpus 8: 64 images, 8 per rank)
+    shard = parallel.shard_range(args.batch * world, rank, world)
+    batch = synth_batch(cfg, len(shard), args.size, n_classes, L, dev, seed=0, task=args.task, indices=shard)
 
     def local_step():
         out = model.forward_raw(batch)
@@ -255,8 +310,10 @@ def main():
     def step():
         return parallel.all_gather_predictions(local_step())
 
+    gathered = None
     for _ in range(max(args.warmup, 1)):
-        step()
+        gathered = step()
+    dp = parallel.dp_evidence(gathered, args.batch, rank, world, dev)     # rccl_ranks (all-reduce of ones), shard, gathered shape
 
     # The forward has static shapes and no host<->device traffic, so it CAN be captured once into a hipGraph and replayed
     # (--graph).  Default is eager: with batched post-processing and the fused glue kernels the step is GPU-bound.
@@ -304,10 +361,12 @@ def main():
 
     # dominant hand-written kernel, timed live with HIP events on the launch stream: the same 24 launches per step of the
     # global-attention kernel, issued eagerly (events cannot be placed inside a graph replay) right after the timed region
-    ops.PROFILE.enable("vit_attn_global")
+    gemm_tags = ("gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2")
+    ops.PROFILE.enable("vit_attn_global", *gemm_tags)
     for _ in range(min(args.steps, 3)):
         model.forward_raw(batch)
     kern_ms, kern_n = ops.PROFILE.mean_ms("vit_attn_global")
+    gemm = {t: ops.PROFILE.mean_ms(t) for t in gemm_tags}
     ops.PROFILE.disable()
 
     # the full post-processing of the reference's eval branch (instance masks at 1024^2, semantic + panoptic maps),
@@ -323,31 +382,33 @@ def main():
         post_ms = (time.perf_counter() - t1) * 1e3
         del out
 
-    # the timed arithmetic carries its own error, and the parity policy (<= 1e-3 on every a22 output) is timed beside it:
-    # same model, same batch, same step definition, fp32 GEMMs (N = 1, rank 0 only; a few steps -- it is ~5x slower)
+    # the timed arithmetic carries its own error (both reference-generated fixtures); the out-of-tolerance fp16 mode is timed beside
+    # it for reference: same model, same batch, same step definition (N = 1, rank 0 only)
     parity_err = other = None
     if rank == 0 and world == 1 and not args.no_parity_leg:
         try:
             parity_err = parity_error(prec, dev)
-            if args.precision != "parity" and args.model == "vit_huge":
+            if args.precision != "fast" and args.model == "vit_huge":
                 del model
                 torch.cuda.empty_cache()
                 torch.manual_seed(0)
-                pm = HIPIE_IMG(cfg, Precision.parity(), device=dev)
+                pm = HIPIE_IMG(cfg, Precision.fast(), device=dev)
                 randomize_degenerate_inits(pm)
                 pm.finalize()
 
                 def pstep():
                     return inference_compact(pm, pm.forward_raw(batch), batch, topk=100)
-                pstep()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
                 for _ in range(2):
                     pstep()
                 torch.cuda.synchronize()
-                pdt = (time.perf_counter() - t1) / 2
-                other = {"precision_policy": "parity", "dtype": "f32+f16attn", "value": round(args.batch / pdt, 3), "unit": "images/sec",
-                         "ms_per_step": round(pdt * 1e3, 2), "steps": 2, "parity_err": parity_error(Precision.parity(), dev)}
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    pstep()
+                torch.cuda.synchronize()
+                pdt = (time.perf_counter() - t1) / args.steps
+                other = {"precision_policy": "fast", "dtype": "f16", "value": round(args.batch / pdt, 3), "unit": "images/sec",
+                         "ms_per_step": round(pdt * 1e3, 2), "steps": args.steps, "parity_err": parity_error(Precision.fast(), dev),
+                         "note": "single-fp16 operands everywhere: OUTSIDE the 1e-3 tolerance, not the headline"}
                 model = pm
         except Exception as e:          # never lose the measured line to the side legs
             print("bench: parity leg failed: %r" % (e,), file=sys.stderr)
@@ -364,39 +425,70 @@ def main():
         ops.PROFILE.disable()
 
     if rank == 0:
-        traffic = None                  # HBM bytes per launch of the roofline kernel from the committed PMC passes (same shape only)
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_attention.json")
-        if os.path.exists(pmc) and args.model == "vit_huge" and args.batch == 8 and args.size == 1024:
-            traffic = json.load(open(pmc))["traffic_bytes_per_launch"]
+        std = args.model == "vit_huge" and args.batch == 8 and args.size == 1024
+        pmc = {}
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_kernels.json")
+        if os.path.exists(pmc_path) and std:
+            pmc = json.load(open(pmc_path))
         images = args.batch * world * args.steps
         N = (args.size // 16) ** 2
-        flops = 4.0 * N * N * cfg.vit_embed_dim * args.batch          # QK^T + PV of one global block, all heads, this batch
+        E = cfg.vit_embed_dim
+        flops = 4.0 * N * N * E * args.batch          # QK^T + PV of one global block, all heads, this batch
         ach = flops / (kern_ms * 1e-3) / 1e12 if kern_ms else None
+        split = args.precision == "split"
+        # the four ViT linears: algorithmic flops 2 M N K per launch (M = batch * tokens); the split form issues 3 MFMA flops per
+        # algorithmic flop (x_lo.w_hi + x_hi.w_lo + x_hi.w_hi)
+        M_tok = args.batch * N
+        shapes = {"gemm_qkv": (E, 3 * E), "gemm_proj": (E, E), "gemm_fc1": (E, 4 * E), "gemm_fc2": (4 * E, E)}
+        g_ms = sum(gemm[t][0] * gemm[t][1] for t in shapes if gemm.get(t, (None, 0))[0])
+        g_n = sum(gemm[t][1] for t in shapes if gemm.get(t, (None, 0))[0])
+        g_flop = sum(2.0 * M_tok * k * n * gemm[t][1] for t, (k, n) in shapes.items() if gemm.get(t, (None, 0))[0])
+        g_ach = g_flop / (g_ms * 1e-3) / 1e12 if g_ms else None
+        roof_attn = {"bound": "mfma", "kernel": "%s (ViT global attention, %d launches timed)" %
+                     ("vit_attn_split_kernel<hd%d,NB2,8 waves>: split-fp16 logits (3 products), V hi+lo (2 products)" % (E // cfg.vit_heads)
+                      if split else "vit_attn_sp_kernel<%s,hd%d>" % (str(prec.attn).split(".")[-1], E // cfg.vit_heads), kern_n),
+                     "achieved": None if ach is None else round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                     "frac": None if ach is None else round(ach / 2500.0, 4), "mfma_flops_per_algorithmic_flop": 2.5 if split else 1.0,
+                     "frac_mfma_issued": None if ach is None else round(ach * (2.5 if split else 1.0) / 2500.0, 4),
+                     "avg_launch_ms": None if not kern_ms else round(kern_ms, 4), "flop_per_launch": flops,
+                     "traffic": pmc.get("attn_split", {}).get("traffic_bytes_per_launch") if split else None}
+        if g_ach is not None:
+            roof = {"bound": "mfma", "kernel": "gemm_kernel<320,split> (hipie_gemm, HL8 operands: the ViT qkv / proj / fc1 / fc2 linears, %d launches "
+                                               "timed)" % g_n,
+                    "achieved": round(g_ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(g_ach / 2500.0, 4),
+                    "mfma_flops_per_algorithmic_flop": 3.0, "frac_mfma_issued": round(3.0 * g_ach / 2500.0, 4),
+                    "note": "achieved = ALGORITHMIC flops (2 M N K) / time; the fp32-class product costs three fp16 MFMAs, so a frac of 1/3 "
+                            "would be the matrix pipe saturated; peak = dense fp16 MFMA (gfx950 has no faster exact-fp32 path: fp32 MFMA "
+                            "peaks at 157 TFLOP/s)",
+                    "avg_launch_ms": round(g_ms / g_n, 4), "flop_per_launch": g_flop / g_n,
+                    "per_shape_ms": {t: round(gemm[t][0], 4) for t in shapes if gemm.get(t, (None, 0))[0]},
+                    "traffic": pmc.get("gemm_qkv_split", {}).get("traffic_bytes_per_launch"),
+                    "traffic_note": "bytes per launch of the qkv shape (0.85 ms), rocprofv3 PMC FETCH_SIZE (x2, guide correction) + WRITE_SIZE, "
+                                    "separate passes: profiles/r03_pmc.md"}
+        else:
+            roof = roof_attn
         line = {
             "metric": "images/sec @%dx%d %s bs=%d (single-image inference hot path: box, class and mask logits)"
                       % (args.size, args.size, {"vit_huge": "ViT-H", "vit_large": "ViT-L", "vit_base": "ViT-B", "r50": "R50"}[args.model], args.batch),
             "value": round(images / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fast": "f16", "parity": "f32+f16attn", "bf16": "bf16", "default": "bf16+f32head"}[args.precision],
+            "dtype": {"split": "f16x3 (split-fp16 operands, fp32 accumulate: fp32-class)", "fast": "f16", "parity": "f32+f16attn", "bf16": "bf16",
+                      "default": "bf16+f32head"}[args.precision],
             "data": "synthetic (uint8-valued random images resident in HBM, synthetic BERT token ids, random-init weights)",
             "config": {"workload": "BASELINE.json configs[%s]: %s, %dx%d, batch %d per GPU, %d class prompts (L=%d), detection"
-                                   % ({80: "1" if args.model == "r50" else "2", 150: "3", 1203: "4"}.get(n_classes, "-"),
+                                   % ({80: "1" if args.model == "r50" else ("2" if world == 1 else "3 (global batch, 80-class prompt)"), 150: "3",
+                                       1203: "4"}.get(n_classes, "-"),
                                       args.model, args.size, args.size, args.batch, n_classes, L),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "precision_policy": args.precision,
                        "launch": "hipGraph replay" if graph is not None else "eager",
                        "constants": "weight- and geometry-only tensors (rel-pos tables, position embeddings, valid ratios) are "
                                     "built once; nothing that depends on image or text content is cached"},
-            "roofline": {"bound": "mfma", "kernel": "%s<%s,hd%d,%s,8 waves,in-kernel rel-pos bias> (ViT global attention, %d launches timed)"
-                                                    % (("vit_attn_sp_kernel", "vit_attn_kernel")[args.size // 16 > 64], str(prec.attn).split(".")[-1],
-                                                       cfg.vit_embed_dim // cfg.vit_heads, ("NB2", "NB3")[args.size // 16 > 64], kern_n),
-                         "achieved": None if ach is None else round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": None if ach is None else round(ach / 2500.0, 4), "traffic": traffic,
-                         "traffic_note": "bytes per launch, rocprofv3 PMC FETCH_SIZE (x2, guide correction) + WRITE_SIZE, separate passes: profiles/r02_pmc.md",
-                         "avg_launch_ms": None if not kern_ms else round(kern_ms, 4),
-                         "flop_per_launch": flops},
+            "dp": dp,
+            "roofline": roof,
+            "roofline_attention": roof_attn,
             "postprocess_full_ms": None if post_ms is None else round(post_ms, 2),
             "parity_err": parity_err,
-            "parity_policy": other,
+            "fast_policy": other,
         }
         if not args.no_cpu_baseline and world == 1 and args.model != "r50" and args.classes == 80:   # rank 0 at N = 1 only (bounded ~20 s CPU sample)
             import subprocess

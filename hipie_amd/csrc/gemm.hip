@@ -28,6 +28,8 @@
 //     the workgroups resident on an XCD share a few A row panels and the W panels through that XCD's L2.
 // Epilogue (runtime switches, once per tile): * alpha, + bias, exact-erf GELU | ReLU, + fp32 residual, then the output as
 // fp32, fp16 or HL8 (optionally scaled) -- the HL8 form is directly the A operand of the next GEMM.
+#include <stdlib.h>
+
 #include "common.h"
 #include "mfma.h"
 
@@ -72,7 +74,7 @@ __device__ __forceinline__ unsigned int gm_pack2h(f16_t a, f16_t b) {
   return __builtin_bit_cast(unsigned int, v);
 }
 
-template <int BN, bool SPLIT>
+template <int BN, bool SPLIT, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
   constexpr int BM = 256;
   constexpr int ROWS = BM + BN;                // rows of one LDS stage: the A tile then the W tile
@@ -167,8 +169,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
     };
     load_x(0);
     load_w(0);
-    constexpr int EVERY = (SUB >= 2 * NI) ? 2 : 1;
-    static_assert(SUB / EVERY >= NI, "every DMA instruction of a stage needs a sub-step slot");
+    // DMA plan: the instructions of stage t + 1 are issued in the FIRST sub-steps of stage t, PER sub-step as many as it takes to be
+    // done by sub-step DMA_BY: a fill needs 1-2 us from issue to landing and the stage ends with vmcnt(0), so a late issue stalls
+    // every wave at the barrier (measured: one DMA per sub-step over the whole stage cost ~15 % of the split kernel's rate)
+    constexpr int DMA_BY = VAR == 1 ? SUB : VAR == 2 ? 2 : VAR == 3 ? 3 : (SPLIT ? 4 : 6);      // sub-steps that carry DMA instructions
+    constexpr int PER = (NI + DMA_BY - 1) / DMA_BY;
 #pragma unroll
     for (int s = 0; s < SUB; ++s) {
       const int ks = s / NJ, j = s % NJ;
@@ -188,8 +193,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
       }
       acc[j][0] = Mfma32<f16_t>::mma(wh, xh0, acc[j][0]);
       acc[j][1] = Mfma32<f16_t>::mma(wh, xh1, acc[j][1]);
-      // the DMA instructions of the next stage, spread over the sub-steps (a burst blocks the wave's in-order issue)
-      if (more && (s % EVERY) == EVERY - 1 && s / EVERY < NI) dma(s / EVERY, kt + 1, st ^ 1);
+      if (more) {
+#pragma unroll
+        for (int i = s * PER; i < (s + 1) * PER && i < NI; ++i) dma(i, kt + 1, st ^ 1);
+      }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's DMA writes of stage t+1 have landed
     __syncthreads();                          // ... and everybody's; all reads of stage t are done
@@ -280,12 +287,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
   }
 }
 
-template <int BN, bool SPLIT>
+template <int BN, bool SPLIT, int VAR = 0>
 static int launch_gemm(GemmParams& p, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * (256 + BN) * 128;
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + BN - 1) / BN;
-  auto kern = gemm_kernel<BN, SPLIT>;
+  auto kern = gemm_kernel<BN, SPLIT, VAR>;
   static bool lds_set[64] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -351,6 +358,12 @@ extern "C" int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw
   p.out_fmt = out_fmt; p.act = act; p.alpha = alpha; p.oscale = oscale;
   hipStream_t st = (hipStream_t)stream;
   const bool wide = (N % 320 == 0);
+#ifdef HIPIE_GEMM_VARIANTS
+  { const char* e = getenv("HIPIE_GEMM_VARIANT"); const int v = e ? atoi(e) : 0;
+    if (split && wide && v == 1) return launch_gemm<320, true, 1>(p, st);
+    if (split && wide && v == 2) return launch_gemm<320, true, 2>(p, st);
+    if (split && wide && v == 3) return launch_gemm<320, true, 3>(p, st); }
+#endif
   if (split) return wide ? launch_gemm<320, true>(p, st) : launch_gemm<256, true>(p, st);
   return wide ? launch_gemm<320, false>(p, st) : launch_gemm<256, false>(p, st);
 }

@@ -40,7 +40,7 @@ def register(precision=None, md_cfg_loader=load_maskdino_cfg):
     except ImportError:
         TRANSFORMER_DECODER_REGISTRY = Registry("TRANSFORMER_MODULE")
     msda_shim.install()
-    prec = precision or Precision.fast()
+    prec = precision or Precision.split3()       # the in-tolerance policy (1e-3 at the shipped depths); Precision.fast() is opt-in
 
     def hcfg(cfg):
         return HipieConfig.from_yacs(cfg, md_cfg_loader(cfg))       # errors of the MaskDINO yaml propagate

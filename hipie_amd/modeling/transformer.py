@@ -50,11 +50,11 @@ class PLinear(nn.Linear):
             return ops.split_linear(x, self, "w", self.weight, self.bias, out_fmt=out_fmt, x_hl8=x_hl8)
         return F.linear(x.to(self.weight.dtype), self.weight, self.bias).to(self.out_dtype)
 
-    def forward_relu(self, x, out_fmt=ops.F32):
+    def forward_relu(self, x, out_fmt=ops.F32, x_hl8=False):
         """relu(linear(x)) with the ReLU in the GEMM's epilogue (exact: ReLU commutes with the output rounding);
         removes one read+write of the (tokens, d_ffn) hidden tensor per FFN."""
         if self.split and x.is_cuda and self.weight.dtype == torch.float32 and ops.split_ok(self.in_features):
-            return ops.split_linear(x, self, "w", self.weight, self.bias, act=ops.ACT_RELU, out_fmt=out_fmt)
+            return ops.split_linear(x, self, "w", self.weight, self.bias, act=ops.ACT_RELU, out_fmt=out_fmt, x_hl8=x_hl8)
         x = x.to(self.weight.dtype)
         if x.is_cuda and self.bias is not None:
             y = torch._addmm_activation(self.bias, x.reshape(-1, x.shape[-1]), self.weight.t(), use_gelu=False)
@@ -295,10 +295,10 @@ class MSDeformAttn(nn.Module):
         self.output_proj = PLinear(d_model, d_model)
         self.value_dtype = value_dtype
 
-    def project_value(self, input_flatten, input_padding_mask=None):
+    def project_value(self, input_flatten, input_padding_mask=None, x_hl8=False):
         N, S, _ = input_flatten.shape
         vp = self.value_proj                       # GEMM output stays in the weight dtype: no fp32 round trip, mask in place
-        value = _lin(vp, "w", input_flatten, vp.weight, vp.bias)
+        value = _lin(vp, "w", input_flatten, vp.weight, vp.bias, x_hl8=x_hl8)
         if input_padding_mask is not None:
             value.masked_fill_(input_padding_mask[..., None], 0.0)
         return value.to(self.value_dtype).view(N, S, self.n_heads, self.d_model // self.n_heads)
@@ -320,12 +320,12 @@ class MSDeformAttn(nn.Module):
                              reference_points.float().contiguous(), off, logits)
         return self.output_proj(out)
 
-    def forward_projected(self, query, reference_points, value, input_spatial_shapes, input_level_start_index):
+    def forward_projected(self, query, reference_points, value, input_spatial_shapes, input_level_start_index, x_hl8=False):
         """forward with the value projection done by the caller (one GEMM for all decoder layers): `value` (N, S, heads, hd),
         dense or a column block of the batched projection (sampled in place through its row stride)."""
         w, b = self._fused_proj()
         no = self.n_heads * self.n_levels * self.n_points * 2
-        proj = _lin(self, "offlog", query, w, b)
+        proj = _lin(self, "offlog", query, w, b, x_hl8=x_hl8)
         off = proj[..., :no].unflatten(-1, (self.n_heads, self.n_levels, self.n_points, 2))
         logits = proj[..., no:].unflatten(-1, (self.n_heads, self.n_levels * self.n_points))
         out = ops.msda_fused(value, input_spatial_shapes, input_level_start_index, reference_points.float().contiguous(), off, logits)
@@ -433,6 +433,8 @@ class DeformableTransformerEncoderLayer(nn.Module):
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None, query=None, want_query=False):
         """query: `src + pos` when the previous layer already produced it; want_query: also return the NEXT layer's `src + pos`,
         emitted by the last LayerNorm pass (hipie_add_layernorm_sum) instead of a separate add over the 21760-token stream."""
+        if getattr(self, "split", False) and src.is_cuda and src.dtype == torch.float32 and self.linear1.weight.dtype == torch.float32:
+            return self._forward_split(src, pos, reference_points, spatial_shapes, level_start_index, padding_mask, query, want_query)
         q = src + pos if query is None else query
         src2 = self.self_attn(q, reference_points, src, spatial_shapes, level_start_index, padding_mask)
         src = _add_norm(src, src2, self.norm1)
@@ -442,6 +444,35 @@ class DeformableTransformerEncoderLayer(nn.Module):
             return ops.add_layernorm_sum(src.contiguous(), src2.to(src.dtype).contiguous(), n.weight, n.bias, n.eps, pos.contiguous())
         out = _add_norm(src, src2, self.norm2)
         return (out, None) if want_query else out
+
+
+def _enc_layer_forward_split(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask, carry, want_query):
+    """the encoder layer of the split policy (Precision.split3): every linear is the three-product GEMM and takes its operand as
+    HL8 straight from the pass that produced it -- the post-norm LayerNorm passes emit the fp32 stream, its HL8 copy and (for the
+    next layer's query) `src + pos` as HL8 in ONE launch (hipie_add_layernorm_dec), linear1 writes relu(.) as HL8 for linear2; only
+    the deformable-attention output is converted by hipie_to_hl8.  ``carry``: {"src_h", "q_h"} from the previous layer, or None."""
+    attn = self.self_attn
+    src = src.contiguous()
+    if isinstance(carry, dict):
+        src_h, q_h = carry["src_h"], carry["q_h"]
+    else:
+        src_h, q_h = ops.to_hl8(src), ops.to_hl8(src + pos if carry is None else carry)
+    value = attn.project_value(src_h, padding_mask, x_hl8=True)
+    src2 = attn.forward_projected(q_h, reference_points, value.contiguous(), spatial_shapes, level_start_index, x_hl8=True)
+    n = self.norm1
+    src, s_h, _ = ops.add_layernorm_dec(src, src2.contiguous(), n.weight, n.bias, n.eps, "hl8", want16=True)
+    src2 = self.linear2(self.linear1.forward_relu(s_h, out_fmt=ops.HL8, x_hl8=True), x_hl8=True)
+    n = self.norm2
+    if not want_query:
+        return ops.add_layernorm_dec(src, src2, n.weight, n.bias, n.eps, "hl8")[0]
+    key = (pos.data_ptr(), pos._version, tuple(pos.shape))
+    if getattr(self, "_pos_h_key", None) != key:            # the position embedding is a per-geometry constant
+        self._pos_h, self._pos_h_key = ops.to_hl8(pos.contiguous()), key
+    out, o_h, q_h = ops.add_layernorm_dec(src, src2, n.weight, n.bias, n.eps, "hl8", want16=True, addend=self._pos_h)
+    return out, {"src_h": o_h, "q_h": q_h}
+
+
+DeformableTransformerEncoderLayer._forward_split = _enc_layer_forward_split
 
 
 def encoder_reference_points(spatial_shapes, valid_ratios, device):

@@ -82,6 +82,29 @@ def all_gather_predictions(block):
     return out if block.dtype == torch.float32 else out.view(block.dtype)
 
 
+def live_ranks(device):
+    """number of ranks that actually take part in the process group's collectives: an all-reduce (sum) of ones over the backend
+    in use (RCCL for "nccl").  1 without a process group.  bench.py reports it next to the gathered block's shape."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 1
+    t = torch.ones(1, dtype=torch.float32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(round(float(t.item())))
+
+
+def backend_name():
+    return dist.get_backend() if dist.is_initialized() else None
+
+
+def dp_evidence(gathered, per_rank, rank, world, device):
+    """what bench.py prints about the data-parallel step: `rccl_ranks` = the ranks the process group's collectives really see (an
+    all-reduce of ones; RCCL when the backend is "nccl"), the backend, the global batch and this rank's contiguous shard of it
+    (shard_range), and the shape of the block every rank holds after the all-gather."""
+    shard = shard_range(per_rank * world, rank, world)
+    return {"rccl_ranks": live_ranks(device), "backend": backend_name(), "global_images": per_rank * world,
+            "shard_of_this_rank": [shard.start, shard.stop], "gathered_block_shape": None if gathered is None else list(gathered.shape)}
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

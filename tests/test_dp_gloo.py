@@ -37,8 +37,9 @@ def _worker(rank, world, port, total, q):
     out = parallel.all_gather_predictions(block)
     maps = parallel.all_gather_predictions(parallel.compact_maps(results, (2, 2), stride=4))
     t = parallel.max_over_ranks(1.0 + r, torch.device("cpu"))
+    dp = parallel.dp_evidence(out, n_local, r, w, torch.device("cpu"))      # what bench.py --gpus N prints as "dp"
     parallel.barrier()
-    q.put((r, idx, out.tolist(), t, maps.tolist()))     # plain lists: no shared-memory handles across process exit
+    q.put((r, idx, out.tolist(), t, maps.tolist(), dp))     # plain lists: no shared-memory handles across process exit
 
 
 def test_two_rank_shard_and_gather():
@@ -68,6 +69,12 @@ def test_two_rank_shard_and_gather():
     assert (maps[img3, 0] == 0).all() and (maps[img3, 1] == 4).all()        # class 3 % 3, panoptic id 3 + 1
     pad = [i for i in range(8) if full[i, 0, 5] == -1][0]
     assert (maps[pad] == -1).all()                                          # the padded slot carries no maps
+    # the self-evidence fields of bench.py's N > 1 line: ranks seen by an all-reduce of ones, and the gathered block's shape
+    for r in (0, 1):
+        dp = got[r][5]
+        assert dp["rccl_ranks"] == 2 and dp["backend"] == "gloo" and dp["global_images"] == 8
+        assert dp["gathered_block_shape"] == [8, 5, 7]
+    assert got[0][5]["shard_of_this_rank"] == [0, 4] and got[1][5]["shard_of_this_rank"] == [4, 8]
 
 
 def test_shard_range_covers_everything():

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""hipie_vit_attn_split at the bench geometry (B=8, 64x64 tokens, 16 heads x 80) and the windowed form (200 windows of 14x14)."""
+import sys
+import torch
+sys.path.insert(0, ".")
+from hipie_amd import ops  # noqa: E402
+B, H, W, heads, hd = 8, 64, 64, 16, 80
+C = heads * hd
+
+
+def bench(fn, n=10):
+    for _ in range(2):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+qkv = ops.to_hl8(torch.randn(B, H * W, 3 * C, device="cuda") * 0.8)
+th, tw = ops.hl8_pack(torch.randn(2 * H - 1, hd) * 0.2).cuda(), ops.hl8_pack(torch.randn(2 * W - 1, hd) * 0.2).cuda()
+t = bench(lambda: ops.vit_attn_split(qkv, th, tw, (H, W), heads))
+gf = 4.0 * (H * W) ** 2 * C * B / 1e9
+print("global 64x64 B=8: %.3f ms  %.0f TFLOP/s algorithmic, %.0f MFMA-issued (QK x3, PV x2)" % (t, gf / t, 2.5 * gf / t))
+q2 = ops.to_hl8(torch.randn(200, 196, 3 * C, device="cuda") * 0.8)
+t2h, t2w = ops.hl8_pack(torch.randn(27, hd) * 0.2).cuda(), ops.hl8_pack(torch.randn(27, hd) * 0.2).cuda()
+t2 = bench(lambda: ops.vit_attn_split(q2, t2h, t2w, (14, 14), heads))
+print("windows 14x14 x200: %.3f ms  %.0f TFLOP/s algorithmic" % (t2, 4.0 * 196 * 196 * C * 200 / 1e9 / t2))

@@ -16,7 +16,8 @@ def main():
     torch.set_grad_enabled(False)
     dev = torch.device("cuda", 0)
     cfg = HipieConfig.vit_huge()
-    model = HIPIE_IMG(cfg, Precision.fast(), device=dev)
+    pol = sys.argv[1] if len(sys.argv) > 1 else "split3"
+    model = HIPIE_IMG(cfg, getattr(Precision, pol)(), device=dev)
     bench.randomize_degenerate_inits(model)
     model.finalize()
     batch = bench.synth_batch(cfg, 8, 1024, 80, 194, dev)
@@ -62,8 +63,15 @@ def main():
     t1.record()
     torch.cuda.synchronize()
     os.makedirs("gpurun_out", exist_ok=True)
+    from hipie_amd import ops
+    ops.PROFILE.enable("all")
+    model.forward_raw(batch)
+    prof = ops.PROFILE.summary()
+    ops.PROFILE.disable()
     with open("gpurun_out/stage_times.txt", "w") as f:
-        f.write("forward_raw %.2f ms (mean of %d, with hooks)\n" % (t0.elapsed_time(t1) / n, n))
+        f.write("policy %s: forward_raw %.2f ms (mean of %d, with hooks)\n" % (pol, t0.elapsed_time(t1) / n, n))
+        for tag, (mean, cnt, tot) in sorted(prof.items(), key=lambda kv: -kv[1][2]):
+            f.write("   kernel class %-18s n=%4d mean=%8.3f ms total=%8.2f ms\n" % (tag, cnt, mean, tot))
         for k, v in rec.items():
             f.write("%-40s %8.2f ms  (%d calls / forward)\n" % (k, sum(a.elapsed_time(b) for a, b in v) / n, len(v) // n))
     print(open("gpurun_out/stage_times.txt").read())
