@@ -37,6 +37,7 @@ namespace hipie {
 
 struct GemmParams {
   const char* A; const char* W; const float* bias; const float* resid; char* out;
+  const int32_t* out_row;     // optional: row m of the product goes to output / residual row out_row[m] (< 0: dropped) -- window un-partition
   long lda_b, ldw_b;          // row strides of A / W in BYTES
   long ldr, ldo;              // row strides of resid (fp32 elements) / out (elements of the output format: fp32 | fp16; HL8: fp16 elements)
   int M, N, K;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
     // DMA plan: the instructions of stage t + 1 are issued in the FIRST sub-steps of stage t, PER sub-step as many as it takes to be
     // done by sub-step DMA_BY: a fill needs 1-2 us from issue to landing and the stage ends with vmcnt(0), so a late issue stalls
     // every wave at the barrier (measured: one DMA per sub-step over the whole stage cost ~15 % of the split kernel's rate)
-    constexpr int DMA_BY = VAR == 1 ? SUB : VAR == 2 ? 2 : VAR == 3 ? 3 : (SPLIT ? 4 : 6);      // sub-steps that carry DMA instructions
+    constexpr int DMA_BY = SPLIT ? 4 : 6;                        // sub-steps that carry DMA instructions
     constexpr int PER = (NI + DMA_BY - 1) / DMA_BY;
 #pragma unroll
     for (int s = 0; s < SUB; ++s) {
@@ -204,6 +205,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
 
   // ---- epilogue: lane = token (column of the MFMA tile), registers = features ----
   const bool has_res = p.resid != nullptr;
+#ifdef HIPIE_GEMM_VARIANTS
+  if (VAR == 1 && p.alpha != 12345.f) return;        // timing experiment: no epilogue at all (tools/bench_gemm2.py variants)
+#endif
   const int act = p.act, ofmt = p.out_fmt;
   const float alpha = p.alpha, osc = p.oscale;
   // the tile's bias values go through LDS once (the stage buffers are free after the last barrier): the per-quad bias reads are then
@@ -213,19 +217,25 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
   __syncthreads();
   // residual rows: the four quads of block (t, j + 1) are requested before block (t, j) is processed
   float4 rq[2][4];
-  auto load_res = [&](const int t, const int j, float4 (&dst)[4]) {
+  // output row of this lane's two tokens (identity, or the caller's row map: -1 drops the row)
+  long orow[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
     const int m = m0 + wm * 64 + t * 32 + li;
+    orow[t] = (m < p.M) ? (p.out_row != nullptr ? (long)p.out_row[m] : (long)m) : -1;
+  }
+  auto load_res = [&](const int t, const int j, float4 (&dst)[4]) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int n = n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * hi;
-      dst[g] = (has_res && m < p.M && n < p.N) ? *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dst[g] = (has_res && orow[t] >= 0 && n < p.N) ? *reinterpret_cast<const float4*>(p.resid + orow[t] * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   load_res(0, 0, rq[0]);
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const int m = m0 + wm * 64 + t * 32 + li;
-    const bool mok = m < p.M;
+    const long m = orow[t];
+    const bool mok = m >= 0;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int blk = t * NJ + j;
@@ -245,43 +255,46 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
           v[g][e] = (x + rr[e]) * osc;
         }
       }
-      if (ofmt == HIPIE_F32) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int n = nb + 8 * g + 4 * hi;
-          if (mok && n < p.N)
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.out) + (long)m * p.ldo + n) = make_float4(v[g][0], v[g][1], v[g][2], v[g][3]);
-        }
-      } else if (ofmt == HIPIE_F16) {
+      typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      if (ofmt == HIPIE_F16) {
         // quads g and g + 1 of the two lane halves are exchanged so that the lower half stores features 8g .. 8g+7 and the upper
         // half 8(g+1) .. 8(g+1)+7 as ONE 16-byte piece each
 #pragma unroll
         for (int g = 0; g < 4; g += 2) {
-          typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-          typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
           const u32x2 s0 = __builtin_amdgcn_permlane32_swap(gm_pack2(v[g][0], v[g][1]), gm_pack2(v[g + 1][0], v[g + 1][1]), false, false);
           const u32x2 s1 = __builtin_amdgcn_permlane32_swap(gm_pack2(v[g][2], v[g][3]), gm_pack2(v[g + 1][2], v[g + 1][3]), false, false);
           const int n = nb + 8 * (g + hi);
           if (mok && n < p.N)
-            *reinterpret_cast<u32x4*>(reinterpret_cast<f16_t*>(p.out) + (long)m * p.ldo + n) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+            *reinterpret_cast<u32x4*>(reinterpret_cast<f16_t*>(p.out) + m * p.ldo + n) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
         }
-      } else {   // HIPIE_HL8: group of 8 features = 16 B of hi values then 16 B of lo values; the lower lane half ends up with all 8
-                 // hi values, the upper half with all 8 lo values
+      } else {
+        // fp32 and HL8: the block's 32 features are a 128-byte span of the output row, of which this lane holds the four 16-byte
+        // pieces at byte 32 g + 16 hi (fp32: features 8g+4hi ..+3; HL8: the lower lane half ends up with the 8 hi values of group g,
+        // the upper half with its 8 lo values).
+        u32x4 piece[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-          typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-          f16_t h[4], l[4];
+          if (ofmt == HIPIE_F32) {
+            piece[g] = (u32x4){__builtin_bit_cast(unsigned int, v[g][0]), __builtin_bit_cast(unsigned int, v[g][1]),
+                               __builtin_bit_cast(unsigned int, v[g][2]), __builtin_bit_cast(unsigned int, v[g][3])};
+          } else {
+            f16_t h[4], l[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) hl_split(v[g][e], h[e], l[e]);
-          const unsigned int H0 = gm_pack2h(h[0], h[1]), H1 = gm_pack2h(h[2], h[3]);
-          const unsigned int L0 = gm_pack2h(l[0], l[1]), L1 = gm_pack2h(l[2], l[3]);
-          const u32x2 s0 = __builtin_amdgcn_permlane32_swap(H0, L0, false, false);    // lower: (H0 own, H0 of upper); upper: (L0 of lower, L0 own)
-          const u32x2 s1 = __builtin_amdgcn_permlane32_swap(H1, L1, false, false);
-          const int n = nb + 8 * g;
-          if (mok && n < p.N)
-            *reinterpret_cast<u32x4*>(reinterpret_cast<f16_t*>(p.out) + (long)m * p.ldo + 2 * n + 8 * hi) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+            for (int e = 0; e < 4; ++e) hl_split(v[g][e], h[e], l[e]);
+            const unsigned int H0 = gm_pack2h(h[0], h[1]), H1 = gm_pack2h(h[2], h[3]);
+            const unsigned int L0 = gm_pack2h(l[0], l[1]), L1 = gm_pack2h(l[2], l[3]);
+            const u32x2 s0 = __builtin_amdgcn_permlane32_swap(H0, L0, false, false);    // lower: (H0 own, H0 of upper); upper: (L0 of lower, L0 own)
+            const u32x2 s1 = __builtin_amdgcn_permlane32_swap(H1, L1, false, false);
+            piece[g] = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+          }
         }
+        // one store per piece: 32 rows x 32 bytes per instruction.  (Staging the pieces through LDS so that every store instruction
+        // writes 8 whole 128-byte lines measured 3 % SLOWER: the epilogue is bound by the HBM write rate of the burst -- all CUs finish
+        // their tiles together and write 84 MB at ~4 TB/s -- not by the number of line requests; tools/bench_gemm2.py)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (mok && nb + 8 * g < p.N) *reinterpret_cast<u32x4*>(p.out + (m * p.ldo) * (ofmt == HIPIE_F32 ? 4 : 2) + (long)nb * 4 + 32 * g + 16 * hi) = piece[g];
       }
     }
   }
@@ -332,8 +345,8 @@ __global__ __launch_bounds__(256) void to_hl8_kernel(const T* __restrict__ x, f1
 using namespace hipie;
 
 extern "C" int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* resid, int64_t ldr,
-                          void* out, int64_t ldo, int M, int N, int K, int in_fmt, int out_fmt, int act, float alpha, float oscale,
-                          void* stream) {
+                          void* out, int64_t ldo, const int32_t* out_row, int M, int N, int K, int in_fmt, int out_fmt, int act, float alpha,
+                          float oscale, void* stream) {
   HIPIE_REQUIRE(A && W && out, "gemm: null pointer");
   HIPIE_REQUIRE(in_fmt == HIPIE_F16 || in_fmt == HIPIE_HL8, "gemm: operand format %d (HIPIE_F16 | HIPIE_HL8)", in_fmt);
   HIPIE_REQUIRE(out_fmt == HIPIE_F32 || out_fmt == HIPIE_F16 || out_fmt == HIPIE_HL8, "gemm: output format %d", out_fmt);
@@ -352,7 +365,7 @@ extern "C" int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw
   HIPIE_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
                 ((uintptr_t)bias % 16) == 0 && ((uintptr_t)resid % 16) == 0, "gemm: pointers must be 16-byte aligned");
   GemmParams p;
-  p.A = (const char*)A; p.W = (const char*)W; p.bias = bias; p.resid = resid; p.out = (char*)out;
+  p.A = (const char*)A; p.W = (const char*)W; p.bias = bias; p.resid = resid; p.out = (char*)out; p.out_row = out_row;
   p.lda_b = lda * 2; p.ldw_b = ldw * 2; p.ldr = ldr; p.ldo = ldo;
   p.M = M; p.N = N; p.K = K; p.nkt = K / kq;
   p.out_fmt = out_fmt; p.act = act; p.alpha = alpha; p.oscale = oscale;
@@ -360,9 +373,7 @@ extern "C" int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw
   const bool wide = (N % 320 == 0);
 #ifdef HIPIE_GEMM_VARIANTS
   { const char* e = getenv("HIPIE_GEMM_VARIANT"); const int v = e ? atoi(e) : 0;
-    if (split && wide && v == 1) return launch_gemm<320, true, 1>(p, st);
-    if (split && wide && v == 2) return launch_gemm<320, true, 2>(p, st);
-    if (split && wide && v == 3) return launch_gemm<320, true, 3>(p, st); }
+    if (split && wide && v == 1) return launch_gemm<320, true, 1>(p, st); }
 #endif
   if (split) return wide ? launch_gemm<320, true>(p, st) : launch_gemm<256, true>(p, st);
   return wide ? launch_gemm<320, false>(p, st) : launch_gemm<256, false>(p, st);

@@ -141,10 +141,12 @@ class Attention(nn.Module):
             o = ops.vit_attn(qkv16, rel_h, rel_w, (H, W), nh, self.scale)
         return self.proj(o.to(x.dtype)).view(B, H, W, C)
 
-    def forward_split(self, y, B, H, W):
-        """the split policy: y (B*H*W, 2C) HL8 (LayerNorm output) -> (B*H*W, C) fp32 = proj(attention(qkv(y))).  qkv leaves its GEMM
-        as HL8 (q rows pre-scaled, fold cached per parameter version), the attention forms logits and bias from both halves of
-        both operands (hipie_vit_attn_split) and writes HL8, which the projection GEMM consumes."""
+    def forward_split(self, y, B, H, W, resid, out_row=None):
+        """the split policy: y (B*H*W, 2C) HL8 (LayerNorm output) -> resid + proj(attention(qkv(y))), written IN PLACE into the fp32
+        residual stream ``resid`` (rows, C).  qkv leaves its GEMM as HL8 (q rows pre-scaled, fold cached per parameter version), the
+        attention forms logits and bias from both halves of both operands (hipie_vit_attn_split) and writes HL8, which the projection
+        GEMM consumes; its epilogue adds the residual and -- for the windowed blocks -- stores through ``out_row`` (window row ->
+        token row, -1 for the padding): window_unpartition costs no pass."""
         C = self.qkv.weight.shape[1]
         nh = self.num_heads
         c1 = self.scale * ops.LOG2E
@@ -166,7 +168,8 @@ class Attention(nn.Module):
                           ops.hl8_pack(resize_rel_pos(W, self.rel_pos_w.detach().float()) / self.scale))
             self._tabs_key = key
         o = ops.vit_attn_split(qkv.view(B, H * W, 6 * C), self._tabs[0], self._tabs[1], (H, W), nh)
-        return ops.split_linear(o.view(B * H * W, 2 * C), self, "proj", self.proj.weight, self.proj.bias, x_hl8=True, tag="gemm_proj")
+        return ops.split_linear(o.view(B * H * W, 2 * C), self, "proj", self.proj.weight, self.proj.bias, x_hl8=True, tag="gemm_proj",
+                                resid=resid, out=resid, out_row=out_row)
 
     def _versions(self):
         ps = (self.qkv.weight, self.qkv.bias, self.rel_pos_h, self.rel_pos_w)
@@ -215,10 +218,11 @@ class Mlp(nn.Module):
     def forward(self, x):
         return self.fc2(self.act(self.fc1(x)))
 
-    def forward_split(self, h):
-        """h (rows, 2C) HL8 -> (rows, C) fp32: fc1 with the exact-erf GELU and the HL8 split in its epilogue, fc2 on that operand."""
+    def forward_split(self, h, resid):
+        """h (rows, 2C) HL8 -> resid + mlp(h), IN PLACE in the fp32 stream ``resid`` (rows, C): fc1 with the exact-erf GELU and the HL8
+        split in its epilogue, fc2 on that operand with the residual add in its epilogue."""
         mid = ops.split_linear(h, self, "fc1", self.fc1.weight, self.fc1.bias, act=ops.ACT_GELU, out_fmt=ops.HL8, x_hl8=True, tag="gemm_fc1")
-        return ops.split_linear(mid, self, "fc2", self.fc2.weight, self.fc2.bias, x_hl8=True, tag="gemm_fc2")
+        return ops.split_linear(mid, self, "fc2", self.fc2.weight, self.fc2.bias, x_hl8=True, tag="gemm_fc2", resid=resid, out=resid)
 
 
 class Block(nn.Module):
@@ -257,23 +261,29 @@ class Block(nn.Module):
 
 
 def _block_forward_split(self, x, delta):
-    """Block.forward of the split policy: the fused add + LayerNorm passes emit the GEMM operand as HL8, every linear is the
-    three-product GEMM, the window partition / un-partition are the row maps of the LayerNorm passes as in the 16-bit path."""
+    """Block.forward of the split policy.  The fp32 residual stream is updated IN PLACE by the epilogues of the projection and fc2
+    GEMMs (x += proj(attn), x += mlp), so each LayerNorm pass only reads the stream once and writes the next GEMM operand as HL8;
+    window partition = the row map of the first LayerNorm pass, window un-partition = the store index of the projection GEMM."""
     B, H, W, C = x.shape
     ws = self.window_size
     n1, n2 = self.norm1, self.norm2
+    if delta is not None:
+        x = x + delta
+    xs = x.view(B * H * W, C)
     if ws == 0:
-        x, y = ops.add_layernorm(x, delta, n1.weight, n1.bias, n1.eps, "hl8")
-        a = self.attn.forward_split(y.view(B * H * W, 2 * C), B, H, W)
-        x, h = ops.add_layernorm(x, a.view(B, H, W, C), n2.weight, n2.bias, n2.eps, "hl8")
-        return x, self.mlp.forward_split(h.view(B * H * W, 2 * C)).view(B, H, W, C)
-    if not ops.vit_attn_split_ok((ws, ws), C // self.attn.num_heads):
-        raise NotImplementedError("split policy: window size %d" % ws)
-    out_src, delta_row, nwin = window_row_maps(B, H, W, ws, x.device)
-    x, y = ops.add_layernorm(x, delta, n1.weight, n1.bias, n1.eps, "hl8", out_src=out_src)
-    a = self.attn.forward_split(y, nwin, ws, ws)
-    x, h = ops.add_layernorm(x, a, n2.weight, n2.bias, n2.eps, "hl8", delta_row=delta_row)
-    return x, self.mlp.forward_split(h.view(B * H * W, 2 * C)).view(B, H, W, C)
+        if not ops.vit_attn_split_ok((H, W), C // self.attn.num_heads):
+            raise NotImplementedError("split policy: global attention on a %dx%d token grid (supported: up to 64x64)" % (H, W))
+        y = ops.add_layernorm(x, None, n1.weight, n1.bias, n1.eps, "hl8")[1]
+        self.attn.forward_split(y.view(B * H * W, 2 * C), B, H, W, xs)
+    else:
+        if not ops.vit_attn_split_ok((ws, ws), C // self.attn.num_heads):
+            raise NotImplementedError("split policy: window size %d" % ws)
+        out_src, delta_row, nwin = window_row_maps(B, H, W, ws, x.device)
+        y = ops.add_layernorm(x, None, n1.weight, n1.bias, n1.eps, "hl8", out_src=out_src)[1]
+        self.attn.forward_split(y, nwin, ws, ws, xs, out_row=out_src)
+    h = ops.add_layernorm(x, None, n2.weight, n2.bias, n2.eps, "hl8")[1]
+    self.mlp.forward_split(h.view(B * H * W, 2 * C), xs)
+    return x, None
 
 
 Block._forward_split = _block_forward_split
@@ -311,7 +321,7 @@ class ViT(nn.Module):
         x, delta = x.contiguous(), None
         for blk in self.blocks:
             x, delta = blk(x, delta)
-        x = (x + delta.to(x.dtype)).to(ad)
+        x = (x if delta is None else x + delta.to(x.dtype)).to(ad)
         # fpn1: ConvTranspose2d(k=2, s=2) == one GEMM (E -> 4 * E/2, bias in the epilogue) + a pixel shuffle (vit.py:341-343).
         # The features leave in the activation dtype and in channels-last memory (logical NCHW): the 1x1 / 3x3 projections
         # that consume them run NHWC, so no layout or dtype copy sits between the backbone and the heads.

@@ -694,7 +694,8 @@ ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 
 @_timed(lambda a, w, *args, **kw: kw.get("tag", "gemm"))
-def gemm(a, w, bias=None, resid=None, out_fmt=F32, act=ACT_NONE, alpha=1.0, oscale=1.0, split=None, out=None, tag="gemm"):
+def gemm(a, w, bias=None, resid=None, out_fmt=F32, act=ACT_NONE, alpha=1.0, oscale=1.0, split=None, out=None, tag="gemm", out_row=None,
+         out_rows=None):
     """out = ((act(alpha * a . w^T + bias)) + resid) * oscale on hipie_gemm.
     a (..., K) fp16 and w (N, K) fp16 (one product), or both HL8: a (..., 2K), w (N, 2K) fp16 (three products, fp32-class);
     `split` tells which (default: inferred -- pass it when K is ambiguous).  a may be a row-strided 2-d view.  bias (N) f32,
@@ -711,6 +712,11 @@ def gemm(a, w, bias=None, resid=None, out_fmt=F32, act=ACT_NONE, alpha=1.0, osca
     if a2.stride(-1) != 1 or a2.shape[-1] != w.shape[1]:
         raise RuntimeError("gemm: a rows must be contiguous and as long as w rows (%s vs %s)" % (tuple(a.shape), tuple(w.shape)))
     M = a2.shape[0]
+    if out_row is not None:
+        if out is None:
+            lead = (int(out_rows),)
+        if out_row.dtype != torch.int32 or out_row.numel() != M or not out_row.is_contiguous():
+            raise RuntimeError("gemm: out_row must be a contiguous int32 vector with one entry per row of a")
     if out is None:
         if out_fmt == F32:
             out = torch.empty(*lead, N, dtype=torch.float32, device=a.device)
@@ -728,7 +734,7 @@ def gemm(a, w, bias=None, resid=None, out_fmt=F32, act=ACT_NONE, alpha=1.0, osca
         raise RuntimeError("gemm: bias must be contiguous fp32")
     rc = lib.hipie_gemm(a2.data_ptr(), a2.stride(0), _chk(w, "w"), w.shape[1], None if bias is None else bias.data_ptr(),
                         None if r2 is None else r2.data_ptr(), 0 if r2 is None else r2.stride(0), o2.data_ptr(), o2.stride(0),
-                        M, N, Kw, HL8 if split else F16, int(out_fmt), int(act), float(alpha), float(oscale), _stream())
+                        None if out_row is None else out_row.data_ptr(), M, N, Kw, HL8 if split else F16, int(out_fmt), int(act), float(alpha), float(oscale), _stream())
     _lib.check(rc, "hipie_gemm")
     return out
 
@@ -782,13 +788,17 @@ def split_ok(K):
 
 
 def split_linear(x, owner, key, weight, bias=None, act=ACT_NONE, out_fmt=F32, resid=None, x_hl8=False, weight_fn=None, bias_fn=None,
-                 tag="gemm", params=None):
+                 tag="gemm", params=None, out=None, out_row=None):
     """F.linear(x, weight, bias) at fp32-class accuracy on hipie_gemm's split operands.  x fp32 / fp16 (converted with hipie_to_hl8)
     or already HL8 (x_hl8).  weight_fn / bias_fn: derived weights (folded constants, concatenations) built once per parameter version."""
     if params is None:
         params = [weight] + ([bias] if bias is not None else [])
     w, b, N = split_weight(owner, key, params, weight_fn or (lambda: weight), bias_fn or ((lambda: bias) if bias is not None else None))
     a = x if x_hl8 else to_hl8(x if x.dtype in (torch.float32, torch.float16) else x.float())
+    if out is not None or out_row is not None:
+        if N != w.shape[0]:
+            raise RuntimeError("split_linear: in-place / row-mapped outputs need N % 8 == 0")
+        return gemm(a, w, b, resid, out_fmt=out_fmt, act=act, split=True, tag=tag, out=out, out_row=out_row)
     out = gemm(a, w, b, resid, out_fmt=out_fmt, act=act, split=True, tag=tag)
     if N != w.shape[0]:
         out = out[..., :(2 * N if out_fmt == HL8 else N)].contiguous()

@@ -372,12 +372,14 @@ int hipie_box_refine(const void* delta, const float* ref, float* out, int64_t n,
  *   bias     (N) f32 or NULL;   resid (M, N) f32 with row stride ldr, or NULL
  *   epilogue y = alpha * acc + bias;  act 1: exact-erf GELU(y), 2: ReLU(y);  y = (y + resid) * oscale
  *   out      (M, N) in out_fmt HIPIE_F32 | HIPIE_F16 | HIPIE_HL8 (row stride ldo in elements of that format; HL8: fp16 elements >= 2N):
- *            the HL8 form is directly the A operand of a following hipie_gemm.
+ *            the HL8 form is directly the A operand of a following hipie_gemm.  out may alias resid (in-place residual update).
+ *   out_row  (M) int32 or NULL: product row m is written to output row out_row[m] and takes its residual from resid row out_row[m];
+ *            negative entries are dropped -- window_unpartition (hipie/backbone/utils.py:40-60) as the store index of the projection.
  * All pointers 16-byte aligned.  Deterministic (fixed accumulation order).
  */
 int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* resid, int64_t ldr,
-               void* out, int64_t ldo, int M, int N, int K, int in_fmt, int out_fmt, int act, float alpha, float oscale,
-               void* stream);
+               void* out, int64_t ldo, const int32_t* out_row, int M, int N, int K, int in_fmt, int out_fmt, int act, float alpha,
+               float oscale, void* stream);
 
 /*
  * hipie_vit_attn_rel on SPLIT operands (fp32-class logits): qkv (B, gh*gw, 3, heads, hd) as HIPIE_HL8 rows (2 * 3 * heads * hd fp16

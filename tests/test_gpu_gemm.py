@@ -182,3 +182,26 @@ def test_gemm_rejects_bad_arguments():
     a2 = torch.zeros(8, 128, dtype=torch.float16, device="cuda")
     with pytest.raises(RuntimeError):
         ops.gemm(a2, w2, split=False)           # N = 12 is not a multiple of 8
+
+
+@gpu
+def test_gemm_row_map_and_in_place_residual():
+    """out_row: product row m lands in (and takes its residual from) row out_row[m], negative entries are dropped; out aliases the
+    residual (the ViT stream is updated in place; window_unpartition is the store index)."""
+    from hipie_amd import ops
+    from hipie_amd.modeling.vit import window_row_maps
+    g = torch.Generator(device="cuda").manual_seed(31)
+    B, H, W, C, ws = 2, 9, 9, 256, 7
+    out_src, delta_row, nwin = window_row_maps(B, H, W, ws, torch.device("cuda"))
+    M = nwin * ws * ws
+    a = torch.randn(M, C, device="cuda", generator=g)
+    w = torch.randn(C, C, device="cuda", generator=g) * C ** -0.5
+    bias = torch.randn(C, device="cuda", generator=g)
+    stream = torch.randn(B * H * W, C, device="cuda", generator=g)
+    want = stream.double().clone()
+    full = a.double() @ w.double().t() + bias.double()
+    valid = out_src >= 0
+    want[out_src[valid].long()] += full[valid]
+    got = stream.clone()
+    ops.gemm(ops.hl8_pack(a), ops.hl8_pack(w), bias, resid=got, out=got, out_row=out_src, split=True)
+    assert rel_err(got.cpu(), want.float().cpu()) < 3e-6
