@@ -50,7 +50,9 @@ template <> struct elem<f16_t> {
 // folds the multiply that PRODUCED x into a v_fma_mix*_f16 for one of its two uses (single rounding of the exact product) while the other
 // use converts the fp32-rounded product -- near an fp16 tie the stored hi and the hi the remainder was taken from then differ by one ulp
 // (measured: isolated 1-ulp(hi) errors in one output of 1e5).
+// Values beyond the fp16 range saturate at +-65504 (an overflowing hi would be inf and its remainder x - inf a NaN).
 __device__ __forceinline__ void hl_split(float x, f16_t& h, f16_t& l) {
+  x = __builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f);
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("" : "+v"(x));
 #endif

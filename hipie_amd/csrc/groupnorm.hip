@@ -6,6 +6,9 @@
 //   * output in the same layout, any of f32 / f16 / bf16.
 // Two launches: partial (sum, sum of squares) per (image, group, chunk) in fp32, then the apply pass, which first reduces the
 // partials of its groups (deterministic: no atomics).  HBM-bound: 2 reads + 1 write of the tensor.
+// The sums are SHIFTED: every value has K = (first value of its group, pre-bias included) subtracted before it is accumulated --
+// var = E[(a-K)^2] - (E[a-K])^2 is then free of the cancellation that E[a^2] - mean^2 suffers when |mean| >> std (real
+// convolution biases folded in as pre-bias), at the cost of one extra scalar load per block.
 #include "common.h"
 
 namespace hipie {
@@ -41,12 +44,13 @@ __global__ __launch_bounds__(256) void gn_stats_nhwc_kernel(const T* __restrict_
 #pragma unroll
   for (int i = 0; i < 8; ++i) pb[i] = prebias ? prebias[g * 8 + i] : 0.f;
   const int p1 = min(HW, (chunk + 1) * per);
+  const float K = (float)x[(long)b * HW * C + g * 8] + pb[0];          // the group's shift: its first value
   float s = 0.f, ss = 0.f;
   for (int p = chunk * per + pl; p < p1; p += npl) {
     float v[8];
     V8<T>::ld(x + ((long)b * HW + p) * C + g * 8, v);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { const float a = v[i] + pb[i]; s += a; ss = fmaf(a, a, ss); }
+    for (int i = 0; i < 8; ++i) { const float a = v[i] + pb[i] - K; s += a; ss = fmaf(a, a, ss); }
   }
   red[0][threadIdx.x] = s;
   red[1][threadIdx.x] = ss;
@@ -72,9 +76,10 @@ __global__ __launch_bounds__(256) void gn_apply_nhwc_kernel(const T* __restrict_
     const float* pp = part + ((long)b * G + threadIdx.x) * nchunk * 2;
     for (int k = 0; k < nchunk; ++k) { s += pp[2 * k]; ss += pp[2 * k + 1]; }
     const float n = (float)HW * GN_CPG;
-    const float mean = s / n;
-    stat[0][threadIdx.x] = mean;
-    stat[1][threadIdx.x] = rsqrtf(fmaxf(ss / n - mean * mean, 0.f) + eps);
+    const float ms = s / n;                                              // mean of the shifted values
+    const float K = (float)x[(long)b * HW * C + threadIdx.x * 8] + (prebias ? prebias[threadIdx.x * 8] : 0.f);
+    stat[0][threadIdx.x] = K + ms;
+    stat[1][threadIdx.x] = rsqrtf(fmaxf(ss / n - ms * ms, 0.f) + eps);
   }
   __syncthreads();
   const float mean = stat[0][g], rstd = stat[1][g];
@@ -105,12 +110,14 @@ __global__ __launch_bounds__(256) void gn_stats_nchw_kernel(const T* __restrict_
   const float pb = prebias ? prebias[c] : 0.f;
   const T* xp = x + (long)bc * HW;
   const int e1 = min(HW, (chunk + 1) * per);
+  const int c0 = (c / GN_CPG) * GN_CPG;                                  // the group's shift: the first value of its first channel
+  const float K = (float)x[((long)b * C + c0) * HW] + (prebias ? prebias[c0] : 0.f);
   float s = 0.f, ss = 0.f;
   for (int e = chunk * per + threadIdx.x * 8; e < e1; e += 256 * 8) {
     float v[8];
     V8<T>::ld(xp + e, v);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { const float a = v[i] + pb; s += a; ss = fmaf(a, a, ss); }
+    for (int i = 0; i < 8; ++i) { const float a = v[i] + pb - K; s += a; ss = fmaf(a, a, ss); }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
@@ -141,9 +148,11 @@ __global__ __launch_bounds__(256) void gn_apply_nchw_kernel(const T* __restrict_
     for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
     if (threadIdx.x == 0) {
       const float n = (float)HW * GN_CPG;
-      const float mean = s / n;
-      stat[0] = mean;
-      stat[1] = rsqrtf(fmaxf(ss / n - mean * mean, 0.f) + eps);
+      const float ms = s / n;
+      const int c0 = g * GN_CPG;
+      const float K = (float)x[((long)b * C + c0) * HW] + (prebias ? prebias[c0] : 0.f);
+      stat[0] = K + ms;
+      stat[1] = rsqrtf(fmaxf(ss / n - ms * ms, 0.f) + eps);
     }
   }
   __syncthreads();

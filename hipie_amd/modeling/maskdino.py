@@ -180,7 +180,12 @@ class MaskDINODecoder(nn.Module):
             if isinstance(mask_features, FoldedMaskFeatures):      # 16-bit features: 3 = single product, 4 = embedding split hi + lo
                 e32 = emb.float()
                 w, b = mask_features.weight.float(), mask_features.bias.float()
-                masks = ops.mask_einsum16(e32 @ w, mask_features.pre, split=self.precision.einsum == 4, row_bias=e32 @ b)
+                pre = mask_features.pre
+                if e32.shape[1] <= 320 and (pre.shape[-1] * pre.shape[-2]) % 8 == 0:
+                    masks = ops.mask_einsum16(e32 @ w, pre, split=self.precision.einsum == 4, row_bias=e32 @ b)
+                else:       # more queries than the 16-bit kernel's tile (or an odd pixel count): the fp32-feature kernel, bias added after
+                    masks = ops.mask_einsum((e32 @ w).contiguous(), pre.float().contiguous(), precision=1, out_dtype=self.precision.act)
+                    masks = masks + (e32 @ b).to(masks.dtype)[..., None, None]
             else:
                 masks = ops.mask_einsum(emb.float().contiguous(), mask_features, precision=self.precision.einsum,
                                         out_dtype=self.precision.act)

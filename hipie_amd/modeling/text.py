@@ -118,9 +118,21 @@ class BertModel(nn.Module):
                 lin.weight.data = lin.weight.data.to(dtype)
                 lin.bias.data = lin.bias.data.to(dtype)
         self._fused = fused
+        self._fused_key = self._qkv_versions()
         return self
 
+    def _qkv_versions(self):
+        ps = []
+        for layer in self.encoder.layer:
+            at = layer.attention.self
+            ps += [at.query.weight, at.key.weight, at.value.weight, at.query.bias, at.key.bias, at.value.bias]
+        return tuple((q.data_ptr(), q._version) for q in ps)
+
     def _forward16(self, input_ids, attention_mask):
+        if self._fused is None or getattr(self, "_fused_key", None) != self._qkv_versions():
+            # a sub-module load_state_dict / in-place update after finalize(): rebuild the fused 16-bit QKV weights (the other dense
+            # layers are cast in place by set_compute_dtype, which a load into fp16 parameters preserves)
+            self.set_compute_dtype(self.compute_dtype)
         dt = self.compute_dtype
         emb = self.embeddings
         L = input_ids.shape[1]

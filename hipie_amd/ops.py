@@ -148,7 +148,9 @@ def msda_fused(value, spatial_shapes, level_start_index, ref, offsets, logits):
     out = torch.empty(B, Lq, M * D, dtype=value.dtype, device=value.device)
     if not value.is_cuda or value.dtype not in _DT:
         raise RuntimeError("Not implemented on the CPU (value)" if not value.is_cuda else "msda_fused: bad value dtype")
-    rc = lib.hipie_msda_fused_forward_strided(value.data_ptr(), vrow, _chk(spatial_shapes, "spatial_shapes", torch.int64),
+    # dense values go in with row stride 0 (= M * D inside the library): the % 8 requirement applies to strided column blocks only
+    rc = lib.hipie_msda_fused_forward_strided(value.data_ptr(), 0 if value.is_contiguous() else vrow,
+                                              _chk(spatial_shapes, "spatial_shapes", torch.int64),
                                               _chk(level_start_index, "level_start_index", torch.int64),
                                               _chk(ref, "ref", torch.float32), offsets.data_ptr(), logits.data_ptr(), out.data_ptr(),
                                               B, S, M, D, L, Lq, P, ref.shape[-1], _DT[value.dtype], _DT[offsets.dtype],
@@ -661,7 +663,7 @@ def hl8_pack(x, scale=1.0):
     """(..., K) float tensor -> (..., 2K) fp16 in HL8 layout, written with torch ops (weights, once per checkpoint; tests)."""
     K = x.shape[-1]
     assert K % 8 == 0
-    xs = x.float() * scale
+    xs = (x.float() * scale).clamp(-65504.0, 65504.0)      # saturate like the kernels' hl_split (no inf hi / NaN lo)
     hi = xs.half()
     lo = (xs - hi.float()).half()
     return torch.stack([hi.reshape(*x.shape[:-1], K // 8, 8), lo.reshape(*x.shape[:-1], K // 8, 8)], dim=-2).reshape(*x.shape[:-1], 2 * K).contiguous()

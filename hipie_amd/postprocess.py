@@ -234,6 +234,7 @@ def _instances_on_device(model, out, batched_inputs, do_postprocess=True):
             "pmap": pmap, "C": C, "is_thing": is_thing, "task": task}
 
 
+@torch.no_grad()
 def inference_compact(model, out, batched_inputs, topk=100, do_postprocess=True):
     """the (B, topk, 7) block of parallel.compact_predictions(inference(..., with_masks=False, with_sem_pan=False), topk)
     -- [x0, y0, x1, y1, score, class, query index] per instance, score order, zero padded -- built entirely on the device:
@@ -251,6 +252,7 @@ def inference_compact(model, out, batched_inputs, topk=100, do_postprocess=True)
     return torch.cat([rows, rows.new_zeros(B, topk - K, rows.shape[2])], 1)
 
 
+@torch.no_grad()
 def inference(model, out, batched_inputs, do_postprocess=True, with_masks=True, with_sem_pan=True):
     """a22 dictionary -> list of {"instances": Instances, "panoptic_seg": (label map, segments_info), "sem_seg"} like
     HIPIE_IMG.forward's eval branch (hipie_img.py:313-362).  with_masks / with_sem_pan False skip the instance masks /

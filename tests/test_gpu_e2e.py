@@ -231,3 +231,106 @@ def test_full_size_open_vocabulary_configs(n_classes, L):
     from hipie_amd.postprocess import inference
     res = inference(model, out, b, with_masks=False, with_sem_pan=False)
     assert int(res[0]["instances"].pred_classes.max()) < n_classes
+
+
+def test_split_policy_large_activations_stay_finite():
+    """scaled weights: the linears of the backbone and the heads see activations 30x larger than the synthetic checkpoint's (real
+    checkpoints have outlier channels).  The split policy's operands are fp16 PAIRS: values beyond the fp16 range saturate (never inf /
+    NaN), everything else keeps fp32-class accuracy -- every a22 output stays finite."""
+    from hipie_amd.config import Precision
+    g, model = build(Precision.split3())
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("mlp.fc1.weight") or n.endswith("linear1.weight") or "input_proj" in n and n.endswith("0.weight"):
+                p.mul_(30.0)
+    model._invalidate()
+    out = model.forward_raw(inputs(g, "detection"))
+    for k in KEYS:
+        assert torch.isfinite(out[k].float()).all(), k
+
+
+@pytest.mark.parametrize("policy", ["split3", "parity"])
+def test_stages_tiny_on_the_gpu(policy):
+    """the PRODUCT path stage by stage against tests/golden/stages_tiny.npz (intermediate tensors of the reference's own modules
+    inside coco_inference): backbone features + sine position + level masks (rows a3, a7), the encoder memory and the fused
+    language stream (a9, a11), decoder states and references (a13; the two-stage selection a12 pinned), the CondInst mask-head
+    convolutions (a18), MaskDINO's encoder memory, multi-scale features and mask features (a8, a20).  Forward hooks on the modules;
+    the a15 / a16 / a17 heads are the last step from `dec_hs` to the a22 outputs checked by the e2e tests."""
+    from hipie_amd.config import Precision
+    st = Golden("stages_tiny")
+    g, model = build(getattr(Precision, policy)())
+    model.pin_topk(g["detection_topk_fg"], g["detection_topk_md"])
+    d = model.detr
+    caps = {}
+
+    def cap(name):
+        def f(mod, inp, out):
+            caps[name] = out
+        return f
+    hooks = [d.detr.backbone.register_forward_hook(cap("backbone")),
+             d.detr.transformer.encoder.register_forward_hook(cap("encoder")),
+             d.detr.transformer.decoder.register_forward_hook(cap("decoder")),
+             d.mask_head.register_forward_hook(cap("mask_head")),
+             d.mask_dino.pixel_decoder.transformer.register_forward_hook(cap("md_enc"))]
+    pix = d.mask_dino.pixel_decoder
+    orig_ff = pix.forward_features
+
+    def ff(features, masks=None):
+        r = orig_ff(features, masks)
+        caps["md_pix"] = r
+        return r
+    pix.forward_features = ff
+    try:
+        model.forward_raw(inputs(g, "detection"))
+    finally:
+        pix.forward_features = orig_ff
+        for h in hooks:
+            h.remove()
+    tol = 1e-3
+
+    def chk(key, t, valid=None):
+        """max|a-b| / max|b| against the fixture; `valid` (bool, broadcastable to t): compare those entries only."""
+        a, b = st.like(key, t.float().cpu().contiguous()), st[key]
+        if valid is None:
+            e = rel_err(a, b)
+        else:
+            v = st.like(key, valid.expand_as(t).contiguous().cpu())
+            e = float(((a - b).abs() * v).max() / (b.abs() * v).max())
+        assert e < tol, (key, e)
+        return e
+    feats, pos = caps["backbone"]
+    errs = {}
+    for i in range(3):
+        errs["feat%d" % i] = chk("feat%d" % i, feats[i].tensors)
+        assert torch.equal(st.like("mask%d" % i, feats[i].mask.cpu()), st["mask%d" % i])
+        # the sine embedding is compared on the VALID pixels: in a fully padded row the x coordinate is (0 - 0.5) / 1e-6 and the
+        # embedding is sin / cos of ~3e6 rad -- a value nothing reads (the padding mask removes it), on which the host's and the
+        # device's range reduction legitimately differ
+        valid = (~feats[i].mask.cpu())[:, None].expand_as(pos[i]).contiguous()
+        a = st.like("pos%d" % i, pos[i].float().cpu().contiguous())
+        v = st.like("pos%d" % i, valid)
+        e = float(((a - st["pos%d" % i]).abs() * v).max())
+        assert e < 1e-4, ("pos%d" % i, e)
+        errs["pos%d" % i] = e
+    # PADDED tokens carry the sine embedding of a degenerate coordinate (see above): the reference's values there depend on its
+    # device's sin / cos of ~3e6 rad, and nothing reads them except the 3x3 convolutions of the mask head, which smear them a few
+    # pixels into the image.  The encoder memory is compared on the valid tokens, the mask-head map 9 pixels away from the padding
+    # (receptive field of lay3@s32 .. lay2@s8 in stride-8 pixels).
+    m0 = feats[0].mask
+    lvl_masks = [f.mask for f in feats] + [torch.nn.functional.interpolate(m0[None].float(), size=(m0.shape[1] // 8, m0.shape[2] // 8)).bool()[0]]
+    tok_valid = ~torch.cat([m.flatten(1) for m in lvl_masks], 1)
+    errs["memory"] = chk("memory", caps["encoder"]["visual"], tok_valid[..., None])
+    errs["vl0_lang"] = chk("vl0_lang", caps["encoder"]["lang"]["hidden"])
+    hs, refs = caps["decoder"][0], caps["decoder"][1]
+    errs["dec_hs"] = chk("dec_hs", hs)
+    errs["dec_refs"] = chk("dec_refs", refs)
+    far = torch.nn.functional.max_pool2d(m0[:, None].float(), 19, 1, 9)[:, 0] == 0            # no padded pixel within 9 pixels
+    errs["mask_head"] = chk("mask_head_out", caps["mask_head"], far[:, None])
+    errs["md_enc_memory"] = chk("md_enc_memory", caps["md_enc"][0])
+    mf, _, ms = caps["md_pix"]
+    if not torch.is_tensor(mf):                  # 16-bit policies keep the mask features in front of their last 1x1 convolution
+        mf = torch.nn.functional.conv2d(mf.pre.float(), mf.weight.float()[:, :, None, None], mf.bias.float())
+    errs["md_mask_features"] = chk("md_mask_features", mf)
+    for i in range(4):
+        errs["md_ms%d" % i] = chk("md_ms%d" % i, ms[i])
+    print("stages (%s): " % policy + " ".join("%s=%.1e" % kv for kv in errs.items()))

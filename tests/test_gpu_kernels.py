@@ -879,3 +879,51 @@ def test_layernorm_hl8_outputs():
     o32, n16, s16 = ops.add_layernorm_dec(xs, ds, w, b, 1e-5, "hl8", want16=True, addend=ops.hl8_pack(add32))
     assert torch.equal(n16, ops.hl8_pack(o32))
     assert torch.equal(s16, ops.hl8_pack(o32 + ops.hl8_unpack(ops.hl8_pack(add32))))
+
+
+@pytest.mark.parametrize("nhwc", [False, True])
+def test_group_norm_large_mean(nhwc):
+    """|mean| >> std (a large convolution bias folded in as pre-bias): the shifted sums keep the variance; E[x^2] - mean^2 in fp32
+    would lose it (mean 300, std 0.05: relative spacing of fp32 at 9e4 is 8e-3 >> var 2.5e-3)."""
+    import torch.nn.functional as F
+    from hipie_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 256, 24, 40, generator=gen) * 0.05
+    pb = 300.0 + torch.randn(256, generator=gen) * 0.01
+    w, b = 1 + 0.2 * torch.randn(256, generator=gen), 0.2 * torch.randn(256, generator=gen)
+    xin = x.to(DEV)
+    if nhwc:
+        xin = xin.contiguous(memory_format=torch.channels_last)
+    got = ops.group_norm(xin, 32, w.to(DEV), b.to(DEV), 1e-5, prebias=pb.to(DEV))
+    want = F.group_norm(x.double() + pb.double().view(1, -1, 1, 1), 32, w.double(), b.double(), 1e-5).float()
+    assert rel_err(got.float().cpu(), want) < 2e-4
+
+
+def test_msda_fused_tiny_dense_heads():
+    """dense value with M * D not a multiple of 8 (the reference's own unit shapes, ops/test.py: M = 2, D = 2) through the fused op."""
+    from hipie_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    B, M, D, L, P, Lq = 1, 2, 2, 2, 2, 3
+    shapes = torch.tensor([(6, 4), (3, 2)], dtype=torch.long)
+    S = int(shapes.prod(1).sum())
+    value = torch.rand(B, S, M, D, generator=gen)
+    ref = torch.rand(B, Lq, L, 2, generator=gen)
+    off = torch.randn(B, Lq, M, L, P, 2, generator=gen)
+    logits = torch.randn(B, Lq, M, L * P, generator=gen)
+    loc = ref[:, :, None, :, None, :] + off / torch.stack([shapes[:, 1], shapes[:, 0]], -1)[None, None, None, :, None, :].float()
+    attn = torch.softmax(logits, -1).view(B, Lq, M, L, P)
+    want = oo.ms_deform_attn_core(value, shapes, loc, attn)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    got = ops.msda_fused(value.to(DEV), shapes.to(DEV), lsi.to(DEV), ref.to(DEV), off.to(DEV), logits.to(DEV))
+    assert rel_err(got.cpu(), want) < 2e-5
+
+
+def test_hl8_saturates_instead_of_nan():
+    """values beyond the fp16 range: hi saturates at 65504 and lo stays finite (an inf hi would make lo = x - inf a NaN)."""
+    from hipie_amd import ops
+    x = torch.tensor([[1e6, -3e5, 65504.0, 70000.0, 1.0, -2.0, 0.0, 123.456]], device=DEV)
+    h = ops.to_hl8(x)
+    assert torch.isfinite(h.float()).all()
+    back = ops.hl8_unpack(h)[0].cpu()
+    assert back[0] == 65504.0 and back[1] == -65504.0 and back[3] == 65504.0 and abs(float(back[7]) - 123.456) < 1e-4
+    assert torch.equal(h, ops.hl8_pack(x))
