@@ -117,7 +117,14 @@ class HipieConfig:
     prior_prob: float = 0.01
     max_query_len: int = 256                    # MODEL.LANGUAGE_BACKBONE.MAX_QUERY_LEN (hipie/config.py:84; 4096 / 8192 in the eval yamls)
     pad_max: bool = True                        # MODEL.LANGUAGE_BACKBONE.PAD_MAX (hipie/config.py:88): padding="max_length" else "longest"
-    clip_enabled: bool = False                  # MODEL.CLIP.ENABLED: MaskCLIP score fusion -- not built: construction raises
+    clip_enabled: bool = False                  # MODEL.CLIP.ENABLED: MaskCLIP score fusion (hipie_amd/open_vocab.py; on in 10 / 11 eval yamls)
+    clip_name: str = "ViT-L-14-336"             # MODEL.CLIP.NAME (hipie/config.py:153-161)
+    clip_alpha: float = 0.35                    # weight of the CLIP probability for classes that overlap the training vocabulary
+    clip_beta: float = 0.7                      # ... for novel classes
+    clip_fg_a: float = 0.3                      # instance score = sqrt(prob^a * sigmoid(iou)^b)
+    clip_fg_b: float = 1.7
+    clip_agg_mode: str = "MUL"                  # "MUL": geometric fusion, "ADD": arithmetic
+    pano_temp_fg: float = 0.06                  # MODEL.PANO_TEMPERATURE_CLIP_FG (hipie/config.py:222)
     # post-processing (hipie_img.py:60-135: values of hipie/config.py:190-257; the eval yamls override the last three)
     ota: bool = True
     mask_thres: float = 0.5
@@ -185,7 +192,10 @@ class HipieConfig:
         if bad:
             raise NotImplementedError("hipie_amd builds the shipped eval configuration only; unsupported: " + "; ".join(bad))
         c.max_query_len, c.pad_max = int(m.LANGUAGE_BACKBONE.MAX_QUERY_LEN), bool(m.LANGUAGE_BACKBONE.PAD_MAX)
-        c.clip_enabled = bool(m.CLIP.ENABLED)
+        c.clip_enabled, c.clip_name = bool(m.CLIP.ENABLED), str(m.CLIP.NAME)
+        c.clip_alpha, c.clip_beta, c.clip_agg_mode = float(m.CLIP.ALPHA), float(m.CLIP.BETA), str(m.CLIP.AGG_MODE)
+        c.clip_fg_a, c.clip_fg_b = float(m.CLIP.FG_IOU_A), float(m.CLIP.FG_IOU_B)
+        c.pano_temp_fg = float(m.PANO_TEMPERATURE_CLIP_FG)
         if m.BACKBONE.NAME == "D2ViT":
             geo = {"ViT-Base": (768, 12, 12), "ViT-Large": (1024, 24, 16), "ViT-huge": (1280, 32, 16)}[m.VIT.NAME]
             c.backbone, (c.vit_embed_dim, c.vit_depth, c.vit_heads) = "vit", geo

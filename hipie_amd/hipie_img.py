@@ -58,10 +58,6 @@ class HIPIE_IMG(nn.Module):
     def __init__(self, cfg: HipieConfig, precision: Precision = None, device="cuda"):
         super().__init__()
         _lib.load()       # fail loudly at construction when the HIP library is missing -- there is no fallback path
-        if cfg.clip_enabled:
-            raise NotImplementedError(
-                "MODEL.CLIP.ENABLED: the MaskCLIP score fusion (hipie/open_vocab/clip.py:243-383, SURVEY 8f-2) is not part of "
-                "this build -- run with MODEL.CLIP.ENABLED False (the scores then differ from the shipped eval setting)")
         self.cfg = cfg
         self.precision = precision or Precision()
         self.device = torch.device(device)
@@ -83,12 +79,26 @@ class HIPIE_IMG(nn.Module):
         self.detr = DDETRSegmUniDN(model, cfg, self.precision)
         self.register_buffer("pixel_mean", torch.tensor(cfg.pixel_mean).view(3, 1, 1), persistent=False)
         self.register_buffer("pixel_std", torch.tensor(cfg.pixel_std).view(3, 1, 1), persistent=False)
+        # MaskCLIP score fusion (hipie_img.py:248-262).  The CLIP towers are not part of a HIPIE checkpoint (the reference downloads
+        # the OpenAI weights through open_clip at construction): load them with self.clip.load_clip_state_dict(); the training
+        # vocabulary (hipie_img.py:72) comes from the reference installation's label file when it is present.
+        self.enable_clip = bool(cfg.clip_enabled)
+        if self.enable_clip:
+            from .open_vocab import MaskCLIP, load_openseg_labels
+            self.clip = MaskCLIP(cfg.clip_name)
+            self.train_labels = load_openseg_labels("coco_panoptic", prompt_engineered=True)
         self.eval()
         # Weight-derived state (policy-dtype casts, BN folds, fused projection weights, per-geometry constants) is built by
         # finalize().  It runs lazily on the first forward and again after every load_state_dict, so the order
         # build -> DetectionCheckpointer.load -> forward of train_net.py:269-271 never sees folds of the random init.
         self._final = False
-        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module._invalidate())
+        self.register_load_state_dict_post_hook(HIPIE_IMG._after_load)
+
+    @staticmethod
+    def _after_load(module, incompatible_keys):
+        # the CLIP towers are loaded separately (MaskCLIP.load_clip_state_dict): a HIPIE checkpoint never has them
+        incompatible_keys.missing_keys[:] = [k for k in incompatible_keys.missing_keys if not k.startswith("clip.")]
+        module._invalidate()
 
     def _invalidate(self):
         self._final = False

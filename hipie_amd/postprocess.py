@@ -2,8 +2,8 @@
 
 Mirrors HIPIE_IMG.inference (projects/HIPIE/hipie/hipie_img.py:537-766), panoptic_inference (:473-535), semantic_inference
 (:870-878), convert_grounding_to_od_logits (:1025-1052) and segmentation_postprocess (hipie/models/ddetrs.py:1029-1076)
-for decouple_decoder True / bg_query_from_lang False / demo_only False / score_thres 0 (the shipped eval settings);
-MaskCLIP score fusion is the next row (f-2) and raises if requested.
+for decouple_decoder True / bg_query_from_lang False / demo_only False / score_thres 0 (the shipped eval settings), with the
+MaskCLIP score fusion of MODEL.CLIP.ENABLED (hipie_img.py:592-609, 735-747, 811-868; hipie_amd/open_vocab.py) when the model has it.
 
 What changed relative to the reference's per-image, per-class, per-segment Python loops:
   * token -> class pooling is one GEMM (mean) or one padded gather + max for the whole batch, FG/BG masking a `where`;
@@ -165,6 +165,24 @@ def _segments_info(tables):
     return out
 
 
+def _clip_logits(model, batched_inputs, i, mask_logits, pred_open_prob):
+    """HIPIE_IMG.get_clip_logits for image i (hipie_img.py:811-868).  The image is the un-normalised input / 255 (:349-351); the test
+    vocabulary is the input's `open_seg_labels` ([{"name": "a,b,..."}] per class, data/coco_dataset_mapper_uni.py), the training
+    vocabulary model.train_labels."""
+    from .open_vocab import get_clip_logits
+    x = batched_inputs[i]
+    test = x.get("open_seg_labels")
+    if test is None:
+        raise ValueError("MODEL.CLIP.ENABLED needs `open_seg_labels` in every input (the test-time mapper provides it)")
+    if getattr(model, "train_labels", None) is None:
+        raise RuntimeError("MaskCLIP: the training vocabulary is missing -- set model.train_labels (get_openseg_labels('coco_panoptic', "
+                           "prompt_engineered=True)) or provide the reference's openseg_labels directory (HIPIE_ASSETS)")
+    cfg = model.cfg
+    img = x["image"].to(mask_logits.device).float() / 255.0
+    return get_clip_logits(model.clip, img, mask_logits, [t["name"].split(",") for t in test],
+                           [t["name"].split(",") for t in model.train_labels], pred_open_prob, cfg.clip_alpha, cfg.clip_beta, cfg.clip_agg_mode)
+
+
 # ------------------------------------------------------------------------------------------------ the entry point
 @torch.no_grad()
 def _instances_on_device(model, out, batched_inputs, do_postprocess=True):
@@ -172,8 +190,7 @@ def _instances_on_device(model, out, batched_inputs, do_postprocess=True):
     NMS, the per-image top-k over (kept query, class), boxes scaled / clipped to the output size.  No host synchronisation:
     every per-image quantity is a row of a (B, K) tensor and `ok` marks the rows that are instances."""
     cfg = model.cfg
-    if getattr(model, "enable_clip", False):
-        raise NotImplementedError("MaskCLIP score fusion (MODEL.CLIP.ENABLED) is not part of this build (SURVEY 8f-2)")
+    use_clip = bool(getattr(model, "enable_clip", False))
     task = batched_inputs[0]["task"]
     max_num_inst = {"detection": 100, "grounding": 1}[task]
     nbg, s = cfg.num_bg_queries, cfg.mask_stride
@@ -196,7 +213,17 @@ def _instances_on_device(model, out, batched_inputs, do_postprocess=True):
     Q = box_cls.shape[1]
     logits = convert_grounding_to_od_logits(box_cls, C, pmap, is_thing, ["FG" if h else None for h in has_thing],
                                             cfg.mode_free, cfg.max_pool)        # (B, Q, C)
-    prob = torch.sqrt(logits.sigmoid() * iou.sigmoid())
+    if use_clip and cfg.ota:
+        # hipie_img.py:592-609: the detector's class probabilities are fused with MaskCLIP's per-mask class probabilities
+        if cfg.transform_eval and C > 1:
+            p_det = F.softmax(logits.sigmoid() / cfg.pano_temp_fg, dim=-1)
+        else:
+            p_det = logits.sigmoid()
+        fused = torch.stack([_clip_logits(model, batched_inputs, i, pred_masks[i], p_det[i]) for i in range(B)])
+        allowed = (logits[:, :1] != NEG).float()                                  # the reference's is_thing_mask (first query row)
+        prob = torch.sqrt((fused.sigmoid() * allowed) ** cfg.clip_fg_a * iou.sigmoid() ** cfg.clip_fg_b)
+    else:
+        prob = torch.sqrt(logits.sigmoid() * iou.sigmoid())
     if cfg.ota:
         nms_scores, idxs = prob.max(2)
         keep, count = ops.batched_nms(box_pred, nms_scores.contiguous(), idxs.contiguous(), cfg.nms_thresh)
@@ -298,6 +325,11 @@ def inference(model, out, batched_inputs, do_postprocess=True, with_masks=True, 
                 cls_all = F.softmax(logits_all.sigmoid() / cfg.pano_temp, dim=-1)
             else:
                 cls_all = logits_all.sigmoid()
+            if getattr(model, "enable_clip", False):
+                # hipie_img.py:731-747: the masks the reference hands to CLIP are the x4 up-sampled logits cropped to the image
+                up = F.interpolate(masks_all[:, None].float(), scale_factor=float(s), mode="bilinear", align_corners=False)
+                up = up[:, 0, :image_sizes[i][0], :image_sizes[i][1]]
+                cls_all = _clip_logits(model, batched_inputs, i, up, cls_all).softmax(-1)
             sem, tab = _sem_pan(cls_all, masks_all, s, image_sizes[i], out_sizes[i], thing_vector(is_thing[i], C, dev), cfg,
                                 0 if getattr(getattr(model, "precision", None), "einsum", 0) in (0, 1, 4) else 1)
             results[i]["sem_seg"] = sem

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 DEFAULTS = dict(ota=True, mask_thres=0.5, mask_stride=4, transform_eval=True, pano_temp=0.06, overlap_threshold=0.8,
                 object_mask_threshold=0.25, use_bg_for_pano=True, bg_cls_agnostic=False, max_pool=False,
-                mode_free=False, nms_thresh=0.7)
+                mode_free=False, nms_thresh=0.7, clip=None, clip_fg_a=0.3, clip_fg_b=1.7, pano_temp_fg=0.06)
 
 
 def convert_grounding_to_od_logits(logits, num_classes, positive_map, is_thing={}, mode=None, model_free=False,
@@ -144,8 +144,10 @@ def segmentation_postprocess(inst, out_h, out_w):
 
 def inference(a22, image_sizes, positive_map, task, is_thing, out_sizes=None, num_bg=10, **kw):
     """HIPIE_IMG.inference (hipie_img.py:537-766) followed by segmentation_postprocess (hipie_img.py:356-362), decouple_decoder
-    True, bg_query_from_lang False, enable_clip False, demo_only False, score_thres 0.  Returns a list of dicts:
-    instances (dict of tensors), panoptic_seg ((H,W) int32, segments_info), sem_seg (C,H,W)."""
+    True, bg_query_from_lang False, demo_only False, score_thres 0.  Returns a list of dicts:
+    instances (dict of tensors), panoptic_seg ((H,W) int32, segments_info), sem_seg (C,H,W).
+    kw["clip"]: MODEL.CLIP.ENABLED -- a callable (i, mask_logits (Q,h,w), pred_open_prob (Q,C)) -> fused class logits (Q,C)
+    (HIPIE_IMG.get_clip_logits, oracle/clip.py) used at the two call sites hipie_img.py:592-609 and :735-747."""
     o = dict(DEFAULTS)
     o.update(kw)
     max_num_inst = {"detection": 100, "grounding": 1}[task]
@@ -162,7 +164,13 @@ def inference(a22, image_sizes, positive_map, task, is_thing, out_sizes=None, nu
         logits = convert_grounding_to_od_logits(box_cls[i][None], num_classes, positive_map, is_thing=it,
                                                 mode="FG" if has_thing else None, model_free=o["mode_free"],
                                                 max_pool=o["max_pool"])[0]
-        prob = torch.sqrt(logits.sigmoid() * iou_pred[i].sigmoid())
+        if o.get("clip") is not None:
+            allowed = (~(logits[:1] == -9999.0)).float()
+            p_det = F.softmax(logits.sigmoid() / o["pano_temp_fg"], dim=-1) if (o["transform_eval"] and logits.shape[-1] > 1) else logits.sigmoid()
+            prob = o["clip"](i, mask_pred[i][:, 0], p_det).sigmoid() * allowed
+            prob = torch.sqrt((prob ** o["clip_fg_a"]) * (iou_pred[i].sigmoid() ** o["clip_fg_b"]))
+        else:
+            prob = torch.sqrt(logits.sigmoid() * iou_pred[i].sigmoid())
         nms_scores, idxs = torch.max(prob, 1)
         keep = batched_nms(box_cxcywh_to_xyxy(box_pred[i]), nms_scores, idxs, o["nms_thresh"])
         prob = prob[keep]
@@ -196,6 +204,8 @@ def inference(a22, image_sizes, positive_map, task, is_thing, out_sizes=None, nu
                 cls_all = logits_all.sigmoid()
             masks_all = F.interpolate(masks_all, size=(H * s, W * s), mode="bilinear", align_corners=False)
             masks_all = masks_all[:, :, :image_size[0], :image_size[1]]
+            if o.get("clip") is not None:
+                cls_all = o["clip"](i, masks_all[:, 0], cls_all).softmax(-1)
             up = F.interpolate(masks_all, size=tuple(out_sizes[i]), mode="bilinear", align_corners=False)[:, 0]
             sem = semantic_inference(cls_all, up)
             pan, seg_info = panoptic_inference(cls_all, up, it, o["object_mask_threshold"], o["overlap_threshold"])

@@ -46,6 +46,8 @@ def synth_tensor(name, shape, seed=0, dtype=torch.float32):
     g = _gen(seed, name)
     leaf = name.split(".")[-1]
     if len(shape) == 0:
+        if leaf == "logit_scale":          # CLIP's learned temperature: exp(.) near the OpenAI value 1 / 0.07
+            return (2.659 + 0.1 * torch.randn((), generator=g)).to(dtype)
         return torch.zeros((), dtype=torch.long) if "num_batches" in name else torch.randn((), generator=g).to(dtype) * 0.1
     if "running_var" in name:
         return (1.0 + 0.2 * torch.rand(shape, generator=g)).to(dtype)
@@ -224,3 +226,19 @@ def prompt_tokenizer(tmpdir):
     with open(path, "w") as f:
         f.write("\n".join(PROMPT_VOCAB) + "\n")
     return BertTokenizerFast(vocab_file=path, do_lower_case=True)
+
+
+def clip_tokenize(texts, context, vocab):
+    """a deterministic stand-in for open_clip.tokenize (its BPE vocabulary is not available offline): one id per whitespace /
+    punctuation separated word, [start] ... [end] with the END token the highest id of the vocabulary (CLIP.encode_text reads
+    the feature at argmax), zero padded to `context`."""
+    import re as _re
+    if isinstance(texts, str):
+        texts = [texts]
+    out = torch.zeros(len(texts), context, dtype=torch.long)
+    sot, eot = vocab - 2, vocab - 1
+    for i, t in enumerate(texts):
+        words = _re.findall(r"[a-z0-9]+|[^\sa-z0-9]", t.lower())
+        ids = [sot] + [1 + zlib.crc32(w.encode()) % (vocab - 3) for w in words][:context - 2] + [eot]
+        out[i, :len(ids)] = torch.tensor(ids)
+    return out

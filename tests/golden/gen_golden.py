@@ -547,6 +547,71 @@ def gen_post():
     save("post", meta, _full=tuple(k for k in arrays if k.endswith(("masks", "panoptic"))), **arrays)
 
 
+# ------------------------------------------------------------------------------ MaskCLIP score fusion
+CLIP_TEST_LABELS = [{"name": "person,people"}, {"name": "dog"}, {"name": "traffic light"}, {"name": "sky,clouds"}, {"name": "zebra crossing"}]
+CLIP_TRAIN_LABELS = [{"id": 1, "name": "person,child"}, {"id": 2, "name": "dog"}, {"id": 3, "name": "sky"}, {"id": 4, "name": "car"}]
+
+
+def gen_maskclip():
+    """the reference's OWN MaskCLIP (hipie/open_vocab/clip.py: get_mask_embed / encode_image_with_mask / _mask_clip_forward /
+    pred_logits / build_text_embed) and HIPIE_IMG.get_clip_logits (hipie_img.py:811-868), plus HIPIE_IMG.inference with
+    MODEL.CLIP.ENABLED on (:592-609, :735-747), executed over the open_clip stand-in of ref_shim (third-party architecture, tiny
+    configuration, seeded weights).  One image: the reference's CLIP call asserts batch 1 (its evaluation batch size)."""
+    clipm = ref_shim.ref_clip()
+    m = ref_shim.ref_hipie_img()
+    dd = ref("models.ddetrs")
+    cfgc = ref_shim.OPEN_CLIP_CFG
+    mc = clipm.MaskCLIP(name="tiny")
+    man = _synth.load_synth(mc.clip, seed=95)
+    arrays, meta = {}, dict(clip_cfg=cfgc, manifest=man_json(man), test_labels=CLIP_TEST_LABELS, train_labels=CLIP_TRAIN_LABELS)
+    # (a) kernel level: mask embeddings, text embeddings, per-mask class logits, both fusion modes
+    g = torch.Generator().manual_seed(96)
+    image = torch.rand(1, 3, 70, 98, generator=g)
+    ys, xs = torch.linspace(0, 1, 20).view(1, 1, 20, 1), torch.linspace(0, 1, 28).view(1, 1, 1, 28)
+    cy, cx, r = torch.rand(1, 7, 1, 1, generator=g), torch.rand(1, 7, 1, 1, generator=g), 0.15 + 0.25 * torch.rand(1, 7, 1, 1, generator=g)
+    mask = 6.0 * torch.tanh((r - torch.sqrt((ys - cy) ** 2 + (xs - cx) ** 2)) * 12.0) + 0.3 * torch.randn(1, 7, 20, 28, generator=g)
+    mask[0, 6] = -8.0                                           # a mask that covers nothing: its token sees the class token only
+    labels = clipm.prompt_labels([x["name"].split(",") for x in CLIP_TEST_LABELS], "photo") if hasattr(clipm, "prompt_labels") else \
+        ref("open_vocab.helper").prompt_labels([x["name"].split(",") for x in CLIP_TEST_LABELS], "photo")
+    text_embed = mc.build_text_embed(labels)
+    out = mc(image, mask, text_embed, labels)
+    arrays.update(image=image, mask=mask, text_embed=text_embed, mask_embed=out["mask_embed"], open_logits=out["mask_pred_open_logits"])
+    prob = torch.softmax(torch.randn(7, len(CLIP_TEST_LABELS), generator=g), -1)
+    arrays["pred_open_prob"] = prob
+    me = NS(clip=mc, train_labels=CLIP_TRAIN_LABELS)
+    me.get_clip_logits = types.MethodType(m.HIPIE_IMG.get_clip_logits, me)
+    images = NS(tensor=image)
+    for mode in ("MUL", "ADD"):
+        me.clip_agg_mode = mode
+        arrays["fused_" + mode] = me.get_clip_logits(0, [CLIP_TEST_LABELS], mask, images, prob, alpha=0.4, beta=0.45)
+    # (b) HIPIE_IMG.inference with the fusion on: one image of the synthetic a22 dictionary, 5 classes
+    P = dict(POST, sizes=[(200, 256)], n_classes=5, L=32, seed=97)
+    a22 = _synth.synth_a22([tuple(s) for s in P["sizes"]], P["n_bg"], P["n_fg"], P["n_md"], P["L"], seed=P["seed"])
+    _, _, pmap = _synth.synth_token_ids(1, P["n_classes"], P["L"], seed=74)
+    is_thing = {1: True, 2: True, 3: True, 4: False, 5: False}
+    img255 = _synth.synth_images(P["sizes"], seed=98)[0]
+    me = NS(num_bg=P["n_bg"], num_fg=P["n_fg"], ota=True, mode_free_inference=False, max_pool_token_test=False,
+            enable_clip=True, clip=mc, train_labels=CLIP_TRAIN_LABELS, clip_alpha=0.4, clip_beta=0.45, clip_agg_mode="MUL", clip_fg_a=0.3,
+            clip_fg_b=1.7, pano_temp_fg=0.06, demo_only=False, mask_on=True, mask_stride=4, mask_thres=0.5, use_bg_for_pano=True,
+            bg_cls_agnostic=False, transform_eval=True, pano_temp=0.06, object_mask_threshold=0.25, overlap_threshold=0.8,
+            detr=NS(bg_query_from_lang=False, decouple_decoder=True, mask_dino_fixed_linear_head=False))
+    for fn in ("semantic_inference", "panoptic_inference", "get_clip_logits"):
+        setattr(me, fn, types.MethodType(getattr(m.HIPIE_IMG, fn), me))
+    sizes = [tuple(s) for s in P["sizes"]]
+    out22 = {k: v.clone() for k, v in a22.items()}
+    res = m.HIPIE_IMG.inference(me, out22["pred_logits"], out22["pred_boxes"], out22["pred_masks"], sizes, pmap, len(pmap),
+                                task="detection", iou_pred=out22["pred_boxious"], is_thing=[is_thing], sizes=sizes, output=out22,
+                                bg_queries_lang=None, test_labels=[CLIP_TEST_LABELS], images=NS(tensor=(img255 / 255.0)[None]))
+    r = res[0]
+    inst = dd.segmentation_postprocess(r["instances"], sizes[0][0], sizes[0][1])
+    arrays["post_boxes"], arrays["post_scores"], arrays["post_classes"] = inst.pred_boxes.tensor, inst.scores, inst.pred_classes
+    pan, info = r["panoptic_seg"]
+    arrays["post_panoptic"] = pan.to(torch.int16)
+    arrays["post_semseg"] = r["sem_seg"]
+    meta.update(post=P, pmap={str(k): v for k, v in pmap.items()}, is_thing={str(k): v for k, v in is_thing.items()}, segments=info)
+    save("maskclip", meta, _full=("post_panoptic", "image", "mask"), **arrays)
+
+
 def gen_prompts():
     """create_queries_and_maps / create_positive_dict / clean_name of the reference's mapper
     (data/coco_dataset_mapper_uni.py:54-90, 732-736, 1024-1058).  That module cannot be imported (its package pulls in the
@@ -595,7 +660,7 @@ def gen_manifest_full():
 
 
 ALL = dict(manifest_full=gen_manifest_full, prompts=gen_prompts, post=gen_post, resnet50=gen_resnet50, msda=gen_msda, vit_attn=gen_vit_attn, vit_backbone=gen_vit_backbone, bi_attn=gen_bi_attn, bert=gen_bert,
-           dynamic_mask=gen_dynamic_mask, e2e=gen_e2e, stages=gen_stages, e2e_r50=gen_e2e_r50, e2e_long=gen_e2e_long, e2e_deep=gen_e2e_deep)
+           dynamic_mask=gen_dynamic_mask, e2e=gen_e2e, stages=gen_stages, e2e_r50=gen_e2e_r50, e2e_long=gen_e2e_long, e2e_deep=gen_e2e_deep, maskclip=gen_maskclip)
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)

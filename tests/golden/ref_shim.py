@@ -223,6 +223,139 @@ def _populate(m):
         m.box_area = _box_area
     elif n == "torchvision":
         m.__version__ = "0.99.0"
+    elif n == "torchvision.transforms":
+        m.Compose = _TVCompose
+    elif n == "open_clip":
+        m.create_model_and_transforms = _oc_create_model_and_transforms
+        m.tokenize = _oc_tokenize
+    elif n == "detectron2.utils.comm":
+        m.get_local_rank = lambda: 0
+        m.synchronize = lambda: None
+
+
+# ---------------------------------------------------------------------------- open_clip stand-in (MaskCLIP golden)
+# open-clip-torch is THIRD-PARTY (pinned to 2.0.2 by ODISE, the origin of hipie/open_vocab/clip.py), absent from /root/reference and
+# from this image.  The classes below follow its published architecture (open_clip/model.py, v2.0.2: CLIP, VisualTransformer,
+# Transformer, ResidualAttentionBlock around torch.nn.MultiheadAttention, QuickGELU for the OpenAI weights) closely enough for the
+# reference's MaskCLIP / ClipAdapter to run on top: same attribute and parameter names, attention executed by torch's own
+# nn.MultiheadAttention.  Size and vocabulary come from OPEN_CLIP_CFG (a tiny configuration for the fixtures).
+OPEN_CLIP_CFG = dict(width=128, layers=2, heads=2, patch=14, image_size=84, embed_dim=32, text_width=64, text_layers=2, text_heads=2,
+                     context=16, vocab=512, quick_gelu=True)
+
+
+class _QuickGELU(nn.Module):
+    def forward(self, x):
+        return x * torch.sigmoid(1.702 * x)
+
+
+class _OCBlock(nn.Module):
+    def __init__(self, d, heads, quick_gelu):
+        super().__init__()
+        from collections import OrderedDict
+        self.ln_1 = nn.LayerNorm(d)
+        self.attn = nn.MultiheadAttention(d, heads)
+        self.ln_2 = nn.LayerNorm(d)
+        self.mlp = nn.Sequential(OrderedDict([("c_fc", nn.Linear(d, d * 4)), ("gelu", _QuickGELU() if quick_gelu else nn.GELU()),
+                                              ("c_proj", nn.Linear(d * 4, d))]))
+
+    def forward(self, x, attn_mask=None):
+        h = self.ln_1(x)
+        x = x + self.attn(h, h, h, need_weights=False, attn_mask=attn_mask)[0]
+        return x + self.mlp(self.ln_2(x))
+
+
+class _OCTransformer(nn.Module):
+    def __init__(self, d, layers, heads, quick_gelu):
+        super().__init__()
+        self.resblocks = nn.ModuleList([_OCBlock(d, heads, quick_gelu) for _ in range(layers)])
+
+    def forward(self, x, attn_mask=None):
+        for r in self.resblocks:
+            x = r(x, attn_mask=attn_mask)
+        return x
+
+
+class _OCVisual(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        d, g = c["width"], c["image_size"] // c["patch"]
+        self.image_size = c["image_size"]
+        self.conv1 = nn.Conv2d(3, d, kernel_size=c["patch"], stride=c["patch"], bias=False)
+        self.class_embedding = nn.Parameter(d ** -0.5 * torch.randn(d))
+        self.positional_embedding = nn.Parameter(d ** -0.5 * torch.randn(g * g + 1, d))
+        self.ln_pre = nn.LayerNorm(d)
+        self.transformer = _OCTransformer(d, c["layers"], c["heads"], c["quick_gelu"])
+        self.ln_post = nn.LayerNorm(d)
+        self.proj = nn.Parameter(d ** -0.5 * torch.randn(d, c["embed_dim"]))
+
+
+class _OCCLIP(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.context_length = c["context"]
+        self.visual = _OCVisual(c)
+        self.transformer = _OCTransformer(c["text_width"], c["text_layers"], c["text_heads"], c["quick_gelu"])
+        self.token_embedding = nn.Embedding(c["vocab"], c["text_width"])
+        self.positional_embedding = nn.Parameter(0.01 * torch.randn(c["context"], c["text_width"]))
+        self.ln_final = nn.LayerNorm(c["text_width"])
+        self.text_projection = nn.Parameter(c["text_width"] ** -0.5 * torch.randn(c["text_width"], c["embed_dim"]))
+        self.logit_scale = nn.Parameter(torch.ones([]) * 2.659)
+        mask = torch.empty(c["context"], c["context"]).fill_(float("-inf")).triu_(1)
+        self.register_buffer("attn_mask", mask, persistent=False)
+
+    def encode_text(self, text):
+        x = self.token_embedding(text) + self.positional_embedding
+        x = self.transformer(x.permute(1, 0, 2), attn_mask=self.attn_mask).permute(1, 0, 2)
+        x = self.ln_final(x)
+        return x[torch.arange(x.shape[0]), text.argmax(dim=-1)] @ self.text_projection
+
+
+class _TVNormalize:
+    def __init__(self, mean, std):
+        self.mean, self.std = torch.tensor(mean).view(1, 3, 1, 1), torch.tensor(std).view(1, 3, 1, 1)
+
+    def __call__(self, x):
+        return (x - self.mean) / self.std
+
+
+class _TVSameSize:
+    """Resize / CenterCrop of the OpenAI preprocess: MaskCLIP only calls them on images it has already resized to the model size."""
+
+    def __init__(self, size):
+        self.size = size
+
+    def __call__(self, x):
+        assert tuple(x.shape[-2:]) == (self.size, self.size), (tuple(x.shape), self.size)
+        return x
+
+
+class _TVCompose:
+    def __init__(self, transforms):
+        self.transforms = list(transforms)
+
+    def __call__(self, x):
+        for t in self.transforms:
+            x = t(x)
+        return x
+
+
+def _oc_create_model_and_transforms(model_name=None, pretrained=None, device=None, **kw):
+    c = OPEN_CLIP_CFG
+    model = _OCCLIP(c).eval()
+    pre = _TVCompose([_TVSameSize(c["image_size"]), _TVSameSize(c["image_size"]), (lambda x: x), (lambda x: x),
+                      _TVNormalize((0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711))])
+    return model, None, pre
+
+
+def _oc_tokenize(texts):
+    import _synth
+    return _synth.clip_tokenize(texts, OPEN_CLIP_CFG["context"], OPEN_CLIP_CFG["vocab"])
+
+
+def ref_clip():
+    """the reference's hipie/open_vocab/clip.py itself (ClipAdapter, MaskCLIP, build_clip_text_embed) over the stand-ins above."""
+    install()
+    return ref("open_vocab.clip")
 
 
 _INSTALLED = False

@@ -208,3 +208,72 @@ def test_inference_compact_equals_host_path(task, topk):
     assert torch.equal(got, want)
     if task == "detection" and topk == 100:
         assert int((want[1, :, 4] > 0).sum()) < int((want[0, :, 4] > 0).sum())        # the empty boxes of image 1 were dropped
+
+
+def _clip_setup(policy_split):
+    from hipie_amd.modeling.transformer import set_split
+    from hipie_amd.open_vocab import MaskCLIP
+    g = Golden("maskclip")
+    cfg = g.meta["clip_cfg"]
+    sd = _synth.synth_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}, seed=95)
+    m = MaskCLIP("tiny", cfg=cfg, tokenize=lambda t: _synth.clip_tokenize(t, cfg["context"], cfg["vocab"]))
+    m.load_clip_state_dict(sd)
+    m = m.cuda().eval()
+    set_split(m, policy_split)
+    return g, m
+
+
+@pytest.mark.parametrize("split", [True, False])
+def test_maskclip_device_path(split):
+    """MaskCLIP on the device (image tokens on hipie_flash_attn, mask tokens through their patch masks, linears on hipie_gemm's split
+    operands or the fp32 library) against the reference's mask embeddings / per-mask logits / fused logits (tests/golden/maskclip.npz)."""
+    from hipie_amd.open_vocab import get_clip_logits, prompt_labels_photo
+    from util import rel_err
+    g, m = _clip_setup(split)
+    test = [t["name"].split(",") for t in g.meta["test_labels"]]
+    train = [t["name"].split(",") for t in g.meta["train_labels"]]
+    labels = prompt_labels_photo(test)
+    te = m.build_text_embed(labels)
+    assert rel_err(te.cpu(), g["text_embed"]) < 1e-4
+    out = m(g["image"].cuda(), g["mask"].cuda(), te, labels)
+    e1, e2 = rel_err(out["mask_embed"].cpu(), g["mask_embed"]), rel_err(out["mask_pred_open_logits"].cpu(), g["open_logits"])
+    fused = get_clip_logits(m, g["image"][0].cuda(), g["mask"][0].cuda(), test, train, g["pred_open_prob"].cuda(), 0.4, 0.45, "MUL")
+    e3 = rel_err(fused.cpu(), g["fused_MUL"])
+    print("maskclip device path (split=%s): mask_embed %.1e open_logits %.1e fused %.1e" % (split, e1, e2, e3))
+    assert e1 < 1e-3 and e2 < 1e-3 and e3 < 1e-3          # the image-token attention runs on fp16 operands
+
+
+def test_post_product_with_maskclip_matches_reference():
+    """postprocess.inference with MODEL.CLIP.ENABLED (both call sites of the fusion, hipie_img.py:592-609 and :735-747) against
+    the reference's own HIPIE_IMG.inference run with its MaskCLIP: classes exactly, scores / boxes / semantic map to 1e-3,
+    the panoptic map up to pixels whose winning score is within rounding of a competitor's."""
+    from hipie_amd.postprocess import inference
+    from util import rel_err
+    g, m = _clip_setup(True)
+    P = g.meta["post"]
+    sizes = [tuple(s) for s in P["sizes"]]
+    a22 = _synth.synth_a22(sizes, P["n_bg"], P["n_fg"], P["n_md"], P["L"], seed=P["seed"])
+    pmap = {int(k): v for k, v in g.meta["pmap"].items()}
+    is_thing = {int(k): v for k, v in g.meta["is_thing"].items()}
+    img = _synth.synth_images(sizes, seed=98)[0]
+    model = fake_model(P["n_bg"], clip_alpha=0.4, clip_beta=0.45, clip_agg_mode="MUL", clip_fg_a=0.3, clip_fg_b=1.7, pano_temp_fg=0.06)
+    model.enable_clip, model.clip, model.train_labels = True, m, g.meta["train_labels"]
+    out = {k: v.cuda() for k, v in a22.items()}
+    out["image_sizes"] = sizes
+    batched = [{"task": "detection", "positive_map_label_to_token": pmap, "is_thing": is_thing, "image": img.cuda(),
+                "open_seg_labels": g.meta["test_labels"]}]
+    r = inference(model, out, batched)[0]
+    inst = r["instances"]
+    # the 100 instances include (query, class) pairs of classes the FG mode disallows: probability exactly 0 -- torch.topk orders
+    # those ties differently on the host and on the device.  Everything with a positive score is compared in order, the zero tail as a set.
+    pos = g["post_scores"] > 0
+    n = int(pos.sum())
+    assert bool(pos[:n].all()) and n > 50
+    assert torch.equal(inst.pred_classes.cpu().long()[:n], g["post_classes"][:n])
+    assert rel_err(inst.scores.cpu(), g["post_scores"]) < 1e-3
+    assert rel_err(inst.pred_boxes.tensor.cpu()[:n], g["post_boxes"][:n]) < 1e-4
+    assert sorted(inst.pred_classes.cpu().tolist()[n:]) == sorted(g["post_classes"].tolist()[n:])
+    pan, info = r["panoptic_seg"]
+    assert info == g.meta["segments"]
+    assert (pan.cpu().long() != g["post_panoptic"].long()).float().mean() < 1e-3
+    assert rel_err(g.like("post_semseg", r["sem_seg"].cpu().float()), g["post_semseg"]) < 1e-3

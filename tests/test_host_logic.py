@@ -306,7 +306,8 @@ def _eval_cfg(**over):
                     MASK_STRIDE=4, CTRL_LAYERS=3, MASK_THRES=0.5, USE_DINO=True, TWO_STAGE=True, MIXED_SELECTION=True,
                     LOOK_FORWARD_TWICE=True, BG_QUERY_FROM_LANG=False, NEW_MASK_HEAD=False, USE_RAFT=False, USE_REL_COORD=True),
         LANGUAGE_BACKBONE=dict(LANG_DIM=768, MAX_QUERY_LEN=8192, PAD_MAX=True), DYHEAD=dict(LOG_SCALE=0.0, PRIOR_PROB=0.01),
-        CLIP=dict(ENABLED=False, ENABLED_TRAIN=False), MASKDINO=dict(CONFIG_PATH="unused"))
+        CLIP=dict(ENABLED=False, ENABLED_TRAIN=False, NAME="ViT-B-32", ALPHA=0.35, BETA=0.7, FG_IOU_A=0.3, FG_IOU_B=1.7, AGG_MODE="MUL"),
+        PANO_TEMPERATURE_CLIP_FG=0.06, MASKDINO=dict(CONFIG_PATH="unused"))
     cfg = dict(MODEL=model, TEST=dict(USE_BG_FOR_PANO_ON=True, BG_CLS_AGNOSTIC=False, MAX_POOL=False))
     for path, v in over.items():
         node = cfg
@@ -349,8 +350,13 @@ def test_d2_registry_registers_and_builds_from_a_yacs_cfg(monkeypatch):
     model._final = True
     model.load_state_dict(sd, strict=True)
     assert model._final is False                                                 # a checkpoint load re-arms finalize()
-    with pytest.raises(NotImplementedError, match="CLIP"):
-        modeling.META_ARCH_REGISTRY.get("HIPIE_IMG")(_eval_cfg(**{"MODEL.CLIP.ENABLED": True}))
+    # MODEL.CLIP.ENABLED (on in 10 of the 11 shipped eval yamls, with ALPHA 0.4 / BETA 0.45): the model constructs with its
+    # MaskCLIP towers, which are not part of the state_dict, and a strict HIPIE checkpoint load does not ask for them
+    mc = modeling.META_ARCH_REGISTRY.get("HIPIE_IMG")(_eval_cfg(**{"MODEL.CLIP.ENABLED": True, "MODEL.CLIP.ALPHA": 0.4, "MODEL.CLIP.BETA": 0.45}))
+    assert mc.enable_clip and (mc.cfg.clip_alpha, mc.cfg.clip_beta, mc.cfg.clip_agg_mode, mc.cfg.clip_name) == (0.4, 0.45, "MUL", "ViT-B-32")
+    assert not any(k.startswith("clip.") for k in mc.state_dict())
+    assert sum(p.numel() for p in mc.clip.parameters()) > 1e8                    # ViT-B/32 towers are really there
+    mc.load_state_dict(sd, strict=True)                                          # the CLIP-less checkpoint of the model above
     with pytest.raises(NotImplementedError, match="PARALLEL_DET"):
         modeling.META_ARCH_REGISTRY.get("HIPIE_IMG")(_eval_cfg(**{"MODEL.PARALLEL_DET": True}))
     with pytest.raises(NotImplementedError, match="USE_DINO"):
