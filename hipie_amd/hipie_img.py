@@ -70,11 +70,11 @@ class HIPIE_IMG(nn.Module):
         backbone.strides = d2_backbone.feature_strides
         transformer = DeformableTransformerVLDINO(cfg, self.precision)
         model = DeformableDETRDINO(backbone, transformer, cfg)
-        self.tokenizer = None
-        tok_dir = "projects/HIPIE/bert-base-uncased"
-        if os.path.isdir(tok_dir):                         # hipie_img.py:153 (cwd-relative asset, absent on the GPU box)
-            from transformers import AutoTokenizer
-            self.tokenizer = AutoTokenizer.from_pretrained(tok_dir)
+        # hipie_img.py:153: AutoTokenizer.from_pretrained("projects/HIPIE/bert-base-uncased") -- a cwd-relative asset (absent on the
+        # GPU box).  The vocabulary file is all that is needed: hipie_amd.tokenizer.BertWordPiece is the same algorithm without the
+        # transformers dependency (checked against transformers.BertTokenizerFast in tests/test_host_logic.py).
+        from .tokenizer import BertWordPiece
+        self.tokenizer = BertWordPiece.from_dir(os.environ.get("HIPIE_BERT_DIR", "projects/HIPIE/bert-base-uncased"))
         self.text_encoder = nn.Sequential(OrderedDict([("body", BertEncoder(cfg))]))
         self.detr = DDETRSegmUniDN(model, cfg, self.precision)
         self.register_buffer("pixel_mean", torch.tensor(cfg.pixel_mean).view(3, 1, 1), persistent=False)
@@ -152,12 +152,10 @@ class HIPIE_IMG(nn.Module):
             if self.tokenizer is None:
                 raise RuntimeError("no tokenizer assets (projects/HIPIE/bert-base-uncased): pass input_ids/attention_mask")
             captions = [x["expressions"] for x in batched_inputs]
-            tok = self.tokenizer.batch_encode_plus(captions, max_length=self.cfg.max_query_len,
-                                                   padding="max_length" if self.cfg.pad_max else "longest",
-                                                   return_special_tokens_mask=True, return_tensors="pt",
-                                                   truncation=True).to(self.device)                 # hipie_img.py:904-909
+            tok = self.tokenizer(captions, max_length=self.cfg.max_query_len, padding="max_length" if self.cfg.pad_max else "longest",
+                                 return_special_tokens_mask=True, return_tensors="pt", truncation=True).to(self.device)   # hipie_img.py:904-909
             ids, mask = tok.input_ids, tok.attention_mask
-            sep = self.tokenizer(".").input_ids[1]
+            sep = int(self.tokenizer(".").input_ids[0, 1])                                           # bert_model.py:68-73
         return self.text_encoder[0]({"input_ids": ids, "attention_mask": mask}, sep=sep)
 
     @torch.no_grad()

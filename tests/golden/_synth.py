@@ -225,7 +225,7 @@ def prompt_tokenizer(tmpdir):
     path = os.path.join(str(tmpdir), "vocab.txt")
     with open(path, "w") as f:
         f.write("\n".join(PROMPT_VOCAB) + "\n")
-    return BertTokenizerFast(vocab_file=path, do_lower_case=True)
+    return BertTokenizerFast(vocab=path, do_lower_case=True)        # transformers 5: `vocab` (vocab_file= is silently ignored)
 
 
 def clip_tokenize(texts, context, vocab):

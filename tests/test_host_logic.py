@@ -1,5 +1,7 @@
 """CPU: host-side logic of the product (no kernel launches): state_dict compatibility with the reference, config,
 preprocessing, chunked text encoder."""
+import os
+
 import pytest
 import torch
 
@@ -451,3 +453,121 @@ def test_inference_compact_equals_host_path_cpu(task, topk):
     got = inference_compact(model, out, batched, topk=topk)
     assert got.shape == want.shape == (3, topk, parallel.PRED_FIELDS)
     assert torch.equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------------ WordPiece tokenizer
+def _wordpiece_vocab(tmp_path):
+    import os
+    import string
+    words = ["person", "bicycle", "car", "motor", "##cycle", "air", "##plane", "traffic", "light", "fire", "hydrant", "stop", "sign", "hot",
+             "dog", "potted", "plant", "tv", "wine", "glass", "hair", "dr", "##ier", "teddy", "bear", "the", "a", "of", "photo", "cafe",
+             "naive", "tooth", "##brush", "##s", "##ing", "##ed", "un", "##able", "sky", "other", "merged", "zebra", "cross", "##ing"]
+    toks = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + list(string.punctuation) + list(string.ascii_lowercase) + list(string.digits)
+    toks += ["##" + c for c in string.ascii_lowercase + string.digits] + ["中", "文"]
+    seen, out = set(), []
+    for t in toks + words:
+        if t not in seen:
+            seen.add(t)
+            out.append(t)
+    path = os.path.join(str(tmp_path), "vocab.txt")
+    with open(path, "w", encoding="utf-8") as f:
+        f.write("\n".join(out) + "\n")
+    return path
+
+
+WORDPIECE_CASES = [
+    "person. bicycle. car. motorcycle. airplane. traffic light. fire hydrant. stop sign. hot dog. potted plant. tv. wine glass. hair drier. teddy bear. toothbrush",
+    "The Café of a naïve ZEBRA-crossing!!  (merged)", "a photo of a dog.", "", "   ", "unknown€symbol and 中文 text", "x" * 120 + " car",
+    "tabs\tand\nnewlines\r\n. end", "İstanbul Ǆ ß ﬁ", "semi;colon:and,comma.dot?", "a.b.c", "sky-other-merged", "don't stop",
+]
+
+
+def _check_tokenizer_equal(own, hf, text, **kw):
+    a = own(text, **kw)
+    b = hf(text, return_offsets_mapping=True, return_tensors="pt", **kw)
+    assert a.input_ids.tolist() == b["input_ids"].tolist(), text
+    assert a.attention_mask.tolist() == b["attention_mask"].tolist(), text
+    n = int(b["attention_mask"][0].sum())
+    assert [tuple(o) for o in a.offsets[0][:n]] == [tuple(o) for o in b["offset_mapping"][0][:n].tolist()], text
+    for c in range(len(text) + 1):
+        try:
+            want = b.char_to_token(c)
+        except Exception:
+            want = "err"
+        if want != "err":
+            assert a.char_to_token(c) == want, (text, c)
+
+
+def test_wordpiece_tokenizer_matches_huggingface(tmp_path):
+    """hipie_amd.tokenizer.BertWordPiece == transformers.BertTokenizerFast on the same vocabulary: ids, masks, offsets,
+    char_to_token for every character, truncation and both paddings (the three call patterns of the reference)."""
+    from transformers import BertTokenizerFast
+    from hipie_amd.tokenizer import BertWordPiece
+    vf = _wordpiece_vocab(tmp_path)
+    own, hf = BertWordPiece(vf), BertTokenizerFast(vocab=vf, do_lower_case=True)
+    for text in WORDPIECE_CASES:
+        _check_tokenizer_equal(own, hf, text)
+    _check_tokenizer_equal(own, hf, WORDPIECE_CASES[0], max_length=16, truncation=True)
+    _check_tokenizer_equal(own, hf, WORDPIECE_CASES[2], max_length=24, padding="max_length", truncation=True)
+    # a batch (forward_text, hipie_img.py:904-909): padding="longest" and "max_length", special-token mask
+    batch = [WORDPIECE_CASES[0], WORDPIECE_CASES[2], WORDPIECE_CASES[1]]
+    for pad, ml in (("longest", 64), ("max_length", 40)):
+        a = own.batch_encode_plus(batch, max_length=ml, padding=pad, truncation=True, return_special_tokens_mask=True)
+        b = hf(batch, max_length=ml, padding=pad, truncation=True, return_special_tokens_mask=True, return_tensors="pt")   # transformers 5 dropped batch_encode_plus
+        assert a.input_ids.tolist() == b["input_ids"].tolist() and a.attention_mask.tolist() == b["attention_mask"].tolist()
+        assert a.special_tokens_mask.tolist() == b["special_tokens_mask"].tolist()
+    assert own(".").input_ids[0, 1] == hf(".").input_ids[1]                       # the separator id BertEncoder's chunker uses
+    # the class-prompt map through the own tokenizer == through HuggingFace's
+    from hipie_amd.prompts import create_queries_and_maps
+    cats = _synth.PROMPT_CATEGORIES
+    assert create_queries_and_maps(cats, own) == create_queries_and_maps(cats, hf)
+
+
+def test_wordpiece_tokenizer_fuzz(tmp_path):
+    from hypothesis import given, settings, strategies as st
+    from transformers import BertTokenizerFast
+    from hipie_amd.tokenizer import BertWordPiece
+    vf = _wordpiece_vocab(tmp_path)
+    own, hf = BertWordPiece(vf), BertTokenizerFast(vocab=vf, do_lower_case=True)
+    alphabet = "abcdeghilnoprstuy ABCXZ.,-()'!?0129\t éïç中"
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.text(alphabet=alphabet, max_size=40))
+    def run(text):
+        _check_tokenizer_equal(own, hf, text)
+    run()
+
+
+def test_test_time_mapper(tmp_path):
+    """hipie_amd.mapper.TestTimeMapper: the is_train == False path of DetrDatasetMapperUni (coco_dataset_mapper_uni.py:453-600)."""
+    import numpy as np
+    from PIL import Image
+    from hipie_amd.mapper import TestTimeMapper
+    from hipie_amd.predictor import resize_shortest_edge_shape
+    from hipie_amd.tokenizer import BertWordPiece
+    tok = BertWordPiece(_wordpiece_vocab(tmp_path))
+    labels = [{"id": 1, "name": "person,child"}, {"id": 2, "name": "invalid_class_id"}, {"id": 3, "name": "traffic light"},
+              {"id": 4, "name": "sky-other-merged"}]
+    m = TestTimeMapper(tok, min_size_test=64, max_size_test=100).register_dataset("toy_pan", labels, thing_class_ids=[0, 1])
+    m.register_dataset("toy_inw", labels)
+    rgb = np.random.RandomState(0).randint(0, 256, (60, 90, 3), dtype=np.uint8)
+    path = os.path.join(str(tmp_path), "img.png")
+    Image.fromarray(rgb).save(path)
+    out = m({"file_name": path, "height": 60, "width": 90, "task": "detection", "dataset_name": "toy_pan", "annotations": [1, 2]})
+    nh, nw = resize_shortest_edge_shape(60, 90, 64, 100)
+    assert (nh, nw) == (64, 96) and out["image"].shape == (3, nh, nw) and out["image"].dtype == torch.uint8
+    assert (out["height"], out["width"]) == (60, 90) and "annotations" not in out
+    assert out["expressions"] == "person,child. traffic light. sky-other-merged"       # invalid_class_id dropped, names cleaned
+    assert out["is_thing"] == {0: False, 1: True, 2: True, 3: False}
+    assert [c["name"] for c in out["open_seg_labels"]] == ["person,child", "traffic light", "sky-other-merged"]
+    pm = out["positive_map_label_to_token"]
+    toks = tok.convert_ids_to_tokens(tok(out["expressions"]).input_ids[0])
+    assert [toks[i] for i in pm[2]] == ["traffic", "light"] and sorted(pm) == [1, 2, 3]
+    assert m({"file_name": path, "task": "detection", "dataset_name": "toy_inw"})["is_thing"] == {0: True, 1: True, 2: True, 3: True}
+    g = m({"file_name": path, "task": "grounding", "expressions": "the person on the left"})
+    assert g["expressions"] == "the person on the left" and g["is_thing"][1] is True and "positive_map_label_to_token" not in g
+    # BGR format flips the channels of what was read; a wrong size in the dataset dict is refused
+    mb = TestTimeMapper(tok, 60, 100, img_format="BGR")
+    assert torch.equal(mb({"file_name": path, "task": "grounding", "expressions": "x"})["image"], torch.as_tensor(rgb[:, :, ::-1].copy()).permute(2, 0, 1))
+    with pytest.raises(ValueError):
+        m({"file_name": path, "height": 61, "width": 90, "task": "grounding", "expressions": "x"})
