@@ -198,6 +198,8 @@ POLICIES = {
     "cand_einsum_h": {"default": S3, "vit_attn_pv": ("u", "h"), "einsum": H2},
     "cand_einsum_sa": {"default": S3, "vit_attn_pv": ("u", "h"), "einsum": ("s", "h")},
     "cand_b": {"default": S3, "vit_attn_pv": ("u", "s"), "bert_attn": H2, "mha_attn": H2, "bi_attn": H2},
+    "cand_b_value_h": {"default": S3, "vit_attn_pv": ("u", "s"), "bert_attn": H2, "mha_attn": H2, "bi_attn": H2, "lin_out": [("value_proj.", "h")]},
+    "cand_b_ffn_h": {"default": S3, "vit_attn_pv": ("u", "s"), "bert_attn": H2, "mha_attn": H2, "bi_attn": H2, "lin_out": [("linear1.", "h")]},
     "cand_b_out_h": {"default": S3, "vit_attn_pv": ("u", "s"), "bert_attn": H2, "mha_attn": H2, "bi_attn": H2, "attn_out": "h"},
     "cand_b_conv_h": {"default": S3, "vit_attn_pv": ("u", "s"), "bert_attn": H2, "mha_attn": H2, "bi_attn": H2, "conv": H2},
     "split3_vit_head_h": {"default": H2, "vit_lin": S3, "vit_attn_qk": S3, "vit_attn_rel": S3, "vit_attn_pv": ("u", "s")},
@@ -230,6 +232,16 @@ def main():
         with region("vit_lin"):
             return real_block(x, sdd, p, heads, window)
     om.vit_block = vit_block
+    # output roundings of named linears (storage type of what a GEMM hands on): policy["lin_out"] = [(parameter-prefix suffix, mode)]
+    real_lin = om.lin
+
+    def lin_named(x, sdd, p):
+        y = real_lin(x, sdd, p)
+        for suffix, mode in Sim.policy.get("lin_out", ()):
+            if p.endswith(suffix):
+                y = rnd(y, mode)
+        return y
+    om.lin = lin_named
     wrap_region(om, "mha", "mha")
     wrap_region(oo, "bi_attention_block", "bi")
     om.ops.bi_attention_block = oo.bi_attention_block

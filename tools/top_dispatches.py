@@ -14,6 +14,7 @@ t0, t1 = int(rows[0]["Start_Timestamp"]), int(rows[-1]["End_Timestamp"])
 if frac >= 1.0:
     # frac = K >= 1: the window is the last K forwards, located by the 24 global-attention launches each one issues
     marks = [int(r["Start_Timestamp"]) for r in rows if ("vit_attn_sp_kernel" in r["Kernel_Name"]) or
+             ("vit_attn_split_kernel" in r["Kernel_Name"] and ("Li2ELi8E" in r["Kernel_Name"] or "2, 8," in r["Kernel_Name"])) or
              ("flash_attn_kernel" in r["Kernel_Name"] and "Li80ELi2E" in r["Kernel_Name"])]
     k = int(frac) * 24
     cut = marks[-k] - 1500000 if len(marks) >= k else t0          # minus ~1.5 ms: the text encoder / patch embed before it
