@@ -233,9 +233,9 @@ def main():
                          "shipped depths; fast: single-fp16 operands (out of tolerance); parity: fp32 library GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-leg", action="store_true", help="skip parity_err and the fast-policy timing (rank 0, N = 1)")
-    ap.add_argument("--graph", action="store_true", help="capture the forward once into a hipGraph and replay it (experimental: "
-                    "after the launch-count reductions the eager path is no longer host-bound, and whole-model replay "
-                    "showed an unexplained GPU memory fault -- DESIGN.md section 9)")
+    ap.add_argument("--graph", action="store_true", help="capture the forward once into a hipGraph and replay it (same rate as "
+                    "eager: the step is GPU-bound; the round-2 replay fault was torch.topk, replaced by hipie_topk -- DESIGN.md "
+                    "section 9)")
     ap.add_argument("--no-gemm-table", action="store_true", help="do not load the committed TunableOp table "
                     "(hipie_amd/tuning/*.csv: the hipBLASLt solution picked per ViT-H linear shape; library plumbing)")
     ap.add_argument("--timed-only", action="store_true", help="stop right after the timed region (for kernel traces: no "

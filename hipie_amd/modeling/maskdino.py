@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from .transformer import (MLP, DeformableTransformerDecoderLayer, DeformableTransformerEncoderLayer, FeatureResizer, geo_cached,
+from .transformer import (MLP, _select_topk, DeformableTransformerDecoderLayer, DeformableTransformerEncoderLayer, FeatureResizer, geo_cached,
                           PConv2d, PGroupNorm, PLayerNorm, PLinear, PositionEmbeddingSine, _get_clones, encoder_reference_points,
                           gen_encoder_output_proposals, level_tensors,
                           batched_decoder_values, decoder_box_refine, decoder_fast_path, decoder_query_pos)
@@ -208,7 +208,7 @@ class MaskDINODecoder(nn.Module):
         if self.pinned_topk is not None:
             topk = self.pinned_topk.to(src.device)
         else:
-            topk = torch.topk(cls_un.max(-1)[0], self.num_queries, dim=1)[1]
+            topk = _select_topk(cls_un.max(-1)[0], self.num_queries)
         self.last_topk = topk
         ref_un = torch.gather(coord_un, 1, topk.unsqueeze(-1).repeat(1, 1, 4))
         tgt = torch.gather(om, 1, topk.unsqueeze(-1).repeat(1, 1, self.hidden_dim))

@@ -781,7 +781,7 @@ class DeformableTransformerVLDINO(nn.Module):
         if self.pinned_topk is not None:
             topk = self.pinned_topk.to(src.device)
         else:
-            topk = torch.topk(enc_cls[..., 0], self.two_stage_num_proposals, dim=1)[1]
+            topk = _select_topk(enc_cls[..., 0], self.two_stage_num_proposals)
         self.last_topk = topk
         ref = torch.gather(enc_coord, 1, topk.unsqueeze(-1).repeat(1, 1, 4)).sigmoid()
         tgt = self.tgt_embed.weight[None].repeat(bs, 1, 1)
@@ -791,6 +791,16 @@ class DeformableTransformerVLDINO(nn.Module):
         init_ref = ref
         hs, inter_refs = self.decoder(tgt.float(), ref.float(), memory, spatial_shapes, level_start_index, valid_ratios, layer_mask)
         return hs, memory, init_ref, inter_refs, enc_cls, enc_coord, language_dict_features, shapes_list
+
+
+def _select_topk(scores, k):
+    """indices of the k largest scores per row, descending (deformable_transformer_dino.py:222-230).  On the device this is hipie_topk: one
+    launch and hipGraph-replay safe -- torch.topk is 12 launches here and faults under graph replay."""
+    scores = scores.float().contiguous()
+    if not ops.topk_ok(scores, k):
+        raise RuntimeError("two-stage selection: k=%d of %s scores on %s is outside hipie_topk's range (device tensor, k <= 1024)"
+                           % (k, tuple(scores.shape), scores.device))
+    return ops.topk(scores, k)
 
 
 # --------------------------------------------------------------------------- heads

@@ -805,3 +805,22 @@ def split_linear(x, owner, key, weight, bias=None, act=ACT_NONE, out_fmt=F32, re
     if N != w.shape[0]:
         out = out[..., :(2 * N if out_fmt == HL8 else N)].contiguous()
     return out
+
+
+@_timed("topk")
+def topk(x, k, want_values=False):
+    """row-wise top-k of a (rows, n) fp32 device tensor (row stride may exceed n), k <= 1024 -> indices (rows, k) int64 in descending value
+    order (ties: ascending index) [, values].  hipie_topk: one launch, hipGraph-replay safe (torch.topk on this stack is neither)."""
+    lib = _lib.load()
+    if x.dim() != 2 or x.dtype != torch.float32 or not x.is_cuda or x.stride(1) != 1:
+        raise RuntimeError("topk: (rows, n) fp32 device tensor with contiguous rows expected")
+    rows, n = x.shape
+    idx = torch.empty(rows, k, dtype=torch.int64, device=x.device)
+    val = torch.empty(rows, k, dtype=torch.float32, device=x.device) if want_values else None
+    rc = lib.hipie_topk(x.data_ptr(), x.stride(0), rows, n, int(k), idx.data_ptr(), None if val is None else val.data_ptr(), _stream())
+    _lib.check(rc, "hipie_topk")
+    return (idx, val) if want_values else idx
+
+
+def topk_ok(x, k):
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and 0 < k <= min(1024, x.shape[1])

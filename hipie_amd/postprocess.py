@@ -237,7 +237,11 @@ def _instances_on_device(model, out, batched_inputs, do_postprocess=True):
     prob_k = torch.gather(prob, 1, keep_l[:, :, None].expand(-1, -1, C))
     prob_k = torch.where(rows_ok[:, :, None], prob_k, prob_k.new_tensor(-2.0))
     K = min(max_num_inst, Q * C)
-    top_v, top_i = torch.topk(prob_k.flatten(1), K, dim=1)
+    flat = prob_k.flatten(1)
+    if flat.is_cuda and K <= 1024:
+        top_i, top_v = ops.topk(flat.float().contiguous(), K, want_values=True)      # one launch; ties in index order
+    else:
+        top_v, top_i = torch.topk(flat, K, dim=1)                                    # host-side unit tests of this index logic / DETECTIONS_PER_IMAGE > 1024
     top_row, labels = torch.div(top_i, C, rounding_mode="floor"), top_i % C
     top_q = torch.gather(keep_l, 1, top_row)                                     # fg query index of every instance
     boxes = _cxcywh_to_xyxy(torch.gather(box_pred, 1, top_q[:, :, None].expand(-1, -1, 4)))

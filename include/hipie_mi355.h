@@ -396,6 +396,14 @@ int hipie_vit_attn_split(const void* qkv, const void* tab_h, const void* tab_w, 
  * fp16 elements >= 2K): the generic producer of split operands (the LayerNorm / GEMM epilogues emit HL8 directly). */
 int hipie_to_hl8(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int K, int x_dtype, float scale, void* stream);
 
+/*
+ * Row-wise top-k of fp32 scores, k <= 1024: idx_out (rows, k) int64 in descending value order (ascending index among equal values;
+ * NaN sorts as the largest value), val_out (rows, k) f32 or NULL.  One launch, hipGraph-replay safe.
+ * Replaces: torch.topk in the two-stage query selections (models/deformable_detr/deformable_transformer_dino.py:222-230, 900 of Nv;
+ * models/maskdino/transformer_decoder/maskdino_decoder.py:413-426, 300 of Nv) and in HIPIE_IMG.inference (hipie_img.py:640-648).
+ */
+int hipie_topk(const float* x, int64_t row_stride, int rows, int n, int k, int64_t* idx_out, float* val_out, void* stream);
+
 /* device-side self-test helpers used by tests/ to pin the MFMA / LDS-transpose lane layouts this library assumes.
  *   which 0: D = A(32x16) . B(16x32) with v_mfma_f32_32x32x16_bf16, operands loaded with the layouts documented in
  *            csrc/mfma.h; out (32,32) f32.   which 1: ds_read_b64_tr_b16 of a (64,16) bf16 tile; out (64,4) f32 per lane.

@@ -927,3 +927,64 @@ def test_hl8_saturates_instead_of_nan():
     back = ops.hl8_unpack(h)[0].cpu()
     assert back[0] == 65504.0 and back[1] == -65504.0 and back[3] == 65504.0 and abs(float(back[7]) - 123.456) < 1e-4
     assert torch.equal(h, ops.hl8_pack(x))
+
+
+# --------------------------------------------------------------------------- top-k
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,n,k", [(8, 21760, 900), (8, 21760, 300), (2, 340, 20), (1, 72000, 100), (3, 1000, 1000), (2, 1025, 1024),
+                                      (1, 5, 5), (4, 37485, 900)])
+def test_topk_matches_torch(rows, n, k):
+    """hipie_topk vs torch.topk (CPU): identical values, identical indices (distinct scores), descending order."""
+    from hipie_amd import ops
+    g = torch.Generator().manual_seed(rows * 7 + n + k)
+    x = torch.randn(rows, n, generator=g) * 3.0
+    x[0, : min(n, 7)] = torch.tensor([float("inf"), -float("inf"), 0.0, -0.0, 1e-38, -1e-38, 65504.0])[: min(n, 7)]
+    want_v, want_i = torch.topk(x, k, dim=1)
+    idx, val = ops.topk(x.cuda(), k, want_values=True)
+    torch.cuda.synchronize()
+    assert torch.equal(val.cpu(), want_v)
+    distinct = torch.ones(rows, k, dtype=torch.bool)
+    distinct[:, 1:] &= want_v[:, 1:] != want_v[:, :-1]
+    distinct[:, :-1] &= want_v[:, 1:] != want_v[:, :-1]
+    assert torch.equal(idx.cpu()[distinct], want_i[distinct])
+    assert torch.equal(torch.gather(x, 1, idx.cpu()), want_v)
+
+
+@pytest.mark.gpu
+def test_topk_ties_take_the_lowest_indices_in_order():
+    from hipie_amd import ops
+    x = torch.zeros(2, 5000)
+    x[0, 100:110] = 1.0                      # 10 above, the remaining 20 winners come from the tie at 0 -> indices 0..19
+    x[1] = 2.5                               # a constant row: indices 0..k-1
+    idx = ops.topk(x.cuda(), 30).cpu()
+    assert idx[0].tolist() == list(range(100, 110)) + list(range(20))
+    assert idx[1].tolist() == list(range(30))
+    # a strided view (row stride > n) and NaN as the largest value, as torch orders it
+    y = torch.randn(4, 3000)
+    y[2, 17] = float("nan")
+    yv = y.cuda()[:, :2000]
+    got = ops.topk(yv, 50).cpu()
+    want = torch.topk(y[:, :2000], 50, dim=1)[1]
+    assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+def test_topk_replays_in_a_hip_graph():
+    """the property torch.topk lacks here: 200 replays of a captured selection on changing scores."""
+    from hipie_amd import ops
+    x = torch.randn(8, 21760, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ops.topk(x, 900)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=s):
+            idx = ops.topk(x, 900)
+    for it in range(200):
+        x.copy_(torch.randn(8, 21760, device="cuda"))
+        gr.replay()
+        if it % 50 == 49:
+            torch.cuda.synchronize()
+            assert torch.equal(idx.cpu(), torch.topk(x.cpu(), 900, dim=1)[1])
+    with pytest.raises(RuntimeError):
+        ops.topk(x, 1025)
