@@ -175,6 +175,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
     // every wave at the barrier (measured: one DMA per sub-step over the whole stage cost ~15 % of the split kernel's rate)
     constexpr int DMA_BY = SPLIT ? 4 : 6;                        // sub-steps that carry DMA instructions
     constexpr int PER = (NI + DMA_BY - 1) / DMA_BY;
+    frag cx[2][2];               // VAR 2 (fp32 A rows): the k-step's A fragments split in registers, [hi | lo][token tile]
 #pragma unroll
     for (int s = 0; s < SUB; ++s) {
       const int ks = s / NJ, j = s % NJ;
@@ -182,11 +183,26 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
         if ((s + 1) % NJ == 0) load_x(ks + 1);
         load_w(s + 1);
       }
+      if (VAR == 2 && j == 0) {
+        // the two 16-byte chunks of a group hold x0..x3 / x4..x7 as fp32 (the same 32 bytes an HL8 group takes): split them here
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const f32x4 a = __builtin_bit_cast(f32x4, xa[ks & 1][0][t]), b = __builtin_bit_cast(f32x4, xa[ks & 1][1][t]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            f16_t hh, ll;
+            hl_split(a[e], hh, ll);
+            cx[0][t][e] = hh; cx[1][t][e] = ll;
+            hl_split(b[e], hh, ll);
+            cx[0][t][4 + e] = hh; cx[1][t][4 + e] = ll;
+          }
+        }
+      }
       const frag wh = wa[s & 1][0];
-      const frag xh0 = xa[ks & 1][0][0], xh1 = xa[ks & 1][0][1];
+      const frag xh0 = (VAR == 2) ? cx[0][0] : xa[ks & 1][0][0], xh1 = (VAR == 2) ? cx[0][1] : xa[ks & 1][0][1];
       if (SPLIT) {
         const frag wl = wa[s & 1][1];
-        const frag xl0 = xa[ks & 1][1][0], xl1 = xa[ks & 1][1][1];
+        const frag xl0 = (VAR == 2) ? cx[1][0] : xa[ks & 1][1][0], xl1 = (VAR == 2) ? cx[1][1] : xa[ks & 1][1][1];
         acc[j][0] = Mfma32<f16_t>::mma(wl, xh0, acc[j][0]);
         acc[j][1] = Mfma32<f16_t>::mma(wl, xh1, acc[j][1]);
         acc[j][0] = Mfma32<f16_t>::mma(wh, xl0, acc[j][0]);
@@ -348,11 +364,14 @@ extern "C" int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw
                           void* out, int64_t ldo, const int32_t* out_row, int M, int N, int K, int in_fmt, int out_fmt, int act, float alpha,
                           float oscale, void* stream) {
   HIPIE_REQUIRE(A && W && out, "gemm: null pointer");
-  HIPIE_REQUIRE(in_fmt == HIPIE_F16 || in_fmt == HIPIE_HL8, "gemm: operand format %d (HIPIE_F16 | HIPIE_HL8)", in_fmt);
+  HIPIE_REQUIRE(in_fmt == HIPIE_F16 || in_fmt == HIPIE_HL8 || in_fmt == HIPIE_F32, "gemm: operand format %d (HIPIE_F16 | HIPIE_HL8 | HIPIE_F32)",
+                in_fmt);
   HIPIE_REQUIRE(out_fmt == HIPIE_F32 || out_fmt == HIPIE_F16 || out_fmt == HIPIE_HL8, "gemm: output format %d", out_fmt);
   HIPIE_REQUIRE(act >= 0 && act <= 2, "gemm: activation %d (0 none, 1 gelu, 2 relu)", act);
   HIPIE_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0, "gemm: M=%d N=%d K=%d (N must be a multiple of 8)", M, N, K);
-  const bool split = in_fmt == HIPIE_HL8;
+  const bool a_f32 = in_fmt == HIPIE_F32;       // A rows are plain fp32 (lda in fp32 elements), split in the kernel; W is HL8
+  const bool split = in_fmt == HIPIE_HL8 || a_f32;
+  if (a_f32) lda *= 2;                          // from here on in fp16 units like the HL8 form: the same bytes per row
   const int kq = split ? 32 : 64;               // elements per 128-byte k tile
   HIPIE_REQUIRE(K % kq == 0, "gemm: K=%d must be a multiple of %d", K, kq);
   const int epr = split ? 2 * K : K;            // fp16 elements per operand row
@@ -375,6 +394,7 @@ extern "C" int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw
   { const char* e = getenv("HIPIE_GEMM_VARIANT"); const int v = e ? atoi(e) : 0;
     if (split && wide && v == 1) return launch_gemm<320, true, 1>(p, st); }
 #endif
+  if (a_f32) return wide ? launch_gemm<320, true, 2>(p, st) : launch_gemm<256, true, 2>(p, st);
   if (split) return wide ? launch_gemm<320, true>(p, st) : launch_gemm<256, true>(p, st);
   return wide ? launch_gemm<320, false>(p, st) : launch_gemm<256, false>(p, st);
 }

@@ -53,8 +53,11 @@ __device__ __forceinline__ void vs_dma16(const char* sbase, unsigned int voff, u
 }
 
 // HD: head dim (80 | 64);  NB: 32-slot key blocks per tile;  R: key rows of the token grid per tile;  KW: compile-time grid width when R > 1
-template <int HD, int NB, int WAVES, int R, int KW>
-__global__ __launch_bounds__(WAVES * 64, 2) void vit_attn_split_kernel(const VSParams p) {
+// BHC: 0 = the bias_h of every key row is computed up front ([kh][queries] floats of LDS); > 0 = it is recomputed per chunk of BHC
+// key rows (<= 31: a wave's 32 queries span at most two query rows, so 32 consecutive table rows cover a chunk) -- the form for grids
+// wider than 64 (the 84x84 grid of the 1344-pixel configuration), whose 96-slot double-buffered tiles leave no room for kh rows.
+template <int HD, int NB, int WAVES, int R, int KW, int BHC>
+__global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_kernel(const VSParams p) {
   typedef f16_t T;
   constexpr int KT = 32 * NB;                  // key slots per tile
   constexpr int KS = HD / 16;                  // k16 steps of QK^T
@@ -71,6 +74,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void vit_attn_split_kernel(const VSP
   constexpr int QW = WAVES * 32;
   constexpr int NT = WAVES * 64;
   static_assert(R == 1 || (KW > 0 && R * KW <= KT), "R key rows of KW keys must fit the tile");
+  static_assert(BHC == 0 || (R == 1 && BHC <= 31), "chunked bias_h: one key row per tile, at most 31 rows per chunk");
   static_assert(KSTR % 8 == 0 && VSTR % 8 == 0, "plane rows are whole 16-byte chunks");
   typedef Mfma32<T>::frag frag;
   typedef Mfma32<T>::half_frag hfrag;
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void vit_attn_split_kernel(const VSP
   extern __shared__ __attribute__((aligned(1024))) char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   constexpr size_t TILE_BYTES = ((size_t)2 * BUF * sizeof(T) > (size_t)WAVES * 4096) ? (size_t)2 * BUF * sizeof(T) : (size_t)WAVES * 4096;
-  float* bh_all = reinterpret_cast<float*>(smem_raw + TILE_BYTES);            // [kh][QW], log2 domain
+  float* bh_all = reinterpret_cast<float*>(smem_raw + TILE_BYTES);            // [kh | BHC][QW], log2 domain
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void vit_attn_split_kernel(const VSP
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const T* ap = tab + (long)min(32 * jb + li, rows - 1) * (2 * HD) + 16 * hi;
+      const T* ap = tab + (long)min(32 * jb + li, rows - 1) * (2 * HD) + 16 * hi;        // (vs_table_rows below: the same at any start row)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const frag th = *reinterpret_cast<const frag*>(ap + 32 * ks), tl = *reinterpret_cast<const frag*>(ap + 32 * ks + 8);
@@ -150,16 +154,40 @@ __global__ __launch_bounds__(WAVES * 64, 2) void vit_attn_split_kernel(const VSP
         }
       __syncthreads();
     }
-    for (int jb = 0; jb < nbh; ++jb) {
-      const f32x16 acc = table_block(p.tab_h, 2 * kh - 1, jb);
+    if (BHC == 0) {
+      for (int jb = 0; jb < nbh; ++jb) {
+        const f32x16 acc = table_block(p.tab_h, 2 * kh - 1, jb);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ky = qy + kh - 1 - (32 * jb + crow(r, hi));
-        if (ky >= 0 && ky < kh) bh_all[ky * QW + wave * 32 + li] = acc[r];
+        for (int r = 0; r < 16; ++r) {
+          const int ky = qy + kh - 1 - (32 * jb + crow(r, hi));
+          if (ky >= 0 && ky < kh) bh_all[ky * QW + wave * 32 + li] = acc[r];
+        }
       }
     }
     __syncthreads();             // every wave is done with its stage before the tile buffers are filled
   }
+  // chunked bias_h: rows [t0, t0 + BHC) of this wave's 32 queries from the 32 table rows j0 .. j0 + 31, j0 = (first query row of the wave)
+  // + kh - 1 - (t0 + BHC - 1); a wave writes and reads only its own 32 columns of bh_all, LDS operations of a wave execute in order
+  const int qy0 = __builtin_amdgcn_readfirstlane(qy);
+  auto bias_h_chunk = [&](const int t0) {
+    const int j0 = qy0 + kh - 1 - (t0 + BHC - 1);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const T* ap = p.tab_h + (long)min(max(j0 + li, 0), 2 * kh - 2) * (2 * HD) + 16 * hi;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const frag th = *reinterpret_cast<const frag*>(ap + 32 * ks), tl = *reinterpret_cast<const frag*>(ap + 32 * ks + 8);
+      acc = Mfma32<T>::mma(tl, qh[ks], acc);
+      acc = Mfma32<T>::mma(th, ql[ks], acc);
+      acc = Mfma32<T>::mma(th, qh[ks], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ky = qy + kh - 1 - (j0 + crow(r, hi));
+      if (ky >= t0 && ky < t0 + BHC && ky < kh) bh_all[(ky - t0) * QW + wave * 32 + li] = acc[r];
+    }
+  };
 
   // ---- tile streaming by LDS-DMA.  Block j of a tile image: plane = K_hi, K_lo, V_hi, V_lo; chunk c = 64 * (block in plane) + lane ->
   //      plane row c / (K|V)CH, column c % (K|V)CH; columns >= CPR are padding (never read for K; they feed the discarded d rows of
@@ -214,7 +242,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void vit_attn_split_kernel(const VSP
     const T* Vh = Kh + 2 * KPL;
     const T* Vl = Vh + VPL;
     const bool more = t + 1 < nt;
-    float bh0 = bh_all[(R * t) * QW + wave * 32 + li], bh1 = 0.f;
+    if (BHC > 0 && t % (BHC > 0 ? BHC : 1) == 0) bias_h_chunk(t);
+    float bh0 = bh_all[(BHC > 0 ? t % (BHC > 0 ? BHC : 1) : R * t) * QW + wave * 32 + li], bh1 = 0.f;
     if (R > 1) bh1 = (R * t + 1 < kh) ? bh_all[(R * t + 1) * QW + wave * 32 + li] : -INFINITY;
 
     // ---- S^T = K . Q'^T + bias_w (three products per k-step); the fragments of k-step ks + 1 are requested before the MFMAs of ks;
@@ -358,7 +387,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void vit_attn_split_kernel(const VSP
   }
 }
 
-template <int HD, int NB, int WAVES, int R, int KW>
+template <int HD, int NB, int WAVES, int R, int KW, int BHC = 0>
 static int launch_vs(VSParams& p, hipStream_t st) {
   constexpr int KT = 32 * NB, DB = (HD + 31) / 32;
   constexpr int KSTR = HD + 8, VSTR = (DB * 32 == 96 || DB * 32 == 32) ? DB * 32 : DB * 32 + 32;
@@ -366,12 +395,12 @@ static int launch_vs(VSParams& p, hipStream_t st) {
   size_t lds = (size_t)2 * (2 * KBLK + 2 * VBLK) * 1024;
   const size_t stage = (size_t)WAVES * 32 * 32 * sizeof(float);
   if (lds < stage) lds = stage;
-  lds += (size_t)p.kh * WAVES * 32 * sizeof(float);
+  lds += (size_t)(BHC > 0 ? BHC : p.kh) * WAVES * 32 * sizeof(float);
   if (lds > 160 * 1024) return set_err(HIPIE_EINVAL, "vit_attn(split): %zu bytes of LDS needed (grid %dx%d) > 160 KiB", lds, p.kh, p.kw);
   p.nqt = (p.N + WAVES * 32 - 1) / (WAVES * 32);
   p.swz = ((p.B * p.H) % 8 == 0) ? 1 : 0;
   const unsigned grid = (unsigned)(p.nqt * p.B * p.H);
-  auto kern = vit_attn_split_kernel<HD, NB, WAVES, R, KW>;
+  auto kern = vit_attn_split_kernel<HD, NB, WAVES, R, KW, BHC>;
   if (lds > 64 * 1024) {
     static size_t lds_set[64] = {0};
     int dev = 0;
@@ -391,7 +420,8 @@ static int dispatch_vs(VSParams& p, hipStream_t st) {
   if (p.kw <= 32) return launch_vs<HD, 1, 4, 1, 0>(p, st);
   if (p.kw <= 64 && p.kh <= 64) return launch_vs<HD, 2, 8, 1, 0>(p, st);
   if (p.kw <= 64) return launch_vs<HD, 2, 4, 1, 0>(p, st);
-  return set_err(HIPIE_EINVAL, "vit_attn(split): token grids wider than 64 are not supported (got %dx%d)", p.kh, p.kw);
+  if (p.kw <= 96) return launch_vs<HD, 3, 8, 1, 0, 16>(p, st);                // 84x84: the 1344-pixel configuration
+  return set_err(HIPIE_EINVAL, "vit_attn(split): token grids wider than 96 are not supported (got %dx%d)", p.kh, p.kw);
 }
 
 }  // namespace hipie

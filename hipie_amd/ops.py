@@ -700,19 +700,23 @@ def gemm(a, w, bias=None, resid=None, out_fmt=F32, act=ACT_NONE, alpha=1.0, osca
          out_rows=None):
     """out = ((act(alpha * a . w^T + bias)) + resid) * oscale on hipie_gemm.
     a (..., K) fp16 and w (N, K) fp16 (one product), or both HL8: a (..., 2K), w (N, 2K) fp16 (three products, fp32-class);
-    `split` tells which (default: inferred -- pass it when K is ambiguous).  a may be a row-strided 2-d view.  bias (N) f32,
+    `split` tells which (default: inferred -- pass it when K is ambiguous).  With split=True a may also be PLAIN fp32 (..., K) rows
+    (16-byte aligned): the kernel splits them after the LDS read -- no hipie_to_hl8 launch.  a may be a row-strided 2-d view.  bias (N) f32,
     resid (..., N) f32.  out_fmt F32 | F16 | HL8 -> (..., N) f32 / f16 or (..., 2N) fp16 HL8."""
     lib = _lib.load()
-    if a.dtype != torch.float16 or w.dtype != torch.float16 or not a.is_cuda:
-        raise RuntimeError("gemm: operands must be fp16 (plain or HL8) device tensors")
+    a_f32 = a.dtype == torch.float32 and bool(split)
+    if (a.dtype != torch.float16 and not a_f32) or w.dtype != torch.float16 or not a.is_cuda:
+        raise RuntimeError("gemm: operands must be fp16 (plain or HL8) device tensors (a may be fp32 against HL8 weights)")
     if split is None:
         raise RuntimeError("gemm: say split=True (HL8 operands) or split=False (plain fp16)")
     N = w.shape[0]
     Kw = w.shape[1] // 2 if split else w.shape[1]
     lead = a.shape[:-1]
     a2 = a if a.dim() == 2 else a.reshape(-1, a.shape[-1])
-    if a2.stride(-1) != 1 or a2.shape[-1] != w.shape[1]:
+    if a2.stride(-1) != 1 or a2.shape[-1] != (Kw if a_f32 else w.shape[1]):
         raise RuntimeError("gemm: a rows must be contiguous and as long as w rows (%s vs %s)" % (tuple(a.shape), tuple(w.shape)))
+    if a_f32 and (a2.stride(0) % 4 or a2.data_ptr() % 16):
+        raise RuntimeError("gemm: fp32 a rows must be 16-byte aligned")
     M = a2.shape[0]
     if out_row is not None:
         if out is None:
@@ -736,7 +740,7 @@ def gemm(a, w, bias=None, resid=None, out_fmt=F32, act=ACT_NONE, alpha=1.0, osca
         raise RuntimeError("gemm: bias must be contiguous fp32")
     rc = lib.hipie_gemm(a2.data_ptr(), a2.stride(0), _chk(w, "w"), w.shape[1], None if bias is None else bias.data_ptr(),
                         None if r2 is None else r2.data_ptr(), 0 if r2 is None else r2.stride(0), o2.data_ptr(), o2.stride(0),
-                        None if out_row is None else out_row.data_ptr(), M, N, Kw, HL8 if split else F16, int(out_fmt), int(act), float(alpha), float(oscale), _stream())
+                        None if out_row is None else out_row.data_ptr(), M, N, Kw, F32 if a_f32 else (HL8 if split else F16), int(out_fmt), int(act), float(alpha), float(oscale), _stream())
     _lib.check(rc, "hipie_gemm")
     return out
 
@@ -758,9 +762,10 @@ def vit_attn_split(qkv, tab_h, tab_w, grid_hw, heads):
 
 
 def vit_attn_split_ok(grid_hw, hd):
-    """geometry hipie_vit_attn_split covers: head_dim 64 / 80, 14-wide windows or token grids up to 64 x 64."""
+    """geometry hipie_vit_attn_split covers: head_dim 64 / 80, 14-wide windows or token grids up to 96 wide / 160 high (64 x 64 at
+    1024^2, 84 x 84 at 1344^2)."""
     gh, gw = grid_hw
-    return hd in (64, 80) and ((gw == 14 and gh <= 96) or (gw <= 64 and gh <= 64))
+    return hd in (64, 80) and ((gw == 14 and gh <= 96) or (gw <= 96 and gh <= 160))
 
 
 # ---- split ("fp32-class") linears: cached HL8 copies of (derived) weights + the GEMM call ----------------------------------
@@ -796,7 +801,12 @@ def split_linear(x, owner, key, weight, bias=None, act=ACT_NONE, out_fmt=F32, re
     if params is None:
         params = [weight] + ([bias] if bias is not None else [])
     w, b, N = split_weight(owner, key, params, weight_fn or (lambda: weight), bias_fn or ((lambda: bias) if bias is not None else None))
-    a = x if x_hl8 else to_hl8(x if x.dtype in (torch.float32, torch.float16) else x.float())
+    if x_hl8:
+        a = x
+    elif x.dtype == torch.float32 and x.stride(-1) == 1 and x.data_ptr() % 16 == 0 and (x.dim() < 2 or x.stride(-2) % 4 == 0):
+        a = x if x.dim() <= 2 or x.is_contiguous() else x.contiguous()      # fp32 rows: split inside the GEMM
+    else:
+        a = to_hl8(x if x.dtype in (torch.float32, torch.float16) else x.float())
     if out is not None or out_row is not None:
         if N != w.shape[0]:
             raise RuntimeError("split_linear: in-place / row-mapped outputs need N % 8 == 0")

@@ -368,6 +368,9 @@ int hipie_box_refine(const void* delta, const float* ref, float* out, int64_t n,
  *   in_fmt   HIPIE_F16: A (M, K) and W (N, K) fp16, one MFMA per product;
  *            HIPIE_HL8: both operands split fp16 (rows of 2K fp16); the product is W_lo.A_hi + W_hi.A_lo + W_hi.A_hi with fp32
  *            accumulation = fp32-class results (every fp16 x fp16 product is exact in fp32; the dropped lo x lo term is 2^-22).
+ *            HIPIE_F32: A (M, K) plain fp32 rows (lda in fp32 elements, a multiple of 4) against an HL8 W: the kernel splits the A
+ *            fragments into hi / lo after the LDS read (an fp32 group of 8 takes the 32 bytes of an HL8 group) -- the same results
+ *            as hipie_to_hl8 followed by the HL8 form, bit for bit, without the conversion launch.
  *   lda, ldw row strides in fp16 elements (multiples of 8);  K a multiple of 64 (F16) / 32 (HL8);  N a multiple of 8
  *   bias     (N) f32 or NULL;   resid (M, N) f32 with row stride ldr, or NULL
  *   epilogue y = alpha * acc + bias;  act 1: exact-erf GELU(y), 2: ReLU(y);  y = (y + resid) * oscale

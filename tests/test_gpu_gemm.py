@@ -205,3 +205,23 @@ def test_gemm_row_map_and_in_place_residual():
     got = stream.clone()
     ops.gemm(ops.hl8_pack(a), ops.hl8_pack(w), bias, resid=got, out=got, out_row=out_src, split=True)
     assert rel_err(got.cpu(), want.float().cpu()) < 3e-6
+
+
+@gpu
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (1000, 1280, 1280), (64, 2048, 256), (7200, 264, 256)])
+def test_gemm_fp32_rows_equal_the_converted_form_bit_for_bit(M, N, K):
+    """in_fmt HIPIE_F32: the A rows are split inside the kernel -- identical to hipie_to_hl8 + the HL8 form, including a strided view,
+    values beyond the fp16 range (saturated) and fp16-subnormal remainders."""
+    from hipie_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + 2 * N + K)
+    wide = torch.randn(M, K + 64, device="cuda", generator=g) * 2.0
+    a = wide[:, 32:32 + K]                                   # row stride K + 64, 128-byte offset
+    a[0, :4] = torch.tensor([7e4, -1e5, 1e-3, 65504.0], device="cuda")
+    w = ops.hl8_pack(torch.randn(N, K, device="cuda", generator=g) * (K ** -0.5))
+    bias = torch.randn(N, device="cuda", generator=g)
+    want = ops.gemm(ops.to_hl8(a), w, bias, split=True, act=ops.ACT_RELU)
+    got = ops.gemm(a, w, bias, split=True, act=ops.ACT_RELU)
+    assert torch.equal(got, want)
+    want_h = ops.gemm(ops.to_hl8(a), w, bias, split=True, out_fmt=ops.HL8)
+    got_h = ops.gemm(a, w, bias, split=True, out_fmt=ops.HL8)
+    assert torch.equal(got_h, want_h)

@@ -791,7 +791,7 @@ def test_decoder_heads_fused(dt, tol):
 
 
 # ------------------------------------------------------------------------------------------------ split-fp16 ("HL8") kernels
-@pytest.mark.parametrize("name", ["window14", "global16", "global64", "global_rect"])
+@pytest.mark.parametrize("name", ["window14", "global16", "global64", "global_rect", "global84"])
 def test_vit_attention_split_golden(name):
     """hipie_vit_attn_split on the reference-generated cases, fed the UNROUNDED fp32 qkv / tables as HL8 pairs: vs the fp32 oracle
     (the only 16-bit rounding left is the probability operand: 3e-4) and, through the projection, vs the reference golden."""
@@ -827,7 +827,10 @@ def test_vit_attention_split_golden(name):
     (2, 40, 64, 8, 64),          # ViT-B/L head dim, fewer rows than columns, batch/head swizzle on
     (3, 14, 14, 5, 80),          # windows: 7-wave workgroups, odd batch*heads (no swizzle)
     (2, 7, 14, 2, 80),           # odd number of key rows with two rows per tile (ragged last tile)
-    (1, 33, 50, 3, 64)])
+    (1, 33, 50, 3, 64),
+    (1, 84, 84, 2, 80),          # the 1344-pixel configuration: 96-slot tiles, bias_h recomputed per chunk of 16 key rows
+    (2, 37, 70, 4, 64),          # wider than 64, token count not a multiple of the 256-query workgroup, chunk boundary inside
+    (1, 70, 64, 1, 80)])         # 64 wide, more than 64 rows: the 4-wave two-block variant
 def test_vit_attention_split_against_materialised_scores(B, gh, gw, heads, hd):
     """the reference's own formulation with the (N x N) score tensor materialised in fp64 on the device, random fp32 operands with
     LARGE logits (|q.k| up to ~25: a single-fp16 q or k would move the probabilities by 1e-2)."""
