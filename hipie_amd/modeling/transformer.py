@@ -358,10 +358,13 @@ class BiMultiHeadAttention(nn.Module):
         L = l.shape[1]
         H, hd, dt = self.num_heads, self.head_dim, self.attn_dtype
         wq, bq = self._scaled_q()                              # v_proj with the 1/sqrt(head_dim) folded in: no (B, Nv, 2048) multiply pass
-        q = _lin(self, "q_scaled", v, wq, bq).to(dt).view(B, Nv, H, hd)
-        k = self.l_proj(l).to(dt).view(B, L, H, hd)
-        vv = self.values_v_proj(v).to(dt).view(B, Nv, H, hd)
-        vl = self.values_l_proj(l).to(dt).view(B, L, H, hd)
+        # split policy: the GEMM epilogue rounds to the attention operand dtype itself (bit-identical to fp32 out + .to(fp16), minus
+        # a 178M-element cast pass per visual projection)
+        of = ops.F16 if (getattr(self, "split", False) and dt == torch.float16) else ops.F32
+        q = _lin(self, "q_scaled", v, wq, bq, out_fmt=of).to(dt).view(B, Nv, H, hd)
+        k = self.l_proj(l, out_fmt=of).to(dt).view(B, L, H, hd)
+        vv = self.values_v_proj(v, out_fmt=of).to(dt).view(B, Nv, H, hd)
+        vl = self.values_l_proj(l, out_fmt=of).to(dt).view(B, L, H, hd)
         if attention_mask_l is None:
             attention_mask_l = torch.ones(B, L, dtype=torch.uint8, device=v.device)
         ov, ol = ops.bi_xattn(q, k, vv, vl, attention_mask_l != 0, clamp=50000.0, out_f32=getattr(self, "split", False))
@@ -531,8 +534,9 @@ class MultiheadAttention(nn.Module):
         B, N, C = x_qk.shape
         w, b = self.in_proj_weight, self.in_proj_bias
         hd = C // self.n_heads
-        qk = _lin(self, "in_qk", x_qk, w[:2 * C], b[:2 * C]).to(self.attn_dtype).view(B, N, 2, self.n_heads, hd)
-        v = _lin(self, "in_v", x_v, w[2 * C:], b[2 * C:]).to(self.attn_dtype).view(B, N, self.n_heads, hd)
+        of = ops.F16 if (getattr(self, "split", False) and self.attn_dtype == torch.float16) else ops.F32
+        qk = _lin(self, "in_qk", x_qk, w[:2 * C], b[:2 * C], out_fmt=of).to(self.attn_dtype).view(B, N, 2, self.n_heads, hd)
+        v = _lin(self, "in_v", x_v, w[2 * C:], b[2 * C:], out_fmt=of).to(self.attn_dtype).view(B, N, self.n_heads, hd)
         o = ops.flash_attn(qk[:, :, 0], qk[:, :, 1], v, hd ** -0.5, out_f32=getattr(self, "split", False))   # strided q / k views of one GEMM output
         return self.out_proj(o)
 

@@ -19,6 +19,7 @@ class _Profile(object):
 
     def __init__(self):
         self.tags, self.events = set(), {}
+        self.shapes = False            # tools/stage_times.py: tag the generic GEMM launches by (M, N, K, formats)
 
     def enable(self, *tags):
         self.tags, self.events = set(tags), {}
@@ -695,7 +696,17 @@ def to_hl8(x, scale=1.0):
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 
-@_timed(lambda a, w, *args, **kw: kw.get("tag", "gemm"))
+def _gemm_tag(a, w, *args, **kw):
+    tag = kw.get("tag", "gemm")
+    if PROFILE.shapes and tag == "gemm":
+        split = kw.get("split")
+        K = w.shape[1] // 2 if split else w.shape[1]
+        tag = "gemm M%d N%d K%d %s->%s%s" % (a.numel() // a.shape[-1], w.shape[0], K, "f32" if a.dtype == torch.float32 else ("hl8" if split else "f16"),
+                                          {F32: "f32", F16: "f16", HL8: "hl8"}.get(kw.get("out_fmt", F32), "?"), " +res" if kw.get("resid") is not None else "")
+    return tag
+
+
+@_timed(_gemm_tag)
 def gemm(a, w, bias=None, resid=None, out_fmt=F32, act=ACT_NONE, alpha=1.0, oscale=1.0, split=None, out=None, tag="gemm", out_row=None,
          out_rows=None):
     """out = ((act(alpha * a . w^T + bias)) + resid) * oscale on hipie_gemm.

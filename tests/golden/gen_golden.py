@@ -397,7 +397,7 @@ def gen_e2e(c=None, name="e2e_tiny", tasks=(("detection", 9), ("grounding", 1)))
 
 def gen_e2e_r50():
     """the R50 configs (BASELINE configs[0]/[1]): same tiny heads behind the reference's detectron2 ResNet-50."""
-    gen_e2e(dict(TINY, backbone="r50"), "e2e_r50_tiny", (("detection", 9),))
+    gen_e2e(dict(TINY, backbone="r50"), "e2e_r50_tiny", (("detection", 9), ("grounding", 1)))
 
 
 def gen_e2e_long():

@@ -136,15 +136,18 @@ def test_e2e_tiny_bf16_policy():
         assert errs[k] < 8e-2, (k, errs[k])
 
 
-def test_e2e_r50_tiny():
-    """the R50 configs (BASELINE configs[0]/[1]): MIOpen ResNet-50 + the same HIP heads; parity then fast policy."""
+@pytest.mark.parametrize("task", ["detection", "grounding"])
+def test_e2e_r50_tiny(task):
+    """the R50 configs: MIOpen ResNet-50 + the same HIP heads, against the reference's own coco_inference.  `grounding` = BASELINE
+    configs[0] (one image batch + ONE text prompt), `detection` = configs[1] (class prompts).  Split policy (the default of the
+    drop-in) and the fp32 parity policy inside 1e-3; the fast / bf16 policies at their own bounds."""
     from hipie_amd.config import Precision
-    for prec, tol in ((Precision.parity(), 1e-3), (Precision.fast(), 8e-3), (Precision.bf16(), 8e-2)):
+    for prec, tol in ((Precision.split3(), 1e-3), (Precision.parity(), 1e-3), (Precision.fast(), 8e-3), (Precision.bf16(), 8e-2)):
         g, model = build(prec, "e2e_r50_tiny")
-        model.pin_topk(g["detection_topk_fg"], g["detection_topk_md"])
-        out = model.forward_raw(inputs(g, "detection"))
+        model.pin_topk(g[task + "_topk_fg"], g[task + "_topk_md"])
+        out = model.forward_raw(inputs(g, task))
         for k in KEYS:
-            assert rel_err(g.like("detection_" + k, out[k].float().cpu()), g["detection_" + k]) < tol, (k, str(prec))
+            assert rel_err(g.like(task + "_" + k, out[k].float().cpu()), g[task + "_" + k]) < tol, (k, str(prec))
 
 
 def test_stage_vit_backbone():
@@ -199,34 +202,42 @@ def test_e2e_batch_items_are_independent():
     model.pin_topk(None, None)
 
 
-@pytest.mark.parametrize("n_classes,L", [(150, 815), (1203, 4096)])
-def test_full_size_open_vocabulary_configs(n_classes, L):
-    """BASELINE.json configs[3] / [4] at full size: ViT-H, 1344x1344 (84x84 global-attention grid, the NB=3 kernel),
-    ADE-150 caption of ~815 tokens / LVIS-1203 caption cut at MAX_QUERY_LEN 4096 (chunked BERT, 4 / 16 chunks).
-    No golden at this size (the reference cannot run here in seconds): size-independent properties instead --
-    every a22 output finite, and exchanging the two images of the batch exchanges their rows."""
+@pytest.mark.parametrize("policy,n_classes,L,sizes", [
+    ("split3", 150, 815, [(1024, 1024)] * 2),                      # configs[3]: a rank's shard of the bs-64 job -- 1024^2, ADE-150 prompt
+    ("split3", 1203, 4096, [(1000, 1333), (1333, 1000)]),          # configs[4]: 1333-pixel long edge inside a 1344^2 canvas (real pad masks)
+    ("fast", 1203, 4096, [(1344, 1344)] * 2)])
+def test_full_size_open_vocabulary_configs(policy, n_classes, L, sizes):
+    """BASELINE.json configs[3] / [4] at full size on ViT-H: the ADE-150 caption of ~815 tokens on 1024^2 images (what one rank of
+    the 8-GPU bs-64 job runs) and the LVIS-1203 caption cut at MAX_QUERY_LEN 4096 (chunked BERT) on 1333-pixel long-edge images --
+    padded by the product into a 1344^2 canvas, i.e. an 84x84 global-attention grid (the NB = 3 kernels) WITH pad masks through
+    position embedding, encoder and proposals.  No golden at this size (the reference cannot run here in seconds): size-independent
+    properties instead -- every a22 output finite, and exchanging the two images of the batch exchanges their rows."""
     import bench
     from hipie_amd.config import HipieConfig, Precision
     from hipie_amd.hipie_img import HIPIE_IMG
     cfg = HipieConfig.vit_huge()
     torch.manual_seed(0)
-    model = HIPIE_IMG(cfg, Precision.fast(), device="cuda")
+    model = HIPIE_IMG(cfg, getattr(Precision, policy)(), device="cuda")
     bench.randomize_degenerate_inits(model)
     model.finalize()
-    b = bench.synth_batch(cfg, 2, 1344, n_classes, L, torch.device("cuda"))
+    b = bench.synth_batch(cfg, 2, max(sizes[0]), n_classes, L, torch.device("cuda"))
+    for item, (h, w) in zip(b, sizes):
+        item["image"] = item["image"][:, :h, :w].contiguous()
     n_named = len(b[0]["positive_map_label_to_token"])
     assert n_named == n_classes and int(b[0]["attention_mask"].sum()) > 0.85 * L
     out = model.forward_raw(b)
     fg, md = model.last_topk()
-    assert out["pred_masks"].shape[-2:] == (336, 336)
+    canvas = 32 * ((max(max(s) for s in sizes) + 31) // 32)
+    assert out["pred_masks"].shape[-2:] == (canvas // 4, canvas // 4)
     for k in KEYS:
         assert torch.isfinite(out[k].float()).all(), k
     model.pin_topk(fg.flip(0).cpu(), md.flip(0).cpu())
     swapped = model.forward_raw(b[::-1])
     model.pin_topk(None, None)
     for k in KEYS:
-        # not bit-identical: the library GEMMs' reduction order depends on the row position (fp16 policy: ~1e-3)
-        assert rel_err(swapped[k].float().flip(0).cpu(), out[k].float().cpu()) < 1e-2, k
+        # fast: the library GEMMs' reduction order depends on the row position (~1e-3); split3: hipie_gemm's order is fixed, what is
+        # left are MIOpen's convolutions
+        assert rel_err(swapped[k].float().flip(0).cpu(), out[k].float().cpu()) < (1e-2 if policy == "fast" else 1e-3), k
     # the instance post-processing sees the whole vocabulary: one score per (query, class)
     from hipie_amd.postprocess import inference
     res = inference(model, out, b, with_masks=False, with_sem_pan=False)

@@ -151,14 +151,16 @@ def test_e2e_long_prompt():
         assert rel_err(g.like("detection_" + k, out[k]), g["detection_" + k]) < 2e-4, k
 
 
-def test_e2e_r50_tiny():
-    """BASELINE configs[0]/[1] (R50 backbone): a22 against the reference run behind its own detectron2 ResNet-50."""
+@pytest.mark.parametrize("task", ["detection", "grounding"])
+def test_e2e_r50_tiny(task):
+    """BASELINE configs[0] (R50, one text prompt: grounding) / [1] (R50, class prompts): a22 against the reference run behind its own
+    detectron2 ResNet-50."""
     g = Golden("e2e_r50_tiny")
-    cfg, sd, imgs, ids, mask = e2e_inputs(g, "detection")
+    cfg, sd, imgs, ids, mask = e2e_inputs(g, task)
     lang = om.bert_encoder(ids, mask, sd, "text_encoder.body.model.", cfg)
-    out = om.coco_inference(imgs, lang, sd, cfg, task="detection", topk_fg=g["detection_topk_fg"], topk_md=g["detection_topk_md"])
+    out = om.coco_inference(imgs, lang, sd, cfg, task=task, topk_fg=g[task + "_topk_fg"], topk_md=g[task + "_topk_md"])
     for k in E2E_KEYS:
-        assert rel_err(g.like("detection_" + k, out[k]), g["detection_" + k]) < 2e-4, k
+        assert rel_err(g.like(task + "_" + k, out[k]), g[task + "_" + k]) < 2e-4, k
 
 
 def test_stages_tiny():

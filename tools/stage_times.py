@@ -64,6 +64,7 @@ def main():
     torch.cuda.synchronize()
     os.makedirs("gpurun_out", exist_ok=True)
     from hipie_amd import ops
+    ops.PROFILE.shapes = len(sys.argv) > 2 and sys.argv[2] == "shapes"
     ops.PROFILE.enable("all")
     model.forward_raw(batch)
     prof = ops.PROFILE.summary()
