@@ -143,14 +143,22 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
       for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
 
   // ---- prologue: stage 0 ----
+#ifdef HIPIE_GEMM_VARIANTS
+  const int nkt = (VAR == 3) ? 0 : p.nkt;     // timing experiment: the epilogue alone
+  if (VAR != 3)
+#else
+  const int nkt = p.nkt;
+#endif
+  {
 #pragma unroll
-  for (int i = 0; i < NI; ++i) dma(i, 0, 0);
+    for (int i = 0; i < NI; ++i) dma(i, 0, 0);
+  }
   __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
   __syncthreads();
 
-  for (int kt = 0; kt < p.nkt; ++kt) {
+  for (int kt = 0; kt < nkt; ++kt) {
     const int st = kt & 1;
-    const bool more = kt + 1 < p.nkt;
+    const bool more = kt + 1 < nkt;
     const char* xs = xrow + st * STAGE;
     const char* ws = wrow + st * STAGE;
     // software pipeline inside the stage: the fragments of sub-step s + 1 are requested before the MFMAs of sub-step s
@@ -392,7 +400,8 @@ extern "C" int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw
   const bool wide = (N % 320 == 0);
 #ifdef HIPIE_GEMM_VARIANTS
   { const char* e = getenv("HIPIE_GEMM_VARIANT"); const int v = e ? atoi(e) : 0;
-    if (split && wide && v == 1) return launch_gemm<320, true, 1>(p, st); }
+    if (split && wide && v == 1) return launch_gemm<320, true, 1>(p, st);
+    if (split && wide && v == 3) return launch_gemm<320, true, 3>(p, st); }
 #endif
   if (a_f32) return wide ? launch_gemm<320, true, 2>(p, st) : launch_gemm<256, true, 2>(p, st);
   if (split) return wide ? launch_gemm<320, true>(p, st) : launch_gemm<256, true>(p, st);

@@ -123,6 +123,28 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     return out
 
 
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step=64):
+    """MSDA.ms_deform_attn_backward (ops/src/vision.cpp:13-16; ms_deform_attn_cuda.cu:83-153): the gradients of the op above with
+    respect to value, sampling_loc and attn_weight, all f32 or all f64 -> (grad_value, grad_sampling_loc, grad_attn_weight)."""
+    lib = _lib.load()
+    B, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_loc.shape
+    dt = value.dtype
+    if dt not in (torch.float32, torch.float64):
+        raise RuntimeError("ms_deform_attn_backward: float32 / float64 only (got %s)" % dt)
+    if not value.is_cuda:
+        raise RuntimeError("Not implemented on the CPU (ms_deform_attn_backward)")
+    gv = torch.empty_like(value, memory_format=torch.contiguous_format)
+    gl = torch.empty(sampling_loc.shape, dtype=dt, device=value.device)
+    ga = torch.empty(attn_weight.shape, dtype=dt, device=value.device)
+    rc = lib.hipie_msda_backward(_chk(value, "value", dt), _chk(spatial_shapes, "spatial_shapes", torch.int64),
+                                 _chk(level_start_index, "level_start_index", torch.int64), _chk(sampling_loc, "sampling_loc", dt),
+                                 _chk(attn_weight, "attn_weight", dt), _chk(grad_output.contiguous(), "grad_output", dt),
+                                 gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), B, S, M, D, L, Lq, P, 3 if dt == torch.float64 else F32, _stream())
+    _lib.check(rc, "hipie_msda_backward")
+    return gv, gl, ga
+
+
 @_timed("msda")
 def msda_fused(value, spatial_shapes, level_start_index, ref, offsets, logits):
     """value (B,S,M,D); ref (B,Lq,L,2|4) f32; offsets (B,Lq,M,L,P,2); logits (B,Lq,M,L*P) (f32/f16/bf16, same dtype; they

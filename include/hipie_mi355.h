@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPIE_ABI_VERSION 4
+#define HIPIE_ABI_VERSION 5
 
 /* element types of activations */
 #define HIPIE_F32 0
@@ -69,6 +69,22 @@ const char* hipie_last_error(void);
 int hipie_msda_forward(const void* value, const int64_t* spatial_shapes, const int64_t* level_start,
                        const void* sampling_loc, const void* attn_weight, void* out,
                        int B, int S, int M, int D, int L, int Lq, int P, int value_dtype, void* stream);
+
+/*
+ * Backward of the operator above -- the plugin's second entry point.
+ * Replaces: ms_deform_attn_backward of the `MultiScaleDeformableAttention` extension (ops/src/vision.cpp:13-16; called by
+ *           MSDeformAttnFunction.backward, ops/functions/ms_deform_attn_func.py:32-41)
+ *           = ms_deform_attn_cuda_backward (ops/src/cuda/ms_deform_attn_cuda.cu:83-153)
+ *           -> ms_deformable_col2im_gpu_kernel_* (ops/src/cuda/ms_deform_im2col_cuda.cuh:301-1320).  Training only.
+ *   value, spatial_shapes, level_start, sampling_loc, attn_weight: as hipie_msda_forward;  dtype HIPIE_F32 | HIPIE_F64 for all
+ *   grad_output       (B, Lq, M*D)
+ *   grad_value        (B, S, M, D)         zeroed here, then accumulated with hardware atomics (arrival order, as the reference)
+ *   grad_sampling_loc (B, Lq, M, L, P, 2)  fully written, deterministic
+ *   grad_attn_weight  (B, Lq, M, L, P)     fully written, deterministic
+ */
+int hipie_msda_backward(const void* value, const int64_t* spatial_shapes, const int64_t* level_start, const void* sampling_loc,
+                        const void* attn_weight, const void* grad_output, void* grad_value, void* grad_sampling_loc,
+                        void* grad_attn_weight, int B, int S, int M, int D, int L, int Lq, int P, int dtype, void* stream);
 
 /*
  * Fused form used by the product path: sampling locations and the 16-way softmax are computed in the kernel from

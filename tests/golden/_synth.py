@@ -242,3 +242,23 @@ def clip_tokenize(texts, context, vocab):
         ids = [sot] + [1 + zlib.crc32(w.encode()) % (vocab - 3) for w in words][:context - 2] + [eot]
         out[i, :len(ids)] = torch.tensor(ids)
     return out
+
+
+def msda_bwd_inputs(tag, D=None):
+    """seeded inputs of the backward cases (shared with tests/test_gpu_kernels.py): value, shapes, loc, attn, grad_output -- f64."""
+    if tag == "recipe":                # ops/test.py:21-27, 69-85: N, M, Lq, L, P = 1, 2, 2, 2, 2 on maps (6, 4), (3, 2); D = channels
+        B, M, Lq, L, P, shp, seed = 1, 2, 2, 2, 2, [(6, 4), (3, 2)], 300 + D
+        scale, lo, span = 0.01, 0.0, 1.0
+    else:                              # hot-path geometry (M = 8, D = 32, L = 4, P = 4) incl. out-of-range locations
+        B, M, Lq, L, P, shp, seed, D = 2, 8, 50, 4, 4, [(12, 20), (6, 10), (3, 5), (2, 3)], 41, 32
+        scale, lo, span = 1.0, -0.1, 1.2
+    shapes = torch.as_tensor(shp, dtype=torch.long)
+    S = int(shapes.prod(1).sum())
+    g = torch.Generator().manual_seed(seed)
+    f64 = torch.float64
+    value = torch.rand(B, S, M, D, generator=g, dtype=f64) * scale
+    loc = torch.rand(B, Lq, M, L, P, 2, generator=g, dtype=f64) * span + lo
+    attn = torch.rand(B, Lq, M, L, P, generator=g, dtype=f64) + 1e-5
+    attn = attn / attn.sum(-1, keepdim=True).sum(-2, keepdim=True)
+    gout = torch.randn(B, Lq, M * D, generator=g, dtype=f64)
+    return value, shapes, loc, attn, gout

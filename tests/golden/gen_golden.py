@@ -125,6 +125,25 @@ def gen_msda():
     save("msda", meta, **arrays)
 
 
+def gen_msda_bwd():
+    """gradients of the reference's differentiable formulation (ms_deform_attn_core_pytorch, ops/functions/ms_deform_attn_func.py:41-62:
+    F.grid_sample + autograd) in double -- what ops/test.py's gradcheck holds ms_deform_attn_backward to."""
+    fn = ref("models.deformable_detr.ops.functions.ms_deform_attn_func")
+    core = fn.ms_deform_attn_core_pytorch
+    arrays, meta = {}, {"cases": []}
+    cases = [("recipe", D) for D in (30, 32, 64, 71, 1025)] + [("hot", None)]
+    with torch.enable_grad():
+        for tag, D in cases:
+            value, shapes, loc, attn, gout = _synth.msda_bwd_inputs(tag, D)
+            value.requires_grad_(True), loc.requires_grad_(True), attn.requires_grad_(True)
+            out = core(value, shapes, loc, attn)
+            gv, gl, ga = torch.autograd.grad(out, (value, loc, attn), gout)
+            name = tag if D is None else "%s%d" % (tag, D)
+            arrays.update({name + "_out": out.detach(), name + "_gvalue": gv, name + "_gloc": gl, name + "_gattn": ga})
+            meta["cases"].append([name, tag, D])
+    save("msda_bwd", meta, _full=tuple(arrays), **arrays)
+
+
 # ------------------------------------------------------------------------------ ViT attention / backbone
 def gen_vit_attn():
     vit = ref("backbone.vit")
@@ -659,7 +678,7 @@ def gen_manifest_full():
     print("wrote manifest_r50.json  %d entries" % len(man))
 
 
-ALL = dict(manifest_full=gen_manifest_full, prompts=gen_prompts, post=gen_post, resnet50=gen_resnet50, msda=gen_msda, vit_attn=gen_vit_attn, vit_backbone=gen_vit_backbone, bi_attn=gen_bi_attn, bert=gen_bert,
+ALL = dict(manifest_full=gen_manifest_full, prompts=gen_prompts, post=gen_post, resnet50=gen_resnet50, msda=gen_msda, msda_bwd=gen_msda_bwd, vit_attn=gen_vit_attn, vit_backbone=gen_vit_backbone, bi_attn=gen_bi_attn, bert=gen_bert,
            dynamic_mask=gen_dynamic_mask, e2e=gen_e2e, stages=gen_stages, e2e_r50=gen_e2e_r50, e2e_long=gen_e2e_long, e2e_deep=gen_e2e_deep, maskclip=gen_maskclip)
 
 if __name__ == "__main__":

@@ -991,3 +991,105 @@ def test_topk_replays_in_a_hip_graph():
             assert torch.equal(idx.cpu(), torch.topk(x.cpu(), 900, dim=1)[1])
     with pytest.raises(RuntimeError):
         ops.topk(x, 1025)
+
+
+# --------------------------------------------------------------------------- MSDA backward (the plugin's second entry point)
+def _msda_bwd_case(case):
+    g = Golden("msda_bwd")
+    tag, D = [(t, d) for n, t, d in g.meta["cases"] if n == case][0]
+    return g, _synth.msda_bwd_inputs(tag, D)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["recipe30", "recipe32", "recipe64", "recipe71", "recipe1025", "hot"])
+def test_msda_backward_golden(case):
+    """hipie_msda_backward vs the gradients of the reference's own differentiable formulation (tests/golden/msda_bwd.npz: F.grid_sample +
+    autograd in double): the f64 instantiation to 1e-11, the f32 one to fp32 rounding.  Channel counts of ops/test.py:97-98."""
+    from hipie_amd import ops
+    g, (value, shapes, loc, attn, gout) = _msda_bwd_case(case)
+    sh, ls = shapes.to(DEV), _lsi(shapes).to(DEV)
+    gv, gl, ga = ops.ms_deform_attn_backward(value.to(DEV), sh, ls, loc.to(DEV), attn.to(DEV), gout.to(DEV), 2)
+    assert gv.dtype == torch.float64
+    assert rel_err(gv.cpu(), g[case + "_gvalue"]) < 1e-11
+    assert rel_err(gl.cpu(), g[case + "_gloc"]) < 1e-10
+    assert rel_err(ga.cpu(), g[case + "_gattn"]) < 1e-11
+    f = torch.float32
+    gv, gl, ga = ops.ms_deform_attn_backward(value.to(f).to(DEV), sh, ls, loc.to(f).to(DEV), attn.to(f).to(DEV), gout.to(f).to(DEV), 2)
+    assert gv.dtype == f
+    # f32: the inputs themselves are rounded (a location moves by 2^-24 * size pixels), the sums over D run in fp32
+    assert rel_err(gv.cpu(), g[case + "_gvalue"]) < 2e-6
+    assert rel_err(gl.cpu(), g[case + "_gloc"]) < 2e-5
+    assert rel_err(ga.cpu(), g[case + "_gattn"]) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels", [30, 32, 64, 71])
+def test_msda_gradcheck_reference_recipe(channels):
+    """ops/test.py:69-85 check_gradient_numerical: torch.autograd.gradcheck of MSDeformAttnFunction in double on the recipe's shapes --
+    here the Function of hipie_amd.msda_shim (the reference's own Function runs on the same two entry points via install())."""
+    from torch.autograd import gradcheck
+    from hipie_amd.msda_shim import MSDeformAttnFunction
+    N, M, Lq, L, P = 1, 2, 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long, device=DEV)
+    S = int(shapes.prod(1).sum())
+    torch.manual_seed(3)
+    value = (torch.rand(N, S, M, channels, device=DEV) * 0.01).double().requires_grad_(True)
+    loc = torch.rand(N, Lq, M, L, P, 2, device=DEV).double().requires_grad_(True)
+    attn = torch.rand(N, Lq, M, L, P, device=DEV) + 1e-5
+    attn = (attn / attn.sum(-1, keepdim=True).sum(-2, keepdim=True)).double().requires_grad_(True)
+    with torch.enable_grad():
+        assert gradcheck(MSDeformAttnFunction.apply, (value, shapes, _lsi(shapes), loc, attn, 2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels", [2048, 3096])
+def test_msda_backward_wide_channels_vs_oracle_autograd(channels):
+    """the two largest channel counts of ops/test.py (a numerical gradcheck over 1.8e5 inputs would take minutes): analytic gradients vs
+    autograd through the oracle's formulation, double."""
+    from hipie_amd import ops
+    value, shapes, loc, attn, gout = _synth.msda_bwd_inputs("recipe", channels)
+    with torch.enable_grad():
+        v, l, a = value.clone().requires_grad_(True), loc.clone().requires_grad_(True), attn.clone().requires_grad_(True)
+        want = torch.autograd.grad(oo.ms_deform_attn_core(v, shapes, l, a), (v, l, a), gout)
+    got = ops.ms_deform_attn_backward(value.to(DEV), shapes.to(DEV), _lsi(shapes).to(DEV), loc.to(DEV), attn.to(DEV), gout.to(DEV), 2)
+    for w, x in zip(want, got):
+        assert rel_err(x.cpu(), w) < 1e-10
+
+
+@pytest.mark.gpu
+def test_msda_backward_through_the_reference_module_name_and_contended_pixels():
+    """(a) MultiScaleDeformableAttention.ms_deform_attn_backward as the reference's MSDeformAttnFunction.backward calls it (positional
+    arguments, a 3-tuple back); (b) every query samples the SAME point: all grad_value contributions meet on four pixels (atomics),
+    and the training geometry Lq = 21760 x 8 heads finishes; (c) nothing requires_grad-related leaks into the inference op."""
+    import sys
+    from hipie_amd import msda_shim, ops
+    msda_shim.install()
+    import MultiScaleDeformableAttention as MSDA
+    try:
+        B, M, D, L, P, Lq = 1, 8, 32, 4, 4, 21760
+        shapes = torch.as_tensor([(128, 128), (64, 64), (32, 32), (16, 16)], dtype=torch.long, device=DEV)
+        S = int(shapes.prod(1).sum())
+        g = torch.Generator(device="cuda").manual_seed(5)
+        # double: 87040 equal addends meet on each of four pixels per level -- in fp32 that running sum rounds every add the same way
+        # (5437.3 instead of 5440, as any fp32 accumulation in arrival order would); the f64 atomics are exact to 1e-12
+        value = torch.randn(B, S, M, D, device=DEV, generator=g, dtype=torch.float64)
+        loc = torch.full((B, Lq, M, L, P, 2), 0.3, device=DEV, dtype=torch.float64)
+        attn = torch.full((B, Lq, M, L, P), 1.0 / (L * P), device=DEV, dtype=torch.float64)
+        gout = torch.ones(B, Lq, M * D, device=DEV, dtype=torch.float64)
+        res = MSDA.ms_deform_attn_backward(value, shapes, _lsi(shapes), loc, attn, gout, 64)
+        assert isinstance(res, tuple) and len(res) == 3
+        gv, gl, ga = res
+        torch.cuda.synchronize()
+        # each level: the bilinear weights of the one sampled point sum to 1 -> sum of grad_value over the level = Lq * P * A per (head, channel)
+        start = 0
+        for (H, W) in shapes.tolist():
+            tot = gv[0, start:start + H * W].sum(0)
+            assert torch.allclose(tot, torch.full_like(tot, Lq * P / (L * P)), rtol=1e-10)
+            assert int((gv[0, start:start + H * W].abs().sum((1, 2)) > 0).sum()) <= 4
+            start += H * W
+        # all queries are identical: so are their location / weight gradients
+        assert torch.equal(gl[0, 0], gl[0, -1]) and torch.equal(ga[0, 0], ga[0, -1])
+        fwd = ops.ms_deform_attn_forward(value, shapes, _lsi(shapes), loc, attn, 64)
+        assert rel_err(ga.sum((3, 4)).reshape(B, Lq, M).cpu() * 1.0, (fwd.view(B, Lq, M, D).sum(-1) * (L * P)).cpu()) < 1e-10
+    finally:
+        sys.modules.pop("MultiScaleDeformableAttention")

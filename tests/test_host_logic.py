@@ -82,9 +82,15 @@ def test_msda_shim_installs_reference_module_name():
     from hipie_amd import msda_shim
     mod = msda_shim.install()
     import MultiScaleDeformableAttention as MSDA
-    assert MSDA is mod and callable(MSDA.ms_deform_attn_forward)
-    with pytest.raises(NotImplementedError):
-        MSDA.ms_deform_attn_backward()
+    assert MSDA is mod and callable(MSDA.ms_deform_attn_forward) and callable(MSDA.ms_deform_attn_backward)
+    # both entry points refuse host tensors loudly (there is no CPU path behind the plugin)
+    v = torch.zeros(1, 4, 1, 2)
+    shapes, start = torch.tensor([[2, 2]]), torch.tensor([0])
+    loc, w = torch.zeros(1, 1, 1, 1, 1, 2), torch.ones(1, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError):
+        MSDA.ms_deform_attn_forward(v, shapes, start, loc, w, 64)
+    with pytest.raises(RuntimeError):
+        MSDA.ms_deform_attn_backward(v, shapes, start, loc, w, torch.zeros(1, 1, 2), 64)
     sys.modules.pop("MultiScaleDeformableAttention")
 
 

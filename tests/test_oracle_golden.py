@@ -192,3 +192,21 @@ def test_resnet50_backbone():
     out = om.resnet50_backbone(x, sd, "")
     for k in ("res3", "res4", "res5"):
         assert rel_err(g.like(k, out[k]), g[k]) < 5e-5
+
+
+@pytest.mark.parametrize("case", ["recipe30", "recipe32", "recipe64", "recipe71", "recipe1025", "hot"])
+def test_msda_backward_oracle(case):
+    """autograd through the oracle's explicit corner-gather formulation == the gradients of the reference's own differentiable core
+    (F.grid_sample + autograd, ops/functions/ms_deform_attn_func.py:41-62) in double: the checker of hipie_msda_backward."""
+    g = Golden("msda_bwd")
+    tag, D = [(t, d) for n, t, d in g.meta["cases"] if n == case][0]
+    value, shapes, loc, attn, gout = _synth.msda_bwd_inputs(tag, D)
+    with torch.enable_grad():
+        value.requires_grad_(True), loc.requires_grad_(True), attn.requires_grad_(True)
+        out = oo.ms_deform_attn_core(value, shapes, loc, attn)
+        gv, gl, ga = torch.autograd.grad(out, (value, loc, attn), gout)
+    assert rel_err(out.detach(), g[case + "_out"]) < 1e-12
+    assert rel_err(gv, g[case + "_gvalue"]) < 1e-12
+    assert rel_err(gl, g[case + "_gloc"]) < 1e-10
+    assert rel_err(ga, g[case + "_gattn"]) < 1e-12
+

@@ -62,8 +62,28 @@ def variants():
               (v, t, 6.0 * M * 1280 * 3840 / t / 1e9, th, t2, 6.0 * M * 1280 * 5120 / t2 / 1e9), flush=True)
 
 
+def epilogue_only():
+    """variant 3 = the epilogue alone (no main loop): whole qkv grid (1536 tiles = 6 rounds of 256 CUs), 32 tiles (4 CUs per XCD: the
+    uncontended per-CU epilogue latency) and 1 tile (launch overhead)."""
+    import os
+    b = torch.randn(3840, device="cuda")
+    ws = ops.hl8_pack(torch.randn(3840, 1280, device="cuda") * 0.03)
+    for m, n in ((M, 3840), (M, 1280), (65536, 320), (8192, 320), (256, 320)):
+        xs = ops.to_hl8(torch.randn(m, 1280, device="cuda"))
+        for v in ("0", "3"):
+            os.environ["HIPIE_GEMM_VARIANT"] = v
+            t = bench(lambda: ops.gemm(xs, ws[:n], b[:n], out_fmt=ops.F32, split=True), n=20)
+            th = bench(lambda: ops.gemm(xs, ws[:n], b[:n], out_fmt=ops.HL8, split=True), n=20)
+            tg = bench(lambda: ops.gemm(xs, ws[:n], b[:n], out_fmt=ops.HL8, act=ops.ACT_GELU, split=True), n=20)
+            print("M=%6d N=%4d (%4d tiles) variant %s: fp32 out %.4f ms, HL8 out %.4f ms, GELU+HL8 out %.4f ms; out bytes %.0f MB" %
+                  (m, n, (m // 256) * (n // 320), v, t, th, tg, m * n * 4 / 1e6), flush=True)
+    os.environ["HIPIE_GEMM_VARIANT"] = "0"
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "variants":
         variants()
+    elif len(sys.argv) > 2 and sys.argv[2] == "epilogue":
+        epilogue_only()
     else:
         main()
