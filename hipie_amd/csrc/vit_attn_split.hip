@@ -9,7 +9,7 @@
 // halves of both operands,  a.b = a_lo.b_hi + a_hi.b_lo + a_hi.b_hi  (fp32 accumulation; fp16 x fp16 products are exact in
 // fp32), so the scores and both bias terms are fp32-class: a score error enters the probabilities multiplied by exp().  The
 // probabilities themselves are rounded to one fp16 (relative 2^-11 on values whose rounding errors average out over the keys),
-// V keeps both halves:  O += V_hi^T.P + V_lo^T.P.  Classic running maximum, fp32 row sums of the UNROUNDED probabilities.
+// V keeps both halves:  O += V_hi^T.P + V_lo^T.P.  Lazy running maximum (moves on growth > 2^6), fp32 row sums of the UNROUNDED probabilities.
 // tools/prec_sim.py: with single-fp16 q / k the a22 outputs of the full-depth fixture move by 1.4e-3, with single-fp16 V by 6e-4.
 //
 // Structure = vit_attn_kernel (vit_attn.hip): swapped products S^T = K.Q'^T (C operand = bias_w, -inf on padded key slots) and
@@ -21,6 +21,8 @@
 #include "mfma.h"
 
 namespace hipie {
+
+constexpr float VS_LAZY = 6.f;       // exp2(6) = 64: P <= 64, far inside fp16; a tile's P.V partial sums stay far inside fp32
 
 struct VSParams {
   const f16_t* qkv; f16_t* out; const f16_t* tab_h; const f16_t* tab_w;
@@ -73,6 +75,9 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
   constexpr int NDMA = (NBLK + WAVES - 1) / WAVES;
   constexpr int QW = WAVES * 32;
   constexpr int NT = WAVES * 64;
+  // hd = 80 leaves d rows 80 .. 95 of the last O^T block unused: column 80 of the V_hi plane holds 1.0 (written once; the DMA skips the
+  // padding chunks), so O^T row 80 accumulates the row sums of the (fp16) probabilities on the matrix pipe -- no VALU adds for them
+  constexpr bool ONES = DB * 32 > HD;
   static_assert(R == 1 || (KW > 0 && R * KW <= KT), "R key rows of KW keys must fit the tile");
   static_assert(BHC == 0 || (R == 1 && BHC <= 31), "chunked bias_h: one key row per tile, at most 31 rows per chunk");
   static_assert(KSTR % 8 == 0 && VSTR % 8 == 0, "plane rows are whole 16-byte chunks");
@@ -203,12 +208,20 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
     const int nch = isk ? KCH : VCH;
     const int row = min(min(c / nch, KT - 1), maxrow);
     int col = c % nch;
-    if (col >= CPR) col = 0;
+    if (col >= CPR) col = 0;          // padding chunk: this lane is masked out of the DMA (dskip)
     return (unsigned int)(((long)row * p.st + (isk ? 0 : C2) + 16 * col + 8 * pl) * (long)sizeof(T));
   };
   unsigned int dvoff[NDMA];
+  unsigned int dskip = 0u;            // bit r: this lane's chunk of DMA instruction r is row padding -- not fetched, not written
 #pragma unroll
-  for (int r = 0; r < NDMA; ++r) dvoff[r] = dma_voff(r, nkt - 1);
+  for (int r = 0; r < NDMA; ++r) {
+    dvoff[r] = dma_voff(r, nkt - 1);
+    const int jj = min(wave + WAVES * r, NBLK - 1);
+    const bool isk = jj < 2 * KBLK;
+    const int pl = isk ? jj / KBLK : (jj - 2 * KBLK) / VBLK;
+    const int c = 64 * (isk ? jj - pl * KBLK : jj - 2 * KBLK - pl * VBLK) + lane;
+    if (c % (isk ? KCH : VCH) >= CPR) dskip |= 1u << r;
+  }
   const unsigned int lds0 = (unsigned int)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem_raw);
   const char* kbase0 = reinterpret_cast<const char*>(Kg);
   const long tile_bytes = (long)nkt * p.st * (long)sizeof(T);
@@ -217,8 +230,22 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
     if (j >= NBLK) return;
     const bool last_ragged = ragged && (t == nt - 1);
     const unsigned int vo = last_ragged ? dma_voff(r, p.N - t * nkt - 1) : dvoff[r];
-    vs_dma16(kbase0 + (long)t * tile_bytes, vo, __builtin_amdgcn_readfirstlane(lds0 + (unsigned int)(buf * BUF * (int)sizeof(T) + 1024 * j)));
+    const unsigned int ldst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned int)(buf * BUF * (int)sizeof(T) + 1024 * j));
+    if (!((dskip >> r) & 1u)) vs_dma16(kbase0 + (long)t * tile_bytes, vo, ldst);
   };
+
+  // row padding of the V planes of both buffers (the prologue's staging area overlapped them): zeros, and 1.0 in column HD of V_hi
+  {
+    constexpr int PADC = VCH - CPR;
+    for (int idx = tid; idx < 2 * 2 * KT * PADC; idx += NT) {
+      const int pc = idx % PADC, row = (idx / PADC) % KT, pl = (idx / (PADC * KT)) & 1, buf = idx / (2 * PADC * KT);
+      f16x8 z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = (T)0.f;
+      if (ONES && pl == 0 && pc == 0) z[0] = (T)1.f;
+      *reinterpret_cast<f16x8*>(smem + buf * BUF + 2 * KPL + pl * VPL + row * VSTR + (CPR + pc) * 8) = z;
+    }
+  }
 
   f32x16 O[DB];
   float m_run = -INFINITY, l_run = 0.f;
@@ -300,11 +327,15 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
       for (int r = 0; r < 16; r += 2) mx = vs_max3(mx, S[blk][r], S[blk][r + 1]);
     mx = vs_xhalf_max(mx);
     mx += (R > 1 ? 0.f : bh0);
-    if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0ull) {
+    // LAZY running maximum: the reference point only moves when some row's maximum grew by more than 2^VS_LAZY (log2 domain), so
+    // probabilities may reach 2^VS_LAZY instead of 1 -- fp16 holds them at the same relative precision, the sums are fp32 -- and the
+    // rescale of the 48 accumulator registers (taken on most tiles with the classic rule: one of 32 rows nearly always grows a little)
+    // becomes the rare path it is meant to be
+    if (__builtin_amdgcn_ballot_w64(mx > m_run + VS_LAZY) != 0ull) {
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // m_run = -inf -> 0 (every tile has a valid key)
       m_run = m_new;
-      l_run *= alpha;
+      if (!ONES) l_run *= alpha;
 #pragma unroll
       for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -318,7 +349,7 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float pv = __builtin_amdgcn_exp2f(S[0][j] + off);
-      l_run += pv;
+      if (!ONES) l_run += pv;
       pf[j] = (T)pv;
     }
 #pragma unroll
@@ -343,7 +374,7 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float pv = __builtin_amdgcn_exp2f(S[nb_][8 * ns_ + j] + off);
-            l_run += pv;
+            if (!ONES) l_run += pv;
             pn[j] = (T)pv;
           }
         }
@@ -360,7 +391,9 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
 
   // ---- epilogue: O^T / l as HL8: a lane owns 4 consecutive d = one half of a group of 8 ----
   {
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    // ONES: d row HD = row HD % 32 of the last block = register 8 (crow(8, 0) = 16 = 80 - 64) of the lower lane half
+    static_assert(!ONES || (HD % 32 == 16), "the ones column is read back from O^T row 16 of the last block");
+    const float l_tot = ONES ? __shfl(O[DB - 1][8], li) : l_run + __shfl_xor(l_run, 32);
     const float inv = 1.f / l_tot;
     if (qi < p.N) {
       T* orow = Og + (long)qi * p.o_st;
