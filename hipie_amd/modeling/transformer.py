@@ -65,8 +65,17 @@ class PLinear(nn.Linear):
 class PConv2d(nn.Conv2d):
     out_dtype = torch.float32
     nhwc = False          # 16-bit k>1 convs run channels-last (MIOpen's NHWC implicit-GEMM kernels)
+    split = False         # Precision.split3 (set_split): 1x1 convolutions of channels-last maps run as the split-fp16 GEMM
 
     def forward(self, x):
+        if (self.split and x.is_cuda and x.dim() == 4 and self.kernel_size == (1, 1) and self.stride == (1, 1) and self.padding == (0, 0)
+                and self.groups == 1 and self.weight.dtype == torch.float32 and ops.split_ok(self.in_channels)):
+            xb = x.permute(0, 2, 3, 1)
+            if xb.is_contiguous():          # a 1x1 convolution of an NHWC map IS a linear over its pixel rows (fp32 MIOpen: ~35 TFLOP/s here)
+                B, H, W, C = xb.shape
+                w = self.weight
+                y = ops.split_linear(xb.float().reshape(B * H * W, C), self, "w1x1", w, self.bias, weight_fn=lambda: w.reshape(w.shape[0], C))
+                return y.view(B, H, W, -1).permute(0, 3, 1, 2).to(self.out_dtype)
         x = x.to(self.weight.dtype)
         if self.nhwc:
             x = x.contiguous(memory_format=torch.channels_last)
@@ -612,22 +621,29 @@ def ref_point_query(ref_point_head, sine):
     return F.linear(h, l1.weight, l1.bias).view(*sine.shape[:-1], -1)
 
 
-# The two small per-layer heads as ONE launch each (hipie_ref_point_mlp, hipie_box_head): 75 launches fewer per step, but the fp32-FMA
-# formulation is slower than the library GEMMs it replaces (A/B on one box: 100.0 vs 99.2 ms per step), so it is opt-in
-# (HIPIE_FUSED_HEADS=1) until the layers run on the matrix pipe.
-_FUSED_HEADS = os.environ.get("HIPIE_FUSED_HEADS", "0") == "1"
+# The two small per-layer heads as ONE launch each (hipie_ref_point_mlp, hipie_box_head; exact fp32 FMAs): 75 launches fewer per step.
+# fast policy: slower than the fp16 library GEMMs it replaces (A/B on one box: 100.0 vs 99.2 ms per step) -> opt-in (HIPIE_FUSED_HEADS=1).
+# split policy: the same speed as the 5 small split GEMMs + 2 glue launches per layer (224.5 vs 224.9 ms, same box, same 4.2e-4 parity
+# error) -> on by default there (HIPIE_FUSED_HEADS=0 turns it off).
+_FUSED_HEADS_ENV = os.environ.get("HIPIE_FUSED_HEADS")
+
+
+def _fused_heads(module):
+    if _FUSED_HEADS_ENV is not None:
+        return _FUSED_HEADS_ENV == "1"
+    return bool(getattr(module, "split", False))
 
 
 def decoder_query_pos(ref_point_head, ref, wdt):
     """query_pos of a decoder layer in the GEMM dtype: one launch (sine features + both layers) for the standard 512-256-256 head."""
-    if _FUSED_HEADS and ops.ref_point_mlp_ok(ref, ref_point_head) and ref_point_head.layers[0].weight.dtype == wdt:
+    if _fused_heads(ref_point_head) and ops.ref_point_mlp_ok(ref, ref_point_head) and ref_point_head.layers[0].weight.dtype == wdt:
         return ops.ref_point_mlp(ref, ref_point_head)
     return ref_point_query(ref_point_head, ops.sine_embed(ref, out_dtype=wdt))
 
 
 def decoder_box_refine(bbox_embed, t32, ref):
     """sigmoid(bbox_embed(t) + inverse_sigmoid(ref)): one launch for the standard fp32 MLP(256, 256, 4, 3)."""
-    if _FUSED_HEADS and ops.box_head_ok(t32, bbox_embed):
+    if _fused_heads(bbox_embed) and ops.box_head_ok(t32, bbox_embed):
         return ops.box_head(t32, ref, bbox_embed)
     return ops.box_refine(bbox_embed(t32), ref)
 

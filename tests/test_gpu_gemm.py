@@ -225,3 +225,28 @@ def test_gemm_fp32_rows_equal_the_converted_form_bit_for_bit(M, N, K):
     want_h = ops.gemm(ops.to_hl8(a), w, bias, split=True, out_fmt=ops.HL8)
     got_h = ops.gemm(a, w, bias, split=True, out_fmt=ops.HL8)
     assert torch.equal(got_h, want_h)
+
+
+@gpu
+@pytest.mark.parametrize("cin,cout,hw", [(640, 256, (128, 128)), (1280, 256, (64, 64)), (256, 256, (20, 36))])
+def test_pointwise_conv_on_the_split_gemm(cin, cout, hw):
+    """PConv2d with `split`: a 1x1 convolution of a channels-last map runs as hipie_gemm on the pixel rows (input_proj of both heads,
+    maskdino_encoder.py:213-236 / deformable_detr.py:139-160) -- vs F.conv2d in double; an NCHW-contiguous input keeps the library path."""
+    from hipie_amd.modeling.transformer import PConv2d
+    g = torch.Generator(device="cuda").manual_seed(cin + cout)
+    conv = PConv2d(cin, cout, kernel_size=1).cuda()
+    conv.split = True
+    x = torch.randn(2, hw[0], hw[1], cin, device="cuda", generator=g).permute(0, 3, 1, 2)        # logical NCHW, channels-last memory
+    want = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double())
+    from hipie_amd import ops
+    ops.PROFILE.enable("gemm")
+    y = conv(x)
+    n_gemm = len(ops.PROFILE.events.get("gemm", []))
+    ops.PROFILE.disable()
+    assert n_gemm == 1 and y.shape == want.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert rel_err(y.cpu(), want.float().cpu()) < 3e-6
+    ops.PROFILE.enable("gemm")
+    y2 = conv(x.contiguous())                      # NCHW memory: not a row-major pixel matrix -> MIOpen
+    assert len(ops.PROFILE.events.get("gemm", [])) == 0
+    ops.PROFILE.disable()
+    assert rel_err(y2.cpu(), want.float().cpu()) < 1e-4
