@@ -158,8 +158,8 @@ class BertModel(nn.Module):
         return x
 
     def _forward_split(self, input_ids, attention_mask):
-        """Precision.split3: every dense layer as the split-fp16 GEMM (fused QKV, fp32-class), the attention core on fp16 operands
-        (hipie_flash_attn; tools/prec_sim.py: BERT's attention products may be single fp16, its linears may not), the post-norm
+        """Precision.split3: every dense layer as the split-fp16 GEMM (fused QKV, fp32-class), the attention core in fp32
+        (hipie_attn_f32: tools/prec_sim.py on the full-size fixture -- single-fp16 q / k / v here move pred_masks by 4e-3), the post-norm
         stream fp32; the LayerNorm passes emit the next GEMM operand as HL8, the intermediate GEMM applies the exact-erf GELU and
         writes HL8 for the output GEMM.  8 launches per layer."""
         emb = self.embeddings
@@ -174,12 +174,16 @@ class BertModel(nn.Module):
         xh = ops.to_hl8(x)
         for layer in self.encoder.layer:
             at = layer.attention.self
-            qkv = ops.split_linear(xh, at, "qkv", at.query.weight, None, out_fmt=ops.F16, x_hl8=True,
+            exact = ops.attn_f32_ok(hd)          # the attention core in fp32 (hipie_attn_f32): at the headline configuration fp16 q / k / v
+            qkv = ops.split_linear(xh, at, "qkv", at.query.weight, None, out_fmt=ops.F32 if exact else ops.F16, x_hl8=True,   # here cost 4e-3
                                    weight_fn=lambda at=at: torch.cat([at.query.weight, at.key.weight, at.value.weight]),
                                    bias_fn=lambda at=at: torch.cat([at.query.bias, at.key.bias, at.value.bias]),
                                    params=(at.query.weight, at.key.weight, at.value.weight, at.query.bias, at.key.bias, at.value.bias)
                                    ).view(B, L, 3, heads, hd)
-            ctx = ops.flash_attn(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 1.0 / math.sqrt(hd), key_mask=kmask, out_f32=True)
+            if exact:
+                ctx = ops.attn_f32(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 1.0 / math.sqrt(hd), key_mask=kmask)
+            else:
+                ctx = ops.flash_attn(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 1.0 / math.sqrt(hd), key_mask=kmask, out_f32=True)
             so = layer.attention.output
             d = ops.split_linear(ctx, so, "dense", so.dense.weight, so.dense.bias)
             x, xh, _ = ops.add_layernorm_dec(x, d, so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.eps, "hl8", want16=True)

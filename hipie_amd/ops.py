@@ -211,6 +211,33 @@ def flash_attn(q, k, v, scale, bias_h=None, bias_w=None, key_mask=None, clamp=0.
     return out
 
 
+@_timed("attn_f32")
+def attn_f32(q, k, v, scale, key_mask=None):
+    """hipie_attn_f32: exact fp32 softmax attention.  q (B,Nq,H,hd), k, v (B,Nk,H,hd) fp32 views with hd contiguous and heads hd apart
+    (column blocks of one projection output are fine); hd 32 | 64; key_mask (B,Nk) bool / uint8 -> (B, Nq, H*hd) fp32."""
+    lib = _lib.load()
+    B, Nq, H, hd = q.shape
+    Nk = k.shape[1]
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        if not t.is_cuda:
+            raise RuntimeError("Not implemented on the CPU (%s)" % n)
+        if t.dtype != torch.float32 or t.stride(-1) != 1 or (H > 1 and t.stride(2) != hd):
+            raise RuntimeError("attn_f32: %s must be fp32 (B, N, H, hd) with hd contiguous and heads hd apart" % n)
+    out = torch.empty(B, Nq, H * hd, dtype=torch.float32, device=q.device)
+    mp = None
+    if key_mask is not None:
+        key_mask = key_mask.to(torch.uint8).contiguous()
+        mp = key_mask.data_ptr()
+    rc = lib.hipie_attn_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, out.data_ptr(), B, H, Nq, Nk, hd, q.stride(0), q.stride(1),
+                            k.stride(0), k.stride(1), v.stride(0), v.stride(1), float(scale), _stream())
+    _lib.check(rc, "hipie_attn_f32")
+    return out
+
+
+def attn_f32_ok(hd):
+    return hd in (32, 64)
+
+
 @_timed(lambda qkv, rel_h, rel_w, grid_hw, heads, scale: "vit_attn_global" if grid_hw[0] * grid_hw[1] > 256 else "vit_attn_window")
 def vit_attn(qkv, rel_h, rel_w, grid_hw, heads, scale):
     """qkv (B, gh*gw, 3*heads*hd) 16-bit packed as (3, heads, hd); rel_h (B*heads, gh, N) f32 (key-row major),

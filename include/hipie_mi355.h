@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPIE_ABI_VERSION 5
+#define HIPIE_ABI_VERSION 6
 
 /* element types of activations */
 #define HIPIE_F32 0
@@ -414,6 +414,20 @@ int hipie_vit_attn_split(const void* qkv, const void* tab_h, const void* tab_w, 
 /* rows of `x_dtype` (HIPIE_F32 | HIPIE_F16) values -> HIPIE_HL8 rows of scale * x (K a multiple of 8; ldx in elements of x, ldo in
  * fp16 elements >= 2K): the generic producer of split operands (the LayerNorm / GEMM epilogues emit HL8 directly). */
 int hipie_to_hl8(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int K, int x_dtype, float scale, void* stream);
+
+/*
+ * EXACT fp32 softmax attention for the small attentions of the path (fp32 operands, fp32 FMA products, fp32 softmax):
+ *     out[b,i,h,:] = softmax_j( scale * q[b,i,h,:].k[b,j,h,:] + (key_mask[b,j] ? 0 : -inf) ) . v[b,j,h,:]
+ * q, k, v fp32 with element strides (batch, token); head h is the head_dim contiguous elements at h * head_dim (so the three may be
+ * column blocks of ONE projection output); out (B, Nq, H * head_dim) fp32 contiguous; head_dim 32 | 64; key_mask (B, Nk) uint8 or NULL
+ * (a row whose keys are all masked gives zeros).  Deterministic.
+ * Replaces: BertSelfAttention's matmul -> softmax -> matmul (transformers, behind models/deformable_detr/bert_model.py:54-58) and
+ *           nn.MultiheadAttention's core in the decoder layers (models/deformable_detr/deformable_transformer_dino.py:418-432,
+ *           models/maskdino/transformer_decoder/dino_decoder.py:222-240), which the reference computes in fp32.
+ */
+int hipie_attn_f32(const float* q, const float* k, const float* v, const unsigned char* key_mask, float* out, int B, int H, int Nq, int Nk,
+                   int head_dim, int64_t q_sb, int64_t q_st, int64_t k_sb, int64_t k_st, int64_t v_sb, int64_t v_st, float scale,
+                   void* stream);
 
 /*
  * Row-wise top-k of fp32 scores, k <= 1024: idx_out (rows, k) int64 in descending value order (ascending index among equal values;

@@ -364,7 +364,7 @@ def build_ref_model(c):
     return model.eval()
 
 
-def gen_e2e(c=None, name="e2e_tiny", tasks=(("detection", 9), ("grounding", 1))):
+def gen_e2e(c=None, name="e2e_tiny", tasks=(("detection", 9), ("grounding", 1)), sizes=((200, 256), (256, 224))):
     c = c or TINY
     model = build_ref_model(c)
     bert = build_ref_bert(c)
@@ -372,7 +372,7 @@ def gen_e2e(c=None, name="e2e_tiny", tasks=(("detection", 9), ("grounding", 1)))
     man_b = _synth.load_synth(bert, seed=72)
     full_man = {"detr." + k: v for k, v in man.items()}
     full_man.update({"text_encoder.body." + k: v for k, v in man_b.items()})
-    sizes = [(200, 256), (256, 224)]
+    sizes = [tuple(s_) for s_ in sizes]
     imgs = _synth.synth_images(sizes, seed=73)
     mean = torch.tensor(c["pixel_mean"]).view(3, 1, 1)
     std = torch.tensor(c["pixel_std"]).view(3, 1, 1)
@@ -395,6 +395,7 @@ def gen_e2e(c=None, name="e2e_tiny", tasks=(("detection", 9), ("grounding", 1)))
         task, ncls = spec[0], spec[1]
         max_len, pad_to = (spec[2], spec[3]) if len(spec) > 2 else (64, None)
         ids, mask, pmap = _synth.synth_token_ids(2, ncls, max_len, seed=74, pad_to=pad_to)
+        ids, mask = ids[:len(sizes)], mask[:len(sizes)]          # one prompt row per image (rows are generated independently)
         lang = bert({"input_ids": ids, "attention_mask": mask}, sep=1012)
         arrays[task + "_lang_hidden"] = lang["hidden"].clone()
         topk_log.clear()
@@ -437,20 +438,33 @@ def gen_e2e_deep():
     gen_e2e(DEEP, "e2e_deep", (("detection", 9),))
 
 
+FULL = dict(DEEP, vit_embed_dim=1280, vit_heads=16)
+
+
+def gen_e2e_full():
+    """BASELINE.json's headline configuration itself: the full ViT-H (1280 wide, 16 heads, 32 blocks) and the shipped head sizes on ONE
+    1024 x 1024 image with the 9-class prompt, through the reference's own coco_inference on the CPU (minutes).  Outputs larger than
+    65536 elements are stored as strided subsamples (save())."""
+    import time
+    t0 = time.time()
+    gen_e2e(FULL, "e2e_full", (("detection", 9),), sizes=((1024, 1024),))
+    print("e2e_full: %.0f s" % (time.time() - t0))
+
+
 # ------------------------------------------------------------------------------ sub-module goldens from the e2e model
-def gen_stages():
+def gen_stages(c=None, name="stages_tiny", sizes=((200, 256), (256, 224))):
     """Intermediate tensors of the same tiny model (detection task), for stage-by-stage checks:
     backbone+pos, input_proj, encoder memory, two-stage selection, decoder hs, MaskDINO pixel decoder."""
-    c = TINY
+    c = c or TINY
     model = build_ref_model(c)
     bert = build_ref_bert(c)
     _synth.load_synth(model, seed=71)
     _synth.load_synth(bert, seed=72)
-    sizes = [(200, 256), (256, 224)]
+    sizes = [tuple(s_) for s_ in sizes]
     imgs = _synth.synth_images(sizes, seed=73)
     mean = torch.tensor(c["pixel_mean"]).view(3, 1, 1)
     std = torch.tensor(c["pixel_std"]).view(3, 1, 1)
-    batched = torch.zeros(2, 3, 256, 256)
+    batched = torch.zeros(len(sizes), 3, max(s_[0] for s_ in sizes), max(s_[1] for s_ in sizes))
     for i, x in enumerate(imgs):
         batched[i, :, :x.shape[1], :x.shape[2]] = (x - mean) / std
     misc = ref("util.misc")
@@ -460,6 +474,7 @@ def gen_stages():
     for i, (f, p) in enumerate(zip(feats, pos)):
         arrays["feat%d" % i], arrays["pos%d" % i], arrays["mask%d" % i] = f.tensors, p, f.mask
     ids, mask, _ = _synth.synth_token_ids(2, 9, 64, seed=74)
+    ids, mask = ids[:len(sizes)], mask[:len(sizes)]
     lang = bert({"input_ids": ids, "attention_mask": mask}, sep=1012)
     caps = {}
     tr = model.detr.transformer
@@ -495,7 +510,13 @@ def gen_stages():
     arrays["md_mask_features"] = md_pix["mask_features"]
     for i, t in enumerate(md_pix["ms"]):
         arrays["md_ms%d" % i] = t
-    save("stages_tiny", dict(cfg=c, sizes=sizes), **arrays)
+    save(name, dict(cfg=c, sizes=sizes), **arrays)
+
+
+def gen_stages_full():
+    """the same intermediate tensors at BASELINE.json's headline configuration (full ViT-H, one 1024 x 1024 image; strided subsamples):
+    where along the path an error of the product at full width comes from."""
+    gen_stages(FULL, "stages_full", sizes=((1024, 1024),))
 
 
 def gen_resnet50():
@@ -679,7 +700,7 @@ def gen_manifest_full():
 
 
 ALL = dict(manifest_full=gen_manifest_full, prompts=gen_prompts, post=gen_post, resnet50=gen_resnet50, msda=gen_msda, msda_bwd=gen_msda_bwd, vit_attn=gen_vit_attn, vit_backbone=gen_vit_backbone, bi_attn=gen_bi_attn, bert=gen_bert,
-           dynamic_mask=gen_dynamic_mask, e2e=gen_e2e, stages=gen_stages, e2e_r50=gen_e2e_r50, e2e_long=gen_e2e_long, e2e_deep=gen_e2e_deep, maskclip=gen_maskclip)
+           dynamic_mask=gen_dynamic_mask, e2e=gen_e2e, stages=gen_stages, stages_full=gen_stages_full, e2e_r50=gen_e2e_r50, e2e_long=gen_e2e_long, e2e_deep=gen_e2e_deep, e2e_full=gen_e2e_full, maskclip=gen_maskclip)
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)

@@ -82,6 +82,24 @@ def test_e2e_deep_split_policy():
         assert errs[k] < 1e-3, (k, errs[k])
 
 
+def test_e2e_full_size_split_policy():
+    """BASELINE.json's headline configuration itself -- the full ViT-H (1280 wide, 16 heads, 32 blocks, 64 x 64 token grid) with the shipped
+    head sizes on a 1024 x 1024 image -- against tests/golden/e2e_full.npz, the reference's own coco_inference on the CPU with the same
+    synthetic weights (outputs above 65536 elements compared on the fixture's strided subsample): every a22 output within 1e-3 in
+    the TIMED policy.  This is the arithmetic the throughput is quoted on, at the size it is quoted on."""
+    import os
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "e2e_full.npz")):
+        pytest.skip("tests/golden/e2e_full.npz not generated")
+    from hipie_amd.config import Precision
+    g, model = build(Precision.split3(), "e2e_full")
+    model.pin_topk(g["detection_topk_fg"], g["detection_topk_md"])
+    out = model.forward_raw(inputs(g, "detection")[:len(g.meta["sizes"])])
+    errs = {k: rel_err(g.like("detection_" + k, out[k].float().cpu()), g["detection_" + k]) for k in KEYS}
+    print("split policy, FULL SIZE (ViT-H, 1024^2): " + " ".join("%s=%.1e" % kv for kv in errs.items()))
+    for k in KEYS:
+        assert errs[k] < 1e-3, (k, errs[k])
+
+
 @pytest.mark.parametrize("policy,tol", [("split3", 1e-3), ("parity", 1e-3), ("fast", 1e-2)])       # fast: measured 1e-3 .. 8e-3 (pred_masks)
 def test_e2e_long_prompt(policy, tol):
     """BASELINE configs[3]-style prompt inside the FULL path: 815 tokens go through BertEncoder's > 512 chunker
@@ -260,19 +278,24 @@ def test_split_policy_large_activations_stay_finite():
         assert torch.isfinite(out[k].float()).all(), k
 
 
-@pytest.mark.parametrize("policy", ["split3", "parity"])
-def test_stages_tiny_on_the_gpu(policy):
+@pytest.mark.parametrize("policy,e2e,stages", [("split3", "e2e_tiny", "stages_tiny"), ("parity", "e2e_tiny", "stages_tiny"),
+                                               ("split3", "e2e_full", "stages_full")])
+def test_stages_on_the_gpu(policy, e2e, stages):
     """the PRODUCT path stage by stage against tests/golden/stages_tiny.npz (intermediate tensors of the reference's own modules
     inside coco_inference): backbone features + sine position + level masks (rows a3, a7), the encoder memory and the fused
     language stream (a9, a11), decoder states and references (a13; the two-stage selection a12 pinned), the CondInst mask-head
     convolutions (a18), MaskDINO's encoder memory, multi-scale features and mask features (a8, a20).  Forward hooks on the modules;
     the a15 / a16 / a17 heads are the last step from `dec_hs` to the a22 outputs checked by the e2e tests."""
     from hipie_amd.config import Precision
-    st = Golden("stages_tiny")
-    g, model = build(getattr(Precision, policy)())
+    import os
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", stages + ".npz")):
+        pytest.skip("tests/golden/%s.npz not generated" % stages)
+    st = Golden(stages)           # stages_full: the same tensors at the headline configuration (full ViT-H, one 1024 x 1024 image)
+    g, model = build(getattr(Precision, policy)(), e2e)
     model.pin_topk(g["detection_topk_fg"], g["detection_topk_md"])
     d = model.detr
     caps = {}
+    bad = {}
 
     def cap(name):
         def f(mod, inp, out):
@@ -292,7 +315,7 @@ def test_stages_tiny_on_the_gpu(policy):
         return r
     pix.forward_features = ff
     try:
-        model.forward_raw(inputs(g, "detection"))
+        model.forward_raw(inputs(g, "detection")[:len(g.meta["sizes"])])
     finally:
         pix.forward_features = orig_ff
         for h in hooks:
@@ -307,7 +330,8 @@ def test_stages_tiny_on_the_gpu(policy):
         else:
             v = st.like(key, valid.expand_as(t).contiguous().cpu())
             e = float(((a - b).abs() * v).max() / (b.abs() * v).max())
-        assert e < tol, (key, e)
+        if not e < tol:
+            bad[key] = e
         return e
     feats, pos = caps["backbone"]
     errs = {}
@@ -321,7 +345,8 @@ def test_stages_tiny_on_the_gpu(policy):
         a = st.like("pos%d" % i, pos[i].float().cpu().contiguous())
         v = st.like("pos%d" % i, valid)
         e = float(((a - st["pos%d" % i]).abs() * v).max())
-        assert e < 1e-4, ("pos%d" % i, e)
+        if not e < 1e-4:
+            bad["pos%d" % i] = e
         errs["pos%d" % i] = e
     # PADDED tokens carry the sine embedding of a degenerate coordinate (see above): the reference's values there depend on its
     # device's sin / cos of ~3e6 rad, and nothing reads them except the 3x3 convolutions of the mask head, which smear them a few
@@ -344,4 +369,5 @@ def test_stages_tiny_on_the_gpu(policy):
     errs["md_mask_features"] = chk("md_mask_features", mf)
     for i in range(4):
         errs["md_ms%d" % i] = chk("md_ms%d" % i, ms[i])
-    print("stages (%s): " % policy + " ".join("%s=%.1e" % kv for kv in errs.items()))
+    print("stages %s (%s): " % (stages, policy) + " ".join("%s=%.1e" % kv for kv in errs.items()))
+    assert not bad, bad

@@ -1093,3 +1093,41 @@ def test_msda_backward_through_the_reference_module_name_and_contended_pixels():
         assert rel_err(ga.sum((3, 4)).reshape(B, Lq, M).cpu() * 1.0, (fwd.view(B, Lq, M, D).sum(-1) * (L * P)).cpu()) < 1e-10
     finally:
         sys.modules.pop("MultiScaleDeformableAttention")
+
+
+# --------------------------------------------------------------------------- exact fp32 small attention
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Nq,Nk,H,hd,masked", [(2, 194, 194, 12, 64, True), (3, 910, 910, 8, 32, False), (2, 300, 300, 8, 32, False),
+                                                 (1, 5, 37, 2, 64, True), (2, 512, 512, 12, 64, True)])
+def test_attn_f32_exact(B, Nq, Nk, H, hd, masked):
+    """hipie_attn_f32 (BERT / decoder query self-attention in the split policy) vs softmax attention in double; q / k / v are column blocks
+    of ONE projection output, large logits (|s| up to ~30), a padded tail and one fully masked sequence."""
+    from hipie_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + Nq + hd)
+    C = H * hd
+    qkv = torch.randn(B, Nk, 3 * C, generator=g) * 1.5
+    q, k, v = (qkv[:, :, i * C:(i + 1) * C].view(B, Nk, H, hd) for i in range(3))
+    q = q[:, :Nq]
+    mask = None
+    if masked:
+        mask = torch.ones(B, Nk, dtype=torch.bool)
+        mask[0, Nk - Nk // 3:] = False
+        if B > 1:
+            mask[1, 1::2] = False
+    scale = hd ** -0.5
+    s = torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double()) * scale
+    if mask is not None:
+        s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
+    want = torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), v.double()).reshape(B, Nq, C)
+    dev = qkv.to(DEV)
+    qd, kd, vd = (dev[:, :, i * C:(i + 1) * C].view(B, Nk, H, hd) for i in range(3))
+    got = ops.attn_f32(qd[:, :Nq], kd, vd, scale, key_mask=None if mask is None else mask.to(DEV))
+    e = rel_err(got.cpu(), want.float())
+    print("attn_f32 %dx%d hd %d: %.2e" % (Nq, Nk, hd, e))
+    # fp32 scores of magnitude ~40 (log2 domain) carry 4e-6 of rounding into the exponent: the same bound as any fp32 evaluation
+    assert got.dtype == torch.float32 and e < 1e-5
+    if masked:                                     # a sequence with every key masked: zeros, not NaN
+        m2 = mask.clone()
+        m2[0] = False
+        got2 = ops.attn_f32(qd[:, :Nq], kd, vd, scale, key_mask=m2.to(DEV))
+        assert torch.isfinite(got2).all() and float(got2[0].abs().max()) == 0.0

@@ -139,6 +139,20 @@ def test_e2e_tiny(task):
     assert torch.equal(free["topk_md"], g[task + "_topk_md"])
 
 
+def test_e2e_full_size():
+    """BASELINE.json's headline configuration itself (full ViT-H, shipped head sizes, one 1024 x 1024 image): the oracle against the
+    reference's own coco_inference -- pins the checker, and bench.py's `cpu_baseline`, at the size the metric is quoted on (~1.5 min
+    of CPU; big outputs compared on the fixture's strided subsample)."""
+    g = Golden("e2e_full")
+    cfg, sd, imgs, ids, mask = e2e_inputs(g, "detection")
+    n = len(g.meta["sizes"])
+    lang = om.bert_encoder(ids[:n], mask[:n], sd, "text_encoder.body.model.", cfg)
+    assert rel_err(g.like("detection_lang_hidden", lang["hidden"]), g["detection_lang_hidden"]) < 5e-5
+    out = om.coco_inference(imgs, lang, sd, cfg, task="detection", topk_fg=g["detection_topk_fg"], topk_md=g["detection_topk_md"])
+    for k in E2E_KEYS:
+        assert rel_err(g.like("detection_" + k, out[k]), g["detection_" + k]) < 2e-4, k
+
+
 def test_e2e_long_prompt():
     """BASELINE configs[3]-style prompt through the full path: 815 tokens (BertEncoder's > 512 chunker) padded to 896."""
     g = Golden("e2e_long_tiny")

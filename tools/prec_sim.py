@@ -142,11 +142,12 @@ def vit_attention_core_sim(q, k, v, rel_pos_h, rel_pos_w, hw, scale):
         rel_w = p_einsum("bhwc,wkc->bhwk", r_q, Rw)
     attn = (attn.view(BH, H, W, H, W) + rel_h[:, :, :, :, None] + rel_w[:, :, :, None, :]).view(BH, H * W, H * W)
     mode_p = Sim.policy.get("vit_attn_pv", ("f", "f"))
-    if mode_p[0] == "u":          # unnormalised-P rounding as the flash kernels do: exp(s - max) rounded, row sum of the UNROUNDED p
-        m = attn.max(-1, keepdim=True)[0]
+    if mode_p[0] in ("u", "r"):   # unnormalised-P rounding as the flash kernels do: exp(s - max) rounded; row sum of the UNROUNDED p ("u")
+        m = attn.max(-1, keepdim=True)[0]           # or of the rounded p ("r": the ones-column row sums of hipie_vit_attn_split)
         p = torch.exp(attn - m)
-        l = p.sum(-1, keepdim=True)
-        return _matmul(rnd(p, "h"), rnd(v, mode_p[1])) / l
+        ph = rnd(p, "h")
+        l = (ph if mode_p[0] == "r" else p).sum(-1, keepdim=True)
+        return _matmul(ph, rnd(v, mode_p[1])) / l
     attn = attn.softmax(dim=-1)
     with region("vit_attn_pv"):
         return p_matmul(attn, v)
@@ -154,6 +155,7 @@ def vit_attention_core_sim(q, k, v, rel_pos_h, rel_pos_w, hw, scale):
 
 def run(policy, g, cfg, sd, imgs, ids, mask):
     Sim.policy = policy
+    ids, mask = ids[:len(imgs)], mask[:len(imgs)]
     with region("bert"):
         lang = om.bert_encoder(ids, mask, sd, "text_encoder.body.model.", cfg)
     with region("head"):
@@ -202,6 +204,20 @@ POLICIES = {
     "cand_b_ffn_h": {"default": S3, "vit_attn_pv": ("u", "s"), "bert_attn": H2, "mha_attn": H2, "bi_attn": H2, "lin_out": [("linear1.", "h")]},
     "cand_b_out_h": {"default": S3, "vit_attn_pv": ("u", "s"), "bert_attn": H2, "mha_attn": H2, "bi_attn": H2, "attn_out": "h"},
     "cand_b_conv_h": {"default": S3, "vit_attn_pv": ("u", "s"), "bert_attn": H2, "mha_attn": H2, "bi_attn": H2, "conv": H2},
+    # full-size study (PREC_FIXTURE=e2e_full): which of the remaining single-fp16 spots seeds the decoder's error
+    "cand_b_mha_s": {"default": S3, "vit_attn_pv": ("u", "s"), "bert_attn": H2, "bi_attn": H2},
+    "cand_b_bi_s": {"default": S3, "vit_attn_pv": ("u", "s"), "bert_attn": H2, "mha_attn": H2},
+    "cand_b_bert_s": {"default": S3, "vit_attn_pv": ("u", "s"), "mha_attn": H2, "bi_attn": H2},
+    "cand_b_pfull": {"default": S3, "vit_attn_pv": ("f", "s"), "bert_attn": H2, "mha_attn": H2, "bi_attn": H2},
+    "now": {"default": S3, "vit_attn_pv": ("u", "s"), "bi_attn": H2},            # exact BERT / decoder attention (hipie_attn_f32)
+    "now_rl": {"default": S3, "vit_attn_pv": ("r", "s"), "bi_attn": H2},         # ... and row sums of the ROUNDED probabilities (ones column)
+    "now_bi_s": {"default": S3, "vit_attn_pv": ("u", "s")},
+    "now_p_f": {"default": S3, "vit_attn_pv": ("f", "s"), "bi_attn": H2},
+    "only_vit_p_h": {"vit_attn_pv": ("u", "f")},
+    "only_mha_h": {"mha_attn": H2},
+    "only_bi_h": {"bi_attn": H2},
+    "only_bert_h": {"bert_attn": H2},
+    "only_split3_lin": {"default": S3},
     "split3_vit_head_h": {"default": H2, "vit_lin": S3, "vit_attn_qk": S3, "vit_attn_rel": S3, "vit_attn_pv": ("u", "s")},
 }
 
