@@ -444,11 +444,11 @@ def main():
         g_flop = sum(2.0 * M_tok * k * n * gemm[t][1] for t, (k, n) in shapes.items() if gemm.get(t, (None, 0))[0])
         g_ach = g_flop / (g_ms * 1e-3) / 1e12 if g_ms else None
         roof_attn = {"bound": "mfma", "kernel": "%s (ViT global attention, %d launches timed)" %
-                     ("vit_attn_split_kernel<hd%d,NB2,8 waves>: split-fp16 logits (3 products), V hi+lo (2 products)" % (E // cfg.vit_heads)
+                     ("vit_attn_split_kernel<hd%d,NB2,8 waves>: split-fp16 logits (3 products), P and V as fp16 pairs (3 products)" % (E // cfg.vit_heads)
                       if split else "vit_attn_sp_kernel<%s,hd%d>" % (str(prec.attn).split(".")[-1], E // cfg.vit_heads), kern_n),
                      "achieved": None if ach is None else round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                     "frac": None if ach is None else round(ach / 2500.0, 4), "mfma_flops_per_algorithmic_flop": 2.5 if split else 1.0,
-                     "frac_mfma_issued": None if ach is None else round(ach * (2.5 if split else 1.0) / 2500.0, 4),
+                     "frac": None if ach is None else round(ach / 2500.0, 4), "mfma_flops_per_algorithmic_flop": 3.0 if split else 1.0,
+                     "frac_mfma_issued": None if ach is None else round(ach * (3.0 if split else 1.0) / 2500.0, 4),
                      "avg_launch_ms": None if not kern_ms else round(kern_ms, 4), "flop_per_launch": flops,
                      "traffic": pmc.get("attn_split", {}).get("traffic_bytes_per_launch") if split else None}
         if g_ach is not None:

@@ -45,6 +45,9 @@ struct GemmParams {
   int tiles_m, tiles_n;
   int out_fmt, act;
   float alpha, oscale;
+  // batched form (hipie_gemm_batched): blockIdx.y = outer * nbi + inner; operand / output base offsets in BYTES per outer / inner index
+  int nbi;
+  long a_bo, a_bi, w_bo, w_bi, o_bo, o_bi;
 };
 
 // LDS-DMA, 16 bytes per lane: LDS[m0 + 16 * lane] <- *(sbase + voff).  Inline asm (see vit_attn.hip: the builtin makes hipcc
@@ -76,7 +79,14 @@ __device__ __forceinline__ unsigned int gm_pack2h(f16_t a, f16_t b) {
 }
 
 template <int BN, bool SPLIT, int VAR>
-__global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams pin) {
+  GemmParams p = pin;
+  if (gridDim.y > 1) {                          // batched: one (outer, inner) problem per blockIdx.y
+    const int bo = blockIdx.y / p.nbi, bi = blockIdx.y - bo * p.nbi;
+    p.A += bo * p.a_bo + bi * p.a_bi;
+    p.W += bo * p.w_bo + bi * p.w_bi;
+    p.out += bo * p.o_bo + bi * p.o_bi;
+  }
   constexpr int BM = 256;
   constexpr int ROWS = BM + BN;                // rows of one LDS stage: the A tile then the W tile
   constexpr int STAGE = ROWS * 128;            // bytes
@@ -325,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams p) {
 }
 
 template <int BN, bool SPLIT, int VAR = 0>
-static int launch_gemm(GemmParams& p, hipStream_t st) {
+static int launch_gemm(GemmParams& p, hipStream_t st, int batches = 1) {
   constexpr size_t lds = (size_t)2 * (256 + BN) * 128;
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + BN - 1) / BN;
@@ -337,7 +347,7 @@ static int launch_gemm(GemmParams& p, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (dev >= 0 && dev < 64) lds_set[dev] = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n), (unsigned)batches), dim3(512), lds, st, p);
   return check_launch("gemm");
 }
 
@@ -396,6 +406,7 @@ extern "C" int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw
   p.lda_b = lda * 2; p.ldw_b = ldw * 2; p.ldr = ldr; p.ldo = ldo;
   p.M = M; p.N = N; p.K = K; p.nkt = K / kq;
   p.out_fmt = out_fmt; p.act = act; p.alpha = alpha; p.oscale = oscale;
+  p.nbi = 1; p.a_bo = p.a_bi = p.w_bo = p.w_bi = p.o_bo = p.o_bi = 0;
   hipStream_t st = (hipStream_t)stream;
   const bool wide = (N % 320 == 0);
 #ifdef HIPIE_GEMM_VARIANTS
@@ -406,6 +417,32 @@ extern "C" int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw
   if (a_f32) return wide ? launch_gemm<320, true, 2>(p, st) : launch_gemm<256, true, 2>(p, st);
   if (split) return wide ? launch_gemm<320, true>(p, st) : launch_gemm<256, true>(p, st);
   return wide ? launch_gemm<320, false>(p, st) : launch_gemm<256, false>(p, st);
+}
+
+extern "C" int hipie_gemm_batched(const void* A, int64_t lda, int64_t a_outer, int64_t a_inner, const void* W, int64_t ldw, int64_t w_outer,
+                                  int64_t w_inner, void* out, int64_t ldo, int64_t o_outer, int64_t o_inner, int n_outer, int n_inner, int M,
+                                  int N, int K, int out_fmt, float alpha, void* stream) {
+  HIPIE_REQUIRE(A && W && out, "gemm_batched: null pointer");
+  HIPIE_REQUIRE(out_fmt == HIPIE_F32 || out_fmt == HIPIE_HL8, "gemm_batched: output format %d (HIPIE_F32 | HIPIE_HL8)", out_fmt);
+  HIPIE_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 32 == 0, "gemm_batched: M=%d N=%d K=%d (N %% 8, K %% 32)", M, N, K);
+  HIPIE_REQUIRE(n_outer > 0 && n_inner > 0 && (long)n_outer * n_inner <= 65535, "gemm_batched: %d x %d problems", n_outer, n_inner);
+  HIPIE_REQUIRE(lda >= 2 * K && ldw >= 2 * K && lda % 8 == 0 && ldw % 8 == 0, "gemm_batched: operand row strides %ld / %ld", (long)lda, (long)ldw);
+  HIPIE_REQUIRE((long)256 * lda * 2 < (1L << 31) && (long)320 * ldw * 2 < (1L << 31), "gemm_batched: row stride too large");
+  const int opr = out_fmt == HIPIE_HL8 ? 2 * N : N;
+  HIPIE_REQUIRE(ldo >= opr && ldo % 4 == 0, "gemm_batched: output row stride %ld (>= %d)", (long)ldo, opr);
+  HIPIE_REQUIRE(((a_outer | a_inner | w_outer | w_inner) % 8) == 0 && ((o_outer | o_inner) % 4) == 0, "gemm_batched: batch offsets must keep 16-byte alignment");
+  HIPIE_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0, "gemm_batched: pointers must be 16-byte aligned");
+  GemmParams p;
+  p.A = (const char*)A; p.W = (const char*)W; p.bias = nullptr; p.resid = nullptr; p.out = (char*)out; p.out_row = nullptr;
+  p.lda_b = lda * 2; p.ldw_b = ldw * 2; p.ldr = 0; p.ldo = ldo;
+  p.M = M; p.N = N; p.K = K; p.nkt = K / 32;
+  p.out_fmt = out_fmt; p.act = 0; p.alpha = alpha; p.oscale = 1.f;
+  const long osz = out_fmt == HIPIE_F32 ? 4 : 2;
+  p.nbi = n_inner;
+  p.a_bo = a_outer * 2; p.a_bi = a_inner * 2; p.w_bo = w_outer * 2; p.w_bi = w_inner * 2; p.o_bo = o_outer * osz; p.o_bi = o_inner * osz;
+  hipStream_t st = (hipStream_t)stream;
+  const int batches = n_outer * n_inner;
+  return (N % 320 == 0) ? launch_gemm<320, true>(p, st, batches) : launch_gemm<256, true>(p, st, batches);
 }
 
 extern "C" int hipie_to_hl8(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int K, int x_dtype, float scale, void* stream) {

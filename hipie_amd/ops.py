@@ -211,6 +211,44 @@ def flash_attn(q, k, v, scale, bias_h=None, bias_w=None, key_mask=None, clamp=0.
     return out
 
 
+@_timed("bi_i2t_split")
+def bi_i2t_split(q_hl8, k, vl, text_mask, heads, clamp=50000.0):
+    """image -> text direction of the vision-language fusion at fp32-class accuracy (fuse_helper.py:77-121):
+        out_v[b, i, h] = softmax_j( clamp(q[b,i,h] . k[b,j,h]) over the text tokens kept by text_mask ) . vl[b, j, h]
+    q_hl8 (B, Nv, 2*E) HL8 (E = heads * hd; the scaled v_proj output straight from the GEMM epilogue), k, vl (B, L, E) fp32,
+    text_mask (B, L) -> (B, Nv, E) fp32.  Three launches on the data path: S = Q_h.K_h^T for every (image, head) as ONE batched split
+    GEMM, the masked row softmax written as HL8, P_h.V_h as the second batched GEMM; the text-side operands (L x E) are padded to a
+    multiple of 32 tokens and split on the way."""
+    lib = _lib.load()
+    B, Nv, E2 = q_hl8.shape
+    E = E2 // 2
+    hd = E // heads
+    L = k.shape[1]
+    Lp = (L + 31) // 32 * 32
+    if q_hl8.dtype != torch.float16 or not q_hl8.is_contiguous() or k.dtype != torch.float32 or vl.dtype != torch.float32 or hd % 32:
+        raise RuntimeError("bi_i2t_split: q HL8 (fp16) contiguous, k / vl fp32, head_dim a multiple of 32")
+    dev = q_hl8.device
+    kp = torch.zeros(B, Lp, E, dtype=torch.float32, device=dev)
+    kp[:, :L] = k
+    k_hl8 = to_hl8(kp)                                                        # (B, Lp, 2E): head h = columns [2 hd h, 2 hd (h + 1))
+    vt = torch.zeros(B, heads, hd, Lp, dtype=torch.float32, device=dev)
+    vt[..., :L] = vl.reshape(B, L, heads, hd).permute(0, 2, 3, 1)
+    vt_hl8 = to_hl8(vt)                                                       # (B, heads, hd, 2 Lp): V_h^T, K = tokens
+    S = torch.empty(B, heads, Nv, Lp, dtype=torch.float32, device=dev)
+    rc = lib.hipie_gemm_batched(q_hl8.data_ptr(), 2 * E, Nv * 2 * E, 2 * hd, k_hl8.data_ptr(), 2 * E, Lp * 2 * E, 2 * hd,
+                                S.data_ptr(), Lp, heads * Nv * Lp, Nv * Lp, B, heads, Nv, Lp, hd, F32, 1.0, _stream())
+    _lib.check(rc, "hipie_gemm_batched")
+    P = torch.empty(B, heads, Nv, 2 * Lp, dtype=torch.float16, device=dev)
+    mk = text_mask.to(torch.uint8).contiguous()
+    rc = lib.hipie_softmax_hl8(S.data_ptr(), Lp, P.data_ptr(), 2 * Lp, B * heads * Nv, L, Lp, mk.data_ptr(), heads * Nv, float(clamp), _stream())
+    _lib.check(rc, "hipie_softmax_hl8")
+    out = torch.empty(B, Nv, E, dtype=torch.float32, device=dev)
+    rc = lib.hipie_gemm_batched(P.data_ptr(), 2 * Lp, heads * Nv * 2 * Lp, Nv * 2 * Lp, vt_hl8.data_ptr(), 2 * Lp, heads * hd * 2 * Lp, hd * 2 * Lp,
+                                out.data_ptr(), E, Nv * E, hd, B, heads, Nv, hd, Lp, F32, 1.0, _stream())
+    _lib.check(rc, "hipie_gemm_batched")
+    return out
+
+
 @_timed("attn_f32")
 def attn_f32(q, k, v, scale, key_mask=None):
     """hipie_attn_f32: exact fp32 softmax attention.  q (B,Nq,H,hd), k, v (B,Nk,H,hd) fp32 views with hd contiguous and heads hd apart

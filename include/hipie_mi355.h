@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPIE_ABI_VERSION 6
+#define HIPIE_ABI_VERSION 7
 
 /* element types of activations */
 #define HIPIE_F32 0
@@ -414,6 +414,26 @@ int hipie_vit_attn_split(const void* qkv, const void* tab_h, const void* tab_w, 
 /* rows of `x_dtype` (HIPIE_F32 | HIPIE_F16) values -> HIPIE_HL8 rows of scale * x (K a multiple of 8; ldx in elements of x, ldo in
  * fp16 elements >= 2K): the generic producer of split operands (the LayerNorm / GEMM epilogues emit HL8 directly). */
 int hipie_to_hl8(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int K, int x_dtype, float scale, void* stream);
+
+/*
+ * hipie_gemm on n_outer x n_inner independent problems in ONE launch (split-fp16 HL8 operands only, no bias / residual / activation):
+ * problem (o, i) reads A + o * a_outer + i * a_inner (fp16 elements), W + o * w_outer + i * w_inner, writes out + o * o_outer +
+ * i * o_inner (elements of out_fmt: fp32, or fp16 units for HL8).  Used for the image -> text direction of the vision-language fusion
+ * in the split policy: per (image, head)  S = Q_h . K_h^T  and  out_h = P_h . V_h  (models/deformable_detr/fuse_helper.py:77-121).
+ * n_outer * n_inner <= 65535; offsets keep 16-byte alignment.
+ */
+int hipie_gemm_batched(const void* A, int64_t lda, int64_t a_outer, int64_t a_inner, const void* W, int64_t ldw, int64_t w_outer,
+                       int64_t w_inner, void* out, int64_t ldo, int64_t o_outer, int64_t o_inner, int n_outer, int n_inner, int M, int N,
+                       int K, int out_fmt, float alpha, void* stream);
+
+/*
+ * Row softmax of fp32 logits written as an HL8 operand:  P[r, :Lp] = softmax over the L valid columns of clamp(S[r, :L], +-clamp) with
+ * columns masked by mask[r / rows_per_batch, :] (uint8, 1 = keep; NULL = all) or beyond L set to 0.  S rows lds floats apart, P rows
+ * ldp fp16 elements apart (>= 2 * Lp);  Lp a multiple of 8, <= 4096.  A row with no valid column gives zeros.
+ * Replaces: attn_weights_v = softmax(clamp(attn_weights) + attention_mask) of BiMultiHeadAttention.forward (fuse_helper.py:97-111).
+ */
+int hipie_softmax_hl8(const float* S, int64_t lds, void* P, int64_t ldp, int64_t rows, int L, int Lp, const unsigned char* mask,
+                      int64_t rows_per_batch, float clamp, void* stream);
 
 /*
  * EXACT fp32 softmax attention for the small attentions of the path (fp32 operands, fp32 FMA products, fp32 softmax):

@@ -1131,3 +1131,29 @@ def test_attn_f32_exact(B, Nq, Nk, H, hd, masked):
         m2[0] = False
         got2 = ops.attn_f32(qd[:, :Nq], kd, vd, scale, key_mask=m2.to(DEV))
         assert torch.isfinite(got2).all() and float(got2[0].abs().max()) == 0.0
+
+
+# --------------------------------------------------------------------------- split image -> text fusion attention
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Nv,L,heads,hd", [(2, 1000, 30, 8, 256), (1, 21760, 194, 8, 256), (2, 300, 257, 2, 64)])
+def test_bi_i2t_split(B, Nv, L, heads, hd):
+    """ops.bi_i2t_split (batched split GEMM -> masked softmax -> batched split GEMM) vs the reference formulation of the image -> text
+    direction (fuse_helper.py:77-121: clamp, mask as -9e15 / +1, softmax over the text tokens, bmm with the text values) in double;
+    logits of magnitude ~20 (a single-fp16 q or k would move the probabilities by 1e-2), ragged text lengths."""
+    from hipie_amd import ops
+    g = torch.Generator().manual_seed(L + Nv)
+    E = heads * hd
+    q = torch.randn(B, Nv, E, generator=g) * 0.9
+    k = torch.randn(B, L, E, generator=g) * 0.9
+    vl = torch.randn(B, L, E, generator=g)
+    mask = torch.ones(B, L, dtype=torch.bool)
+    mask[0, L - L // 4:] = False
+    qd, kd, vd = (t.double().view(B, -1, heads, hd) for t in (q, k, vl))
+    w = torch.einsum("bnhd,blhd->bhnl", qd, kd).clamp(-50000, 50000)
+    am = mask.long()[:, None, None, :].expand(B, 1, Nv, L).clone()
+    am = am.masked_fill(am == 0, int(-9e15))
+    want = torch.einsum("bhnl,blhd->bnhd", (w + am).softmax(-1), vd).reshape(B, Nv, E)
+    got = ops.bi_i2t_split(ops.to_hl8(q.to(DEV)), k.to(DEV), vl.to(DEV), mask.to(DEV), heads)
+    e = rel_err(got.cpu(), want.float())
+    print("bi_i2t_split Nv=%d L=%d: %.2e" % (Nv, L, e))
+    assert got.shape == (B, Nv, E) and e < 2e-5

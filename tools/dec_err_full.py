@@ -47,6 +47,49 @@ if "qkv32" in flags:          # additionally keep q / k / v in fp32 (no fp16 rou
         if isinstance(m, T.MultiheadAttention):
             m.attn_dtype = torch.float32
 
+if "bi32" in flags:           # exact fp32 bi-directional fusion attention (fuse_helper.py:69-121) instead of the fp16-operand kernels
+    import hipie_amd.modeling.transformer as T
+    for m in model.modules():
+        if isinstance(m, T.BiMultiHeadAttention):
+            m.attn_dtype = torch.float32
+
+    def bi_exact(q, k, vv, vl, text_mask, clamp=50000.0, out_f32=False):
+        B, Nv, H, hd = q.shape
+        L = k.shape[1]
+        w = torch.einsum("bnhd,blhd->bhnl", q.float(), k.float()).clamp(-clamp, clamp)
+        wT = w.transpose(2, 3)
+        wl = (wT - wT.max(-1, keepdim=True)[0]).clamp(-clamp, clamp).softmax(-1)
+        wv = w.masked_fill(~text_mask.bool()[:, None, None, :], float("-inf")).softmax(-1)
+        ov = torch.einsum("bhnl,blhd->bnhd", wv, vl.float()).reshape(B, Nv, H * hd)
+        ol = torch.einsum("bhln,bnhd->blhd", wl, vv.float()).reshape(B, L, H * hd)
+        return ov, ol
+    T.ops.bi_xattn = bi_exact
+
+if "vit32" in flags:          # exact fp32 ViT attention (materialised scores) on the kernel's operand contract: qkv / tables HL8, q pre-scaled into
+    import hipie_amd.modeling.vit as V   # the exp2 domain, tables / scale; output HL8
+
+    def vit_exact(qkv, tab_h, tab_w, grid_hw, heads):
+        gh, gw = grid_hw
+        B, N, C6 = qkv.shape
+        hd = C6 // (6 * heads)
+        f = ops.hl8_unpack(qkv).view(B, N, 3, heads, hd)
+        q, k, v = (f[:, :, i].permute(0, 2, 1, 3) for i in range(3))                     # (B, heads, N, hd)
+        th, tw = ops.hl8_unpack(tab_h), ops.hl8_unpack(tab_w)
+        ih = torch.arange(gh, device=qkv.device)[:, None] - torch.arange(gh, device=qkv.device)[None, :] + gh - 1
+        iw = torch.arange(gw, device=qkv.device)[:, None] - torch.arange(gw, device=qkv.device)[None, :] + gw - 1
+        out = torch.empty(B, N, heads * hd, device=qkv.device)
+        for b in range(B):
+            for h0 in range(0, heads, 4):
+                qq = q[b, h0:h0 + 4]
+                s = qq @ k[b, h0:h0 + 4].transpose(-1, -2)
+                rq = qq.reshape(-1, gh, gw, hd)
+                s = s.view(-1, gh, gw, gh, gw) + torch.einsum("mhwc,hkc->mhwk", rq, th[ih])[..., :, None] \
+                    + torch.einsum("mhwc,wkc->mhwk", rq, tw[iw])[..., None, :]
+                pr = torch.softmax(s.view(-1, N, N) * 0.6931471805599453, -1)
+                out[b, :, h0 * hd:(h0 + 4) * hd] = (pr @ v[b, h0:h0 + 4]).permute(1, 0, 2).reshape(N, -1)
+        return ops.hl8_pack(out)
+    V.ops.vit_attn_split = vit_exact
+
 imgs = _synth.synth_images([tuple(s) for s in g.meta["sizes"]], seed=73)
 ids, mask, pmap = _synth.synth_token_ids(2, g.meta["detection"]["n_classes"], 64, seed=74)
 caps = {}
