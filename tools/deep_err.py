@@ -19,13 +19,14 @@ torch.set_grad_enabled(False)
 
 def main():
     from hipie_amd.config import Precision
-    names = sys.argv[1:] or ["parity", "fast"]
-    for fixture in ("e2e_tiny", "e2e_deep"):
+    names = [a for a in sys.argv[1:] if not a.startswith("fixtures=")] or ["parity", "fast"]
+    fixtures = ([a[9:].split(",") for a in sys.argv[1:] if a.startswith("fixtures=")] or [["e2e_tiny", "e2e_deep"]])[0]
+    for fixture in fixtures:
         print("%-18s " % fixture + " ".join("%-9s" % k.replace("pred_", "").replace("maskdino", "md")[:9] for k in KEYS) + "  max")
         for n in names:
             g, model = build(getattr(Precision, n)(), fixture)
             model.pin_topk(g["detection_topk_fg"], g["detection_topk_md"])
-            out = model.forward_raw(inputs(g, "detection"))
+            out = model.forward_raw(inputs(g, "detection")[:len(g.meta["sizes"])])
             e = {k: rel_err(g.like("detection_" + k, out[k].float().cpu()), g["detection_" + k]) for k in KEYS}
             print("%-18s " % n + " ".join("%-9.1e" % e[k] for k in KEYS) + "  %.1e" % max(e.values()), flush=True)
             del model
