@@ -42,5 +42,42 @@ def main():
     print("msda_fused: %.3f ms  %.2f TB/s algorithmic" % (t, alg / t / 1e9))
 
 
+def backward():
+    """hipie_msda_backward at the encoder's training geometry (B = 2 images, every one of the 21760 tokens a query), fp32."""
+    dev = "cuda"
+    B, M, D, L, P = 2, 8, 32, 4, 4
+    shapes = [(128, 128), (64, 64), (32, 32), (16, 16)]
+    S = sum(h * w for h, w in shapes)
+    g = torch.Generator().manual_seed(0)
+    value = torch.randn(B, S, M, D, generator=g).to(dev)
+    loc = torch.rand(B, S, M, L, P, 2, generator=g).to(dev)
+    attn = torch.softmax(torch.randn(B, S, M, L * P, generator=g), -1).view(B, S, M, L, P).to(dev)
+    gout = torch.randn(B, S, M * D, generator=g).to(dev)
+    ss = torch.tensor(shapes, device=dev)
+    ls = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+    for _ in range(3):
+        ops.ms_deform_attn_backward(value, ss, ls, loc, attn, gout)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        ops.ms_deform_attn_backward(value, ss, ls, loc, attn, gout)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t) / n * 1e3
+    pts = B * S * M * L * P
+    print("msda_backward B=%d Lq=%d: %.3f ms (incl. the grad_value memset), %.1f G corner atomics of %d floats / s, corner traffic %.2f TB/s"
+          % (B, S, ms, pts * 4 / ms / 1e6, D, pts * 4 * D * 4 * 2 / ms / 1e9))
+    f = ops.ms_deform_attn_forward(value, ss, ls, loc, attn)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n):
+        ops.ms_deform_attn_forward(value, ss, ls, loc, attn)
+    torch.cuda.synchronize()
+    print("msda_forward (unfused op, same inputs): %.3f ms" % ((time.perf_counter() - t) / n * 1e3))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "bwd":
+        backward()
+    else:
+        main()
