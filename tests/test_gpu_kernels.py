@@ -963,7 +963,7 @@ def test_topk_ties_take_the_lowest_indices_in_order():
     assert idx[0].tolist() == list(range(100, 110)) + list(range(20))
     assert idx[1].tolist() == list(range(30))
     # a strided view (row stride > n) and NaN as the largest value, as torch orders it
-    y = torch.randn(4, 3000)
+    y = torch.randn(4, 3000, generator=torch.Generator().manual_seed(77))
     y[2, 17] = float("nan")
     yv = y.cuda()[:, :2000]
     got = ops.topk(yv, 50).cpu()
@@ -975,7 +975,8 @@ def test_topk_ties_take_the_lowest_indices_in_order():
 def test_topk_replays_in_a_hip_graph():
     """the property torch.topk lacks here: 200 replays of a captured selection on changing scores."""
     from hipie_amd import ops
-    x = torch.randn(8, 21760, device="cuda")
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(8, 21760, device="cuda", generator=gen)
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
         ops.topk(x, 900)
@@ -984,7 +985,7 @@ def test_topk_replays_in_a_hip_graph():
         with torch.cuda.graph(gr, stream=s):
             idx = ops.topk(x, 900)
     for it in range(200):
-        x.copy_(torch.randn(8, 21760, device="cuda"))
+        x.copy_(torch.randn(8, 21760, device="cuda", generator=gen))
         gr.replay()
         if it % 50 == 49:
             torch.cuda.synchronize()
