@@ -50,7 +50,7 @@ class Precision:
         """the TIMED policy: the reference's fp32 arithmetic reproduced on the 16-bit matrix pipe.  Every linear runs as the split-fp16
         GEMM (hipie_gemm, HIPIE_HL8 operands: x.w = x_lo.w_hi + x_hi.w_lo + x_hi.w_hi with fp32 accumulation, ~2^-22 operand error),
         the ViT attention forms its logits the same way (hipie_vit_attn_split); probabilities are one fp16, streams / norms / softmax /
-        deformable sampling / convolutions fp32 as in the parity policy, the mask contraction as three bf16 products of split operands.  tools/prec_sim.py: 4.9e-4 on the full-depth
+        deformable sampling / convolutions fp32 as in the parity policy, the mask contraction as three bf16 products of split operands.  tests/study/prec_sim.py: 4.9e-4 on the full-depth
         fixture (the parity policy's single-fp16 attention logits: 1.9e-3)."""
         p = Precision.parity()
         p.split, p.name = True, "split"

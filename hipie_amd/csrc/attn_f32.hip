@@ -3,7 +3,7 @@
 // (900 + 10 / 300 queries, 8 heads x 32; nn.MultiheadAttention in deformable_transformer_dino.py:418-432 and dino_decoder.py:222-240).
 //
 // Why not the MFMA flash kernel: at the headline configuration (full ViT-H, 1024^2) the model amplifies operand rounding by two to three
-// orders of magnitude through the six decoder layers (tools/prec_sim.py on tests/golden/e2e_full.npz): single-fp16 q / k / v in the BERT
+// orders of magnitude through the six decoder layers (tests/study/prec_sim.py on tests/golden/e2e_full.npz): single-fp16 q / k / v in the BERT
 // attention alone moves pred_masks by 4.2e-3, in the decoder self-attention by 5e-4 -- and these attentions are 0.3 % of the step's
 // flops.  So they run as the reference runs them: fp32 operands, fp32 products.
 //

@@ -11,7 +11,7 @@
 // probabilities are an fp16 PAIR as well (P_hi + P_lo) and V keeps both halves:  O += V_hi^T.(P_hi + P_lo) + V_lo^T.P_hi -- three
 // products.  (Round 3 ran P as ONE fp16 at first: fine at the fixture depths, but at the headline configuration the six decoder layers
 // amplify the 2e-5 that leaves in the backbone features into 2e-3 on the CondInst mask logits; tools/dec_err_full.py.)  Lazy running maximum (moves on growth > 2^6), fp32 row sums of the UNROUNDED probabilities.
-// tools/prec_sim.py: with single-fp16 q / k the a22 outputs of the full-depth fixture move by 1.4e-3, with single-fp16 V by 6e-4.
+// tests/study/prec_sim.py: with single-fp16 q / k the a22 outputs of the full-depth fixture move by 1.4e-3, with single-fp16 V by 6e-4.
 //
 // Structure = vit_attn_kernel (vit_attn.hip): swapped products S^T = K.Q'^T (C operand = bias_w, -inf on padded key slots) and
 // O^T = V^T.P^T with P used in place as the B operand and V^T fetched by ds_read_b64_tr_b16; one key tile = R key rows of the token

@@ -159,7 +159,7 @@ class BertModel(nn.Module):
 
     def _forward_split(self, input_ids, attention_mask):
         """Precision.split3: every dense layer as the split-fp16 GEMM (fused QKV, fp32-class), the attention core in fp32
-        (hipie_attn_f32: tools/prec_sim.py on the full-size fixture -- single-fp16 q / k / v here move pred_masks by 4e-3), the post-norm
+        (hipie_attn_f32: tests/study/prec_sim.py on the full-size fixture -- single-fp16 q / k / v here move pred_masks by 4e-3), the post-norm
         stream fp32; the LayerNorm passes emit the next GEMM operand as HL8, the intermediate GEMM applies the exact-erf GELU and
         writes HL8 for the output GEMM.  8 launches per layer."""
         emb = self.embeddings

@@ -2,7 +2,7 @@
 """diagnostics of hipie_vit_attn_split on the golden attention cases: error vs the fp64 formulation and vs variants of it."""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 from util import Golden, rel_err
 import oracle.ops as oo

@@ -11,7 +11,7 @@ policy would round it (products and sums themselves stay fp32 = MFMA fp32 accumu
 A policy maps a region (vit_lin, vit_attn_qk, vit_attn_pv, bert, head_lin, head_attn, conv, einsum, ...) to (lhs, rhs) modes.
 Test infrastructure / design tool only: nothing under hipie_amd/ imports it.
 
-    python tools/prec_sim.py [policy ...]
+    python tests/study/prec_sim.py [policy ...]
 """
 import contextlib
 import os
@@ -20,7 +20,7 @@ import sys
 import torch
 import torch.nn.functional as F
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
