@@ -48,10 +48,14 @@ class Precision:
     @staticmethod
     def split3():
         """the TIMED policy: the reference's fp32 arithmetic reproduced on the 16-bit matrix pipe.  Every linear runs as the split-fp16
-        GEMM (hipie_gemm, HIPIE_HL8 operands: x.w = x_lo.w_hi + x_hi.w_lo + x_hi.w_hi with fp32 accumulation, ~2^-22 operand error),
-        the ViT attention forms its logits the same way (hipie_vit_attn_split); probabilities are one fp16, streams / norms / softmax /
-        deformable sampling / convolutions fp32 as in the parity policy, the mask contraction as three bf16 products of split operands.  tests/study/prec_sim.py: 4.9e-4 on the full-depth
-        fixture (the parity policy's single-fp16 attention logits: 1.9e-3)."""
+        GEMM (hipie_gemm, HIPIE_HL8 operands: x.w = x_lo.w_hi + x_hi.w_lo + x_hi.w_hi with fp32 accumulation, ~2^-22 operand error);
+        the ViT attention forms its logits AND its P.V product the same way (hipie_vit_attn_split: q, k, P, V are fp16 pairs); BERT and
+        the decoders' query self-attention run in exact fp32 (hipie_attn_f32); the image -> text direction of the vision-language fusion
+        as batched split GEMMs around a masked softmax (ops.bi_i2t_split), the text -> image direction on fp16 operands with fp32 output;
+        streams / norms / softmax / deformable sampling / convolutions fp32 as in the parity policy, the mask contraction as three bf16
+        products of split operands.  Measured against the reference's own coco_inference: 1.6e-4 at the headline configuration
+        (tests/golden/e2e_full.npz: full ViT-H, 1024 x 1024), 4e-5 on the full-depth narrow fixture.  tests/study/prec_sim.py and
+        tools/dec_err_full.py hold the attribution that led here."""
         p = Precision.parity()
         p.split, p.name = True, "split"
         p.einsum = 1          # mask contraction: bf16 x 3 split products (2^-16 relative, hipie_mask_einsum precision 1) instead of the fp32 MFMA
