@@ -577,3 +577,25 @@ def test_test_time_mapper(tmp_path):
     assert torch.equal(mb({"file_name": path, "task": "grounding", "expressions": "x"})["image"], torch.as_tensor(rgb[:, :, ::-1].copy()).permute(2, 0, 1))
     with pytest.raises(ValueError):
         m({"file_name": path, "height": 61, "width": 90, "task": "grounding", "expressions": "x"})
+
+
+def test_selection_and_exact_attention_refuse_host_tensors():
+    """no CPU fallback behind the product's own kernels: the two-stage selection and the exact small attention raise on host tensors."""
+    from hipie_amd import ops
+    from hipie_amd.modeling.transformer import _select_topk
+    with pytest.raises(RuntimeError):
+        _select_topk(torch.randn(2, 100), 10)
+    q = torch.randn(1, 4, 2, 32)
+    with pytest.raises(RuntimeError):
+        ops.attn_f32(q, q, q, 1.0)
+    with pytest.raises(RuntimeError):
+        ops.ms_deform_attn_backward(torch.zeros(1, 4, 1, 2), torch.tensor([[2, 2]]), torch.tensor([0]), torch.zeros(1, 1, 1, 1, 1, 2),
+                                    torch.ones(1, 1, 1, 1, 1), torch.zeros(1, 1, 2))
+
+
+def test_effective_cores_respects_affinity_and_is_positive():
+    import bench              # repo root is on sys.path (tests/conftest.py)
+    n = bench.effective_cores()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    if hasattr(os, "sched_getaffinity"):
+        assert n <= len(os.sched_getaffinity(0))
