@@ -48,6 +48,8 @@ struct GemmParams {
   // batched form (hipie_gemm_batched): blockIdx.y = outer * nbi + inner; operand / output base offsets in BYTES per outer / inner index
   int nbi;
   long a_bo, a_bi, w_bo, w_bi, o_bo, o_bi;
+  int variant;                // timing experiments (HIPIE_GEMM_VARIANTS builds only)
+  int prio_mode;              // gemm2: 0 none, 1 blocks 256..511 at low priority (phase offset), 2 by dispatch-round parity
 };
 
 // LDS-DMA, 16 bytes per lane: LDS[m0 + 16 * lane] <- *(sbase + voff).  Inline asm (see vit_attn.hip: the builtin makes hipcc
@@ -76,6 +78,115 @@ __device__ __forceinline__ unsigned int gm_pack2h(f16_t a, f16_t b) {
   v[0] = a;
   v[1] = b;
   return __builtin_bit_cast(unsigned int, v);
+}
+
+
+// ---- tile epilogue of one 32-feature x 32-token MFMA block (both kernels): lane = token, 16 accumulator values = 4 quads of 4
+// consecutive features.  The activation / residual / scale switches are taken once per block (not per value: the per-value form cost
+// ~1400 scalar branches per wave), and the HL8 split works on PAIRS: v_cvt_pk_f16_f32 for the hi and the lo halves.
+typedef _Float16 gm_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gm_split2(float x0, float x1, unsigned int& H, unsigned int& L) {
+  x0 = __builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f);
+  x1 = __builtin_amdgcn_fmed3f(x1, -65504.f, 65504.f);
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(x0), "+v"(x1));       // pin the values: see hl_split (common.h)
+#endif
+  gm_h2 h;
+  h[0] = (f16_t)x0;
+  h[1] = (f16_t)x1;
+  gm_h2 l;
+  l[0] = (f16_t)(x0 - (float)h[0]);
+  l[1] = (f16_t)(x1 - (float)h[1]);
+  H = __builtin_bit_cast(unsigned int, h);
+  L = __builtin_bit_cast(unsigned int, l);
+}
+
+// quads [G0, G0 + NG) of the block; rq = the residual quads (zeros when there is no residual); sb = this block's 32 bias values in LDS
+// x = the raw accumulator values of quads [G0, G0 + NG) of the block (G0 may be a runtime value: 0 | 2 for half blocks)
+template <int NG>
+__device__ __forceinline__ void gm_epi_vals(const float (&x)[NG][4], const int G0, const float4* rq, const float* sb, const long m, const bool mok,
+                                            const int nb, const int hi, const GemmParams& p, const bool has_res) {
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const float alpha = p.alpha, osc = p.oscale;
+  const int act = p.act, ofmt = p.out_fmt;
+  float v[NG][4];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const float4 b4 = *reinterpret_cast<const float4*>(sb + 8 * (G0 + g) + 4 * hi);
+    v[g][0] = x[g][0] * alpha + b4.x;
+    v[g][1] = x[g][1] * alpha + b4.y;
+    v[g][2] = x[g][2] * alpha + b4.z;
+    v[g][3] = x[g][3] * alpha + b4.w;
+  }
+  if (act == 1) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[g][e] = gm_gelu(v[g][e]);
+  } else if (act == 2) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], 0.f);
+  }
+  if (has_res) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { v[g][0] += rq[g].x; v[g][1] += rq[g].y; v[g][2] += rq[g].z; v[g][3] += rq[g].w; }
+  }
+  if (osc != 1.f) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[g][e] *= osc;
+  }
+  if (ofmt == HIPIE_F16) {
+    // quads g and g + 1 of the two lane halves are exchanged so that the lower half stores features 8g .. 8g+7 and the upper
+    // half 8(g+1) .. 8(g+1)+7 as ONE 16-byte piece each
+#pragma unroll
+    for (int g = 0; g < NG; g += 2) {
+      const u32x2 s0 = __builtin_amdgcn_permlane32_swap(gm_pack2(v[g][0], v[g][1]), gm_pack2(v[g + 1][0], v[g + 1][1]), false, false);
+      const u32x2 s1 = __builtin_amdgcn_permlane32_swap(gm_pack2(v[g][2], v[g][3]), gm_pack2(v[g + 1][2], v[g + 1][3]), false, false);
+      const int n = nb + 8 * (G0 + g + hi);
+      if (mok && n < p.N) *reinterpret_cast<u32x4*>(reinterpret_cast<f16_t*>(p.out) + m * p.ldo + n) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+    }
+  } else {
+    // fp32 and HL8: the block's 32 features are a 128-byte span of the output row, of which this lane holds the four 16-byte
+    // pieces at byte 32 g + 16 hi (fp32: features 8g+4hi ..+3; HL8: the lower lane half ends up with the 8 hi values of group g,
+    // the upper half with its 8 lo values).  One store per piece: 32 rows x 32 bytes per instruction.
+    u32x4 piece[NG];
+    if (ofmt == HIPIE_F32) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        piece[g] = (u32x4){__builtin_bit_cast(unsigned int, v[g][0]), __builtin_bit_cast(unsigned int, v[g][1]),
+                           __builtin_bit_cast(unsigned int, v[g][2]), __builtin_bit_cast(unsigned int, v[g][3])};
+    } else {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        unsigned int H0, L0, H1, L1;
+        gm_split2(v[g][0], v[g][1], H0, L0);
+        gm_split2(v[g][2], v[g][3], H1, L1);
+        const u32x2 s0 = __builtin_amdgcn_permlane32_swap(H0, L0, false, false);    // lower: (H0 own, H0 of upper); upper: (L0 of lower, L0 own)
+        const u32x2 s1 = __builtin_amdgcn_permlane32_swap(H1, L1, false, false);
+        piece[g] = (u32x4){s0[0], s1[0], s0[1], s1[1]};
+      }
+    }
+    const long rowb = (m * p.ldo) * (ofmt == HIPIE_F32 ? 4 : 2) + (long)nb * 4 + 16 * hi;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      if (mok && nb + 8 * (G0 + g) < p.N) *reinterpret_cast<u32x4*>(p.out + rowb + 32 * (G0 + g)) = piece[g];
+  }
+}
+
+template <int G0, int NG>
+__device__ __forceinline__ void gm_epi_quads(const f32x16& a, const float4* rq, const float* sb, const long m, const bool mok, const int nb,
+                                             const int hi, const GemmParams& p, const bool has_res) {
+  float x[NG][4];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[g][e] = a[4 * (G0 + g) + e];
+  gm_epi_vals<NG>(x, G0, rq, sb, m, mok, nb, hi, p, has_res);
 }
 
 template <int BN, bool SPLIT, int VAR>
@@ -275,64 +386,153 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams pin) {
       const int blk = t * NJ + j;
       if (blk + 1 < 2 * NJ) load_res((blk + 1) / NJ, (blk + 1) % NJ, rq[(blk + 1) & 1]);
       const int nb = n0 + wn * (BN / 2) + j * 32;             // first feature of the 32-row MFMA block
-      float v[4][4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 b4 = *reinterpret_cast<const float4*>(sbias + (nb - n0) + 8 * g + 4 * hi);
-        const float4 r4 = rq[blk & 1][g];
-        const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float x = acc[j][t][4 * g + e] * alpha + bb[e];
-          if (act == 1) x = gm_gelu(x);
-          else if (act == 2) x = fmaxf(x, 0.f);
-          v[g][e] = (x + rr[e]) * osc;
-        }
-      }
-      typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-      if (ofmt == HIPIE_F16) {
-        // quads g and g + 1 of the two lane halves are exchanged so that the lower half stores features 8g .. 8g+7 and the upper
-        // half 8(g+1) .. 8(g+1)+7 as ONE 16-byte piece each
-#pragma unroll
-        for (int g = 0; g < 4; g += 2) {
-          const u32x2 s0 = __builtin_amdgcn_permlane32_swap(gm_pack2(v[g][0], v[g][1]), gm_pack2(v[g + 1][0], v[g + 1][1]), false, false);
-          const u32x2 s1 = __builtin_amdgcn_permlane32_swap(gm_pack2(v[g][2], v[g][3]), gm_pack2(v[g + 1][2], v[g + 1][3]), false, false);
-          const int n = nb + 8 * (g + hi);
-          if (mok && n < p.N)
-            *reinterpret_cast<u32x4*>(reinterpret_cast<f16_t*>(p.out) + m * p.ldo + n) = (u32x4){s0[0], s1[0], s0[1], s1[1]};
-        }
-      } else {
-        // fp32 and HL8: the block's 32 features are a 128-byte span of the output row, of which this lane holds the four 16-byte
-        // pieces at byte 32 g + 16 hi (fp32: features 8g+4hi ..+3; HL8: the lower lane half ends up with the 8 hi values of group g,
-        // the upper half with its 8 lo values).
-        u32x4 piece[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          if (ofmt == HIPIE_F32) {
-            piece[g] = (u32x4){__builtin_bit_cast(unsigned int, v[g][0]), __builtin_bit_cast(unsigned int, v[g][1]),
-                               __builtin_bit_cast(unsigned int, v[g][2]), __builtin_bit_cast(unsigned int, v[g][3])};
-          } else {
-            f16_t h[4], l[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) hl_split(v[g][e], h[e], l[e]);
-            const unsigned int H0 = gm_pack2h(h[0], h[1]), H1 = gm_pack2h(h[2], h[3]);
-            const unsigned int L0 = gm_pack2h(l[0], l[1]), L1 = gm_pack2h(l[2], l[3]);
-            const u32x2 s0 = __builtin_amdgcn_permlane32_swap(H0, L0, false, false);    // lower: (H0 own, H0 of upper); upper: (L0 of lower, L0 own)
-            const u32x2 s1 = __builtin_amdgcn_permlane32_swap(H1, L1, false, false);
-            piece[g] = (u32x4){s0[0], s1[0], s0[1], s1[1]};
-          }
-        }
-        // one store per piece: 32 rows x 32 bytes per instruction.  (Staging the pieces through LDS so that every store instruction
-        // writes 8 whole 128-byte lines measured 3 % SLOWER: the epilogue is bound by the HBM write rate of the burst -- all CUs finish
-        // their tiles together and write 84 MB at ~4 TB/s -- not by the number of line requests; tools/bench_gemm2.py)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          if (mok && nb + 8 * g < p.N) *reinterpret_cast<u32x4*>(p.out + (m * p.ldo) * (ofmt == HIPIE_F32 ? 4 : 2) + (long)nb * 4 + 32 * g + 16 * hi) = piece[g];
-      }
+      gm_epi_quads<0, 4>(acc[j][t], rq[blk & 1], sbias + (nb - n0), m, mok, nb, hi, p, has_res);
     }
   }
 }
+
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// gemm_small_kernel: the split product for SMALL problems (round 4) -- the decoder / BERT / head linears (M = 1.5k .. 8k rows) fill
+// 7 .. 80 of the 256 x 256 tiles above, i.e. a fraction of the 256 CUs, each walking the whole K range alone: 14 ms of the step were
+// ~250 launches of 0.03 .. 0.19 ms that are pure latency.  Here the tile is 64 tokens x 128 features on 4 waves (wave w owns feature
+// block w: one 32-row MFMA block x 2 token tiles = 32 accumulator registers), 3 LDS slots of a k32 step (192 rows x 128 B = 24 KB:
+// two workgroups per CU), one barrier per step: M = 2400, N = 256 becomes 76 workgroups of 8 short steps instead of 10 of them, and
+// M = 1552, N = 768, K = 3072 (BERT's output dense) 150 instead of 21.  Same operand formats, swizzle and epilogue as gemm_kernel.
+template <int VAR>
+__global__ __launch_bounds__(256, 2) void gemm_small_kernel(const GemmParams p) {
+  constexpr int BM = 64, BN = 128, ROWS = BM + BN, STAGE = ROWS * 128, NI = ROWS / 32;      // NI: DMA instructions per wave and stage
+  typedef Mfma32<f16_t>::frag frag;
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, hi = lane >> 5;
+  const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  unsigned int dvoff[NI];
+  {
+    const int rl = lane >> 3, cp = lane & 7;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = 8 * (4 * i + wave) + rl;              // stage row
+      const int c = cp ^ ((r >> 1) & 7);
+      if (r < BM) dvoff[i] = (unsigned int)((long)min(r, p.M - 1 - m0) * p.lda_b + 16 * c);
+      else dvoff[i] = (unsigned int)((long)min(r - BM, p.N - 1 - n0) * p.ldw_b + 16 * c);
+    }
+  }
+  const char* abase = p.A + (long)m0 * p.lda_b;
+  const char* wbase = p.W + (long)n0 * p.ldw_b;
+  const unsigned int lds0 = (unsigned int)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
+  auto dma_stage = [&](const int kt, const int slot) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const bool isa = (8 * (4 * i + wave)) < BM;         // wave-uniform (BM % 8 == 0)
+      gm_dma16((isa ? abase : wbase) + (long)kt * 128, dvoff[i],
+               __builtin_amdgcn_readfirstlane(lds0 + (unsigned int)(slot * STAGE + 1024 * (4 * i + wave))));
+    }
+  };
+
+  const int swz = (li >> 1) & 7;
+  const char* xrow = smem + li * 128;                               // + t * 32 * 128
+  const char* wrow = smem + (BM + wave * 32 + li) * 128;
+  auto choff = [&](const int ks, const int lo) -> int { return 16 * ((2 * (2 * ks + hi) + lo) ^ swz); };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int nkt = p.nkt;
+  dma_stage(0, 0);
+  if (nkt > 1) dma_stage(1, 1);
+  int slot = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) __builtin_amdgcn_s_waitcnt(0x0F70 | NI);      // stage kt landed; stage kt + 1 may still be in flight
+    else __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();                                                // ... for every wave; all reads of stage kt - 1 are done
+    if (kt + 2 < nkt) dma_stage(kt + 2, slot == 0 ? 2 : slot - 1);
+    const char* xs = xrow + slot * STAGE;
+    const char* ws = wrow + slot * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      frag xh[2], xl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        xh[t] = *reinterpret_cast<const frag*>(xs + t * 4096 + choff(ks, 0));
+        xl[t] = *reinterpret_cast<const frag*>(xs + t * 4096 + choff(ks, 1));
+      }
+      const frag wh = *reinterpret_cast<const frag*>(ws + choff(ks, 0));
+      const frag wl = *reinterpret_cast<const frag*>(ws + choff(ks, 1));
+      if (VAR == 2) {
+        // fp32 A rows: the two 16-byte pieces hold x0..x3 / x4..x7 of the lane's k group (gemm_kernel VAR 2)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const f32x4 a = __builtin_bit_cast(f32x4, xh[t]), b = __builtin_bit_cast(f32x4, xl[t]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            f16_t hh, ll;
+            hl_split(a[e], hh, ll);
+            xh[t][e] = hh; xl[t][e] = ll;
+            hl_split(b[e], hh, ll);
+            xh[t][4 + e] = hh; xl[t][4 + e] = ll;
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc[t] = Mfma32<f16_t>::mma(wl, xh[t], acc[t]);
+        acc[t] = Mfma32<f16_t>::mma(wh, xl[t], acc[t]);
+        acc[t] = Mfma32<f16_t>::mma(wh, xh[t], acc[t]);
+      }
+    }
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+
+  // ---- epilogue ----
+  const bool has_res = p.resid != nullptr;
+  __syncthreads();                                                  // the last stage's reads are done: its slot holds the bias values now
+  float* sbias = reinterpret_cast<float*>(smem);
+  if (tid < BN) sbias[tid] = (p.bias != nullptr && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
+  __syncthreads();
+  const int nb = n0 + wave * 32;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int mm = m0 + t * 32 + li;
+    const long m = (mm < p.M) ? (p.out_row != nullptr ? (long)p.out_row[mm] : (long)mm) : -1;
+    float4 rq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = nb + 8 * g + 4 * hi;
+      rq[g] = (has_res && m >= 0 && n < p.N) ? *reinterpret_cast<const float4*>(p.resid + m * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    gm_epi_quads<0, 4>(acc[t], rq, sbias + wave * 32, m, m >= 0, nb, hi, p, has_res);
+  }
+}
+
+template <int VAR>
+static int launch_gemm_small(GemmParams& p, hipStream_t st) {
+  constexpr size_t lds = (size_t)3 * (64 + 128) * 128;
+  p.tiles_m = (p.M + 63) / 64;
+  p.tiles_n = (p.N + 127) / 128;
+  auto kern = gemm_small_kernel<VAR>;
+  static bool lds_set[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !lds_set[dev]) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (dev >= 0 && dev < 64) lds_set[dev] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), lds, st, p);
+  return check_launch("gemm_small");
+}
+
+#ifdef HIPIE_GEMM_VARIANTS
+#include "gemm_overlap_study.h"
+#endif
 
 template <int BN, bool SPLIT, int VAR = 0>
 static int launch_gemm(GemmParams& p, hipStream_t st, int batches = 1) {
@@ -409,11 +609,32 @@ extern "C" int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw
   p.nbi = 1; p.a_bo = p.a_bi = p.w_bo = p.w_bi = p.o_bo = p.o_bi = 0;
   hipStream_t st = (hipStream_t)stream;
   const bool wide = (N % 320 == 0);
+  // problems that fill less than 3/8 of the CUs with 256-row tiles go to the 64 x 128 tile kernel (HIPIE_GEMM_SMALL=0: never; A/B timing)
+  static int small_on = -1;
+  if (small_on < 0) { const char* e = getenv("HIPIE_GEMM_SMALL"); small_on = e ? atoi(e) : 1; }
+  const bool small_ok = small_on && (long)((M + 255) / 256) * ((N + (wide ? 319 : 255)) / (wide ? 320 : 256)) < 96;
 #ifdef HIPIE_GEMM_VARIANTS
   { const char* e = getenv("HIPIE_GEMM_VARIANT"); const int v = e ? atoi(e) : 0;
     if (split && wide && v == 1) return launch_gemm<320, true, 1>(p, st);
     if (split && wide && v == 3) return launch_gemm<320, true, 3>(p, st); }
 #endif
+  p.prio_mode = 0;
+  p.variant = 0;
+#ifdef HIPIE_GEMM_VARIANTS
+  { const char* e = getenv("HIPIE_GEMM_VARIANT"); p.variant = e ? atoi(e) : 0; }
+  p.prio_mode = gemm2_prio();
+  if (split && gemm2_mode() == 2) {
+    const bool w160 = (N % 160 == 0);
+    if (a_f32) return w160 ? launch_gemm3<5, 2>(p, st) : launch_gemm3<4, 2>(p, st);
+    return w160 ? launch_gemm3<5, 0>(p, st) : launch_gemm3<4, 0>(p, st);
+  }
+  if (split && gemm2_mode() == 1) {
+    const bool w160 = (N % 160 == 0);
+    if (a_f32) return w160 ? launch_gemm2<5, 2>(p, st) : launch_gemm2<4, 2>(p, st);
+    return w160 ? launch_gemm2<5, 0>(p, st) : launch_gemm2<4, 0>(p, st);
+  }
+#endif
+  if (split && small_ok) return a_f32 ? launch_gemm_small<2>(p, st) : launch_gemm_small<0>(p, st);
   if (a_f32) return wide ? launch_gemm<320, true, 2>(p, st) : launch_gemm<256, true, 2>(p, st);
   if (split) return wide ? launch_gemm<320, true>(p, st) : launch_gemm<256, true>(p, st);
   return wide ? launch_gemm<320, false>(p, st) : launch_gemm<256, false>(p, st);
@@ -442,6 +663,11 @@ extern "C" int hipie_gemm_batched(const void* A, int64_t lda, int64_t a_outer, i
   p.a_bo = a_outer * 2; p.a_bi = a_inner * 2; p.w_bo = w_outer * 2; p.w_bi = w_inner * 2; p.o_bo = o_outer * osz; p.o_bi = o_inner * osz;
   hipStream_t st = (hipStream_t)stream;
   const int batches = n_outer * n_inner;
+  p.prio_mode = 0;
+  p.variant = 0;
+#ifdef HIPIE_GEMM_VARIANTS
+  if (gemm2_mode() == 1) return (N % 160 == 0) ? launch_gemm2<5, 0>(p, st, batches) : launch_gemm2<4, 0>(p, st, batches);
+#endif
   return (N % 320 == 0) ? launch_gemm<320, true>(p, st, batches) : launch_gemm<256, true>(p, st, batches);
 }
 

@@ -218,6 +218,9 @@ POLICIES = {
     "only_bi_h": {"bi_attn": H2},
     "only_bert_h": {"bert_attn": H2},
     "only_split3_lin": {"default": S3},
+    # round 4: two-product candidates on top of the shipped policy (PREC_FIXTURE=e2e_full): one ViT linear family with ONE side single fp16
+    **{"r4_%s_%s" % (fam, tag): {"default": S3, "vit_attn_pv": ("u", "s"), "vit_" + fam: mode}
+       for fam in ("qkv", "proj", "fc1", "fc2") for tag, mode in (("sa", SA), ("sw", SW))},
     "split3_vit_head_h": {"default": H2, "vit_lin": S3, "vit_attn_qk": S3, "vit_attn_rel": S3, "vit_attn_pv": ("u", "s")},
 }
 
