@@ -13,7 +13,11 @@
 
 namespace hipie {
 
+// order-preserving key.  Canonical forms first: every NaN (either sign bit: 0 * -inf gives a negative one) is the largest key, as in
+// torch; -0.0 is folded into +0.0 so that equal values tie and the tie is broken by index.
 __device__ __forceinline__ unsigned int tk_key(float v) {
+  if (v != v) return 0xFFFFFFFFu;
+  v += 0.0f;
   const unsigned int b = __builtin_bit_cast(unsigned int, v);
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }

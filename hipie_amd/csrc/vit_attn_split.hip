@@ -18,6 +18,8 @@
 // grid.  Differences: the K / V tiles go L2 -> LDS by LDS-DMA with the hi / lo halves DE-INTERLEAVED into separate planes (the DMA
 // writes LDS lane-linearly but reads a per-lane source address), so every LDS read pattern is the conflict-free one of the
 // single-fp16 kernel; two tile buffers, one barrier per tile; the output is written as HL8 = the A operand of the projection GEMM.
+#include <stdlib.h>
+
 #include "common.h"
 #include "mfma.h"
 
@@ -31,6 +33,11 @@ struct VSParams {
   long sb, st;                  // qkv strides in fp16 elements: batch, token (= 2 * 3C); q at +0, k at +2C, v at +4C (C = H * HD)
   long o_sb, o_st;              // out strides in fp16 elements (token rows of 2C)
   int nqt, swz;
+  // TRANSPOSED walk (grids wider than 96 tokens whose height is <= 96, e.g. 64 x 128 = a 1024 x 2048 image): the kernel's "key row" is
+  // a COLUMN of the token grid -- kh / kw / tab_h / tab_w arrive swapped, logical token i = (ly, lx) lives at memory token lx * kwm + ly.
+  // The logits are symmetric in the two axes, every per-token access is per-lane already, so only three address maps change.
+  int tr, kwm;
+  long krs, kts;                // fp16 elements between consecutive key slots of a tile / between consecutive tiles
 };
 
 __device__ __forceinline__ float vs_max3(float a, float b, float c) {
@@ -110,13 +117,14 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
   const int qi = qt * QW + wave * 32 + li;
   const int qc = min(qi, p.N - 1);
   const int qy = qc / kw, qx = qc - qy * kw;
+  const long qm = p.tr ? (long)qx * p.kwm + qy : (long)qc;       // memory token of this lane's query
   const int nkt = R * kw;
 
   // ---- Q fragments (B operand), both halves: lane (q = li, half hi) holds group 2 ks + hi of its query row ----
   frag qh[KS], ql[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    const T* s = Qg + (long)qc * p.st + 16 * (2 * ks + hi);
+    const T* s = Qg + qm * p.st + 16 * (2 * ks + hi);
     qh[ks] = *reinterpret_cast<const frag*>(s);
     ql[ks] = *reinterpret_cast<const frag*>(s + 8);
   }
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
     const int row = min(min(c / nch, KT - 1), maxrow);
     int col = c % nch;
     if (col >= CPR) col = 0;          // padding chunk: this lane is masked out of the DMA (dskip)
-    return (unsigned int)(((long)row * p.st + (isk ? 0 : C2) + 16 * col + 8 * pl) * (long)sizeof(T));
+    return (unsigned int)(((long)row * p.krs + (isk ? 0 : C2) + 16 * col + 8 * pl) * (long)sizeof(T));
   };
   unsigned int dvoff[NDMA];
   unsigned int dskip = 0u;            // bit r: this lane's chunk of DMA instruction r is row padding -- not fetched, not written
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
   }
   const unsigned int lds0 = (unsigned int)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem_raw);
   const char* kbase0 = reinterpret_cast<const char*>(Kg);
-  const long tile_bytes = (long)nkt * p.st * (long)sizeof(T);
+  const long tile_bytes = (R > 1 ? (long)nkt * p.st : p.kts) * (long)sizeof(T);
   auto dma_tile = [&](const int t, const int buf, const int r) {
     const int j = wave + WAVES * r;
     if (j >= NBLK) return;
@@ -407,7 +415,7 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
     const float l_tot = ONES ? __shfl(O[DB - 1][8], li) : l_run + __shfl_xor(l_run, 32);
     const float inv = 1.f / l_tot;
     if (qi < p.N) {
-      T* orow = Og + (long)qi * p.o_st;
+      T* orow = Og + qm * p.o_st;
 #pragma unroll
       for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -465,7 +473,7 @@ static int dispatch_vs(VSParams& p, hipStream_t st) {
   if (p.kw <= 64 && p.kh <= 64) return launch_vs<HD, 2, 8, 1, 0>(p, st);
   if (p.kw <= 64) return launch_vs<HD, 2, 4, 1, 0>(p, st);
   if (p.kw <= 96) return launch_vs<HD, 3, 8, 1, 0, 16>(p, st);                // 84x84: the 1344-pixel configuration
-  return set_err(HIPIE_EINVAL, "vit_attn(split): token grids wider than 96 are not supported (got %dx%d)", p.kh, p.kw);
+  return set_err(HIPIE_EINVAL, "vit_attn(split): token grids wider than 96 in BOTH directions are not supported (got %dx%d)", p.kh, p.kw);
 }
 
 }  // namespace hipie
@@ -483,6 +491,16 @@ extern "C" int hipie_vit_attn_split(const void* qkv, const void* tab_h, const vo
   p.qkv = (const f16_t*)qkv; p.out = (f16_t*)out; p.tab_h = (const f16_t*)tab_h; p.tab_w = (const f16_t*)tab_w;
   p.B = B; p.H = heads; p.N = (int)N; p.kh = gh; p.kw = gw;
   p.sb = N * 6 * C; p.st = 6 * C; p.o_sb = N * 2 * C; p.o_st = 2 * C;
+  p.tr = 0; p.kwm = gw; p.krs = p.st; p.kts = (long)gw * p.st;
+  {
+    // grids wider than 96 tokens (eval yamls: MAX_SIZE_TEST 2048 -> up to 64 x 128): walk the grid column by column
+    static int force_tr = -1;
+    if (force_tr < 0) { const char* e = getenv("HIPIE_VA_TRANSPOSE"); force_tr = e ? atoi(e) : 0; }      // 1: always (tests)
+    if ((gw > 96 && gh <= 96) || (force_tr == 1 && gw != 14)) {
+      p.tr = 1; p.kh = gw; p.kw = gh; p.tab_h = (const f16_t*)tab_w; p.tab_w = (const f16_t*)tab_h;
+      p.krs = (long)gw * p.st; p.kts = p.st;
+    }
+  }
   hipStream_t st = (hipStream_t)stream;
   if (hd == 80) return dispatch_vs<80>(p, st);
   if (hd == 64) return dispatch_vs<64>(p, st);

@@ -9,8 +9,9 @@ through ``build_model(cfg)`` unchanged, and ``DetectionCheckpointer`` loads refe
 
 Order of events in train_net.py:269-271 is build -> load checkpoint -> forward: nothing weight-derived is computed at
 construction (HIPIE_IMG finalises lazily on the first forward and after every load_state_dict).
-Unsupported switch positions of the yaml (MODEL.CLIP.ENABLED, PARALLEL_DET, ...) raise NotImplementedError at construction
-instead of silently evaluating something else.
+Unsupported switch positions of the yaml (PARALLEL_DET, DECOUPLE_TGT off, USE_DINO off, ...) raise NotImplementedError at construction
+instead of silently evaluating something else; MODEL.CLIP.ENABLED is supported (hipie_amd/open_vocab.py, round 3).
+Exercised so far only against a stand-in detectron2 (tests/test_host_logic.py::test_d2_registry_*): the image has no detectron2.
 """
 from .config import HipieConfig, Precision
 

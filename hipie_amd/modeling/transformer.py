@@ -853,8 +853,12 @@ def _select_topk(scores, k):
     launch and hipGraph-replay safe -- torch.topk is 12 launches here and faults under graph replay."""
     scores = scores.float().contiguous()
     if not ops.topk_ok(scores, k):
-        raise RuntimeError("two-stage selection: k=%d of %s scores on %s is outside hipie_topk's range (device tensor, k <= 1024)"
-                           % (k, tuple(scores.shape), scores.device))
+        # outside the kernel's range (k > 1024: e.g. TWO_STAGE_NUM_PROPOSALS 2000): the library selection on the device -- except inside a
+        # hipGraph capture, where torch.topk is known to fault on replay (DESIGN.md section 9), and never on the host
+        if scores.is_cuda and not torch.cuda.is_current_stream_capturing():
+            return torch.topk(scores, k, dim=1)[1]
+        raise RuntimeError("two-stage selection: k=%d of %s scores on %s is outside hipie_topk's range (device tensor, k <= 1024) and "
+                           "torch.topk is not usable here (host tensor or hipGraph capture)" % (k, tuple(scores.shape), scores.device))
     return ops.topk(scores, k)
 
 

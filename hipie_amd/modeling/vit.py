@@ -272,7 +272,7 @@ def _block_forward_split(self, x, delta):
     xs = x.view(B * H * W, C)
     if ws == 0:
         if not ops.vit_attn_split_ok((H, W), C // self.attn.num_heads):
-            raise NotImplementedError("split policy: global attention on a %dx%d token grid (supported: up to 96 wide, 160 high)" % (H, W))
+            raise NotImplementedError("split policy: global attention on a %dx%d token grid (not covered: wider than 96 tokens in BOTH directions)" % (H, W))
         y = ops.add_layernorm(x, None, n1.weight, n1.bias, n1.eps, "hl8")[1]
         self.attn.forward_split(y.view(B * H * W, 2 * C), B, H, W, xs)
     else:

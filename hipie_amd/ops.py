@@ -860,10 +860,14 @@ def vit_attn_split(qkv, tab_h, tab_w, grid_hw, heads):
 
 
 def vit_attn_split_ok(grid_hw, hd):
-    """geometry hipie_vit_attn_split covers: head_dim 64 / 80, 14-wide windows or token grids up to 96 wide / 160 high (64 x 64 at
-    1024^2, 84 x 84 at 1344^2)."""
+    """geometry hipie_vit_attn_split covers: head_dim 64 / 80, 14-wide windows, token grids up to 96 wide (64 x 64 at 1024^2, 84 x 84 at
+    1344^2) and -- walked column by column -- grids wider than 96 whose height is <= 96 (64 x 128: a 1024 x 2048 image, the eval yamls'
+    MAX_SIZE_TEST).  Only grids wider than 96 in BOTH directions (beyond 1536 x 1536 pixels) are not covered."""
     gh, gw = grid_hw
-    return hd in (64, 80) and ((gw == 14 and gh <= 96) or (gw <= 96 and gh <= 160))
+
+    def rows_ok(kh, kw):           # LDS: the per-key-row bias table of the <= 64-wide instances holds kh rows
+        return (kw <= 32 and kh <= 160) or (kw <= 64 and kh <= 132) or (64 < kw <= 96 and kh <= 160)
+    return hd in (64, 80) and ((gw == 14 and gh <= 96) or rows_ok(gh, gw) or (gw > 96 and gh <= 96 and rows_ok(gw, gh)))
 
 
 # ---- split ("fp32-class") linears: cached HL8 copies of (derived) weights + the GEMM call ----------------------------------

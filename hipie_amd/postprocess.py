@@ -219,7 +219,14 @@ def _instances_on_device(model, out, batched_inputs, do_postprocess=True):
             p_det = F.softmax(logits.sigmoid() / cfg.pano_temp_fg, dim=-1)
         else:
             p_det = logits.sigmoid()
-        fused = torch.stack([_clip_logits(model, batched_inputs, i, pred_masks[i], p_det[i]) for i in range(B)])
+        # MaskCLIP resizes the image and the mask logits independently to its input size: the two must cover the same extent.  The
+        # reference runs at B = 1, where the logits span the image's own padded canvas; in a mixed-size batch image i therefore gets the
+        # logits of ITS canvas (size rounded up to the backbone's divisibility), not of the batch canvas -- the B = 1 result of that image.
+        def own_canvas(i):
+            hm = -(-image_sizes[i][0] // 32) * 32 // s
+            wm = -(-image_sizes[i][1] // 32) * 32 // s
+            return pred_masks[i][:, :min(hm, pred_masks.shape[-2]), :min(wm, pred_masks.shape[-1])]
+        fused = torch.stack([_clip_logits(model, batched_inputs, i, own_canvas(i), p_det[i]) for i in range(B)])
         allowed = (logits[:, :1] != NEG).float()                                  # the reference's is_thing_mask (first query row)
         prob = torch.sqrt((fused.sigmoid() * allowed) ** cfg.clip_fg_a * iou.sigmoid() ** cfg.clip_fg_b)
     else:

@@ -155,6 +155,7 @@ def gen_vit_attn():
         "global64": (80, 1, (64, 64), (1, 64, 64)),      # the real 64x64 geometry, 1 head
         "global_rect": (160, 2, (64, 64), (1, 12, 20)),  # non-square token grid
         "global84": (80, 1, (64, 64), (1, 84, 84)),      # 1344-pixel images (BASELINE configs[4]): table 127 -> 167 (utils.py:75-86)
+        "global128": (80, 1, (64, 64), (1, 64, 128)),    # a 1024 x 2048 image (eval yamls: MAX_SIZE_TEST 2048): 64 x 128 tokens, tables 127 / 127 -> 255
     }
     for name, (dim, heads, insz, (B, H, W)) in cases.items():
         m = vit.Attention(dim, num_heads=heads, qkv_bias=True, use_rel_pos=True, rel_pos_zero_init=True,

@@ -3,11 +3,11 @@
 The two top-k query selections are discontinuous (a 1-ulp score change swaps queries), so the end-to-end comparison pins
 their indices to the reference's (hard part (c)); the free-running selection is checked separately by overlap.
 Tolerances (max|a-b| / max|b|, BASELINE.json: "within 1e-3 rel fp16 tolerance"):
-  Precision.parity() (fp32 GEMMs, fp16 attention operands)             1e-3 on every a22 output;
-  Precision.fast()   (the TIMED policy: fp16 operands, fp32 accumulate) 8e-3 on every a22 output (measured 1e-3 .. 6e-3: logits /
-                     boxes 1-3e-3, mask logits and the IoU head 3-6e-3 -- every 16-bit stage contributes 1-3e-3 and the maximum
-                     over a tensor moves by +-1e-3 with any change of rounding order; bench.py prints the same numbers as
-                     `parity_err` next to the parity policy's throughput);
+  Precision.split3() (the TIMED policy and the registry default: split-fp16 linears and ViT attention, exact small attentions)
+                     1e-3 on every a22 output (measured 4e-5 .. 2e-4, incl. the full-size fixture e2e_full);
+  Precision.parity() (fp32 library GEMMs, fp16 attention operands)     1e-3 on the 3-block fixtures (fails at depth: DESIGN.md section 6);
+  Precision.fast()   (opt-in: single fp16 operands, fp32 accumulate)   8e-3 on the tiny fixtures (measured 1e-3 .. 6e-3; out of
+                     tolerance at the shipped depths -- bench.py prints its numbers as `fast_policy`, never as `value`);
   Precision.bf16()   (bf16 everywhere)                                  8e-2 -- bf16 has 8 mantissa bits, the reference is fp32
                      (measured 7e-3 .. 6e-2)."""
 import pytest
@@ -117,9 +117,11 @@ def test_e2e_long_prompt(policy, tol):
         assert errs[k] < tol, (k, errs[k])
 
 
-def test_e2e_tiny_free_topk_overlap():
+@pytest.mark.parametrize("policy", ["split3", "parity"])          # split3 = the registry default / the timed policy
+def test_e2e_tiny_free_topk_overlap(policy):
+    """un-pinned selection: the product's own two-stage top-k (hipie_topk) picks >= 90 % of the reference's queries"""
     from hipie_amd.config import Precision
-    g, model = build(Precision.parity())
+    g, model = build(getattr(Precision, policy)())
     model.forward_raw(inputs(g, "detection"))
     fg, md = model.last_topk()
     for got, want in ((fg.cpu(), g["detection_topk_fg"]), (md.cpu(), g["detection_topk_md"])):
@@ -130,7 +132,7 @@ def test_e2e_tiny_free_topk_overlap():
 
 @pytest.mark.parametrize("task", ["detection", "grounding"])
 def test_e2e_tiny_fast_policy(task):
-    """the policy bench.py times (fp16 operands, fp32 accumulation and residual stream): every a22 output within 8e-3
+    """the opt-in `fast` policy (single fp16 operands, fp32 accumulation and residual stream; NOT the timed one): every a22 output within 8e-3
     (a 16-bit operand pipeline of this depth does not reach the parity policy's 1e-3: tools/prec_matrix.py shows every stage
     contributing 1-3e-3; bf16 is at 2-3e-2)."""
     from hipie_amd.config import Precision
@@ -174,7 +176,7 @@ def test_stage_vit_backbone():
     from hipie_amd.modeling.vit import D2ViT
     g = Golden("vit_backbone")
     cfg = HipieConfig.from_dict(g.meta["cfg"])
-    for prec, tol in ((Precision.parity(), 1e-3), (Precision.fast(), 3e-3), (Precision.bf16(), 3e-2)):
+    for prec, tol in ((Precision.split3(), 2e-4), (Precision.parity(), 1e-3), (Precision.fast(), 3e-3), (Precision.bf16(), 3e-2)):
         m = D2ViT(cfg, prec)
         m.load_state_dict(_synth.synth_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}, seed=31))
         m = m.cuda().eval().cast_weights()
@@ -199,11 +201,12 @@ def test_stage_bert_short_and_chunked():
         assert rel_err(g.like(tag + "_hidden", out.float().cpu()), g[tag + "_hidden"]) < 2e-4
 
 
-def test_e2e_batch_items_are_independent():
+@pytest.mark.parametrize("policy", ["split3", "parity"])
+def test_e2e_batch_items_are_independent(policy):
     """size-independent property: with equal image sizes the a22 rows of an image do not depend on its batch neighbours
     (exercises every batch / head / XCD index map of the kernels); pinned top-k so the comparison is continuous."""
     from hipie_amd.config import Precision
-    g, model = build(Precision.parity())
+    g, model = build(getattr(Precision, policy)())
     imgs = _synth.synth_images([(192, 256), (192, 256), (192, 256)], seed=99)
     ids, mask, pmap = _synth.synth_token_ids(3, 9, 64, seed=74)
 
@@ -260,6 +263,35 @@ def test_full_size_open_vocabulary_configs(policy, n_classes, L, sizes):
     from hipie_amd.postprocess import inference
     res = inference(model, out, b, with_masks=False, with_sem_pan=False)
     assert int(res[0]["instances"].pred_classes.max()) < n_classes
+
+
+def test_full_size_wide_image_split_policy():
+    """the shipped eval yamls resize to MIN_SIZE_TEST 1024 / MAX_SIZE_TEST 2048: a 2:1 image becomes 1024 x 2048 = a 64 x 128 token grid,
+    wider than the 96 key slots of a global-attention tile.  The registry-default policy (split3) walks such grids column by column
+    (hipie_vit_attn_split, transposed form; reference-generated golden `global128` in tests/test_gpu_kernels.py).  Full-size ViT-H,
+    size-independent properties: shapes, finite outputs, batch-exchange equivariance with a real pad mask in the second image."""
+    import bench
+    from hipie_amd.config import HipieConfig, Precision
+    from hipie_amd.hipie_img import HIPIE_IMG
+    cfg = HipieConfig.vit_huge()
+    torch.manual_seed(0)
+    model = HIPIE_IMG(cfg, Precision.split3(), device="cuda")
+    bench.randomize_degenerate_inits(model)
+    model.finalize()
+    sizes = [(1024, 2048), (1000, 1920)]
+    b = bench.synth_batch(cfg, 2, 2048, 80, 194, torch.device("cuda"))
+    for item, (h, w) in zip(b, sizes):
+        item["image"] = item["image"][:, :h, :w].contiguous()
+    out = model.forward_raw(b)
+    fg, md = model.last_topk()
+    assert out["pred_masks"].shape[-2:] == (256, 512) and out["pred_masks_maskdino"].shape[-2:] == (256, 512)
+    for k in KEYS:
+        assert torch.isfinite(out[k].float()).all(), k
+    model.pin_topk(fg.flip(0).cpu(), md.flip(0).cpu())
+    swapped = model.forward_raw(b[::-1])
+    model.pin_topk(None, None)
+    for k in KEYS:
+        assert rel_err(swapped[k].float().flip(0).cpu(), out[k].float().cpu()) < 1e-3, k
 
 
 def test_split_policy_large_activations_stay_finite():

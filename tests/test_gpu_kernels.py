@@ -791,7 +791,7 @@ def test_decoder_heads_fused(dt, tol):
 
 
 # ------------------------------------------------------------------------------------------------ split-fp16 ("HL8") kernels
-@pytest.mark.parametrize("name", ["window14", "global16", "global64", "global_rect", "global84"])
+@pytest.mark.parametrize("name", ["window14", "global16", "global64", "global_rect", "global84", "global128"])
 def test_vit_attention_split_golden(name):
     """hipie_vit_attn_split on the reference-generated cases, fed the UNROUNDED fp32 qkv / tables as HL8 pairs: vs the fp32 oracle
     (the only 16-bit rounding left is the probability operand: 3e-4) and, through the projection, vs the reference golden."""
@@ -830,7 +830,10 @@ def test_vit_attention_split_golden(name):
     (1, 33, 50, 3, 64),
     (1, 84, 84, 2, 80),          # the 1344-pixel configuration: 96-slot tiles, bias_h recomputed per chunk of 16 key rows
     (2, 37, 70, 4, 64),          # wider than 64, token count not a multiple of the 256-query workgroup, chunk boundary inside
-    (1, 70, 64, 1, 80)])         # 64 wide, more than 64 rows: the 4-wave two-block variant
+    (1, 70, 64, 1, 80),          # 64 wide, more than 64 rows: the 4-wave two-block variant
+    (1, 64, 128, 2, 80),         # a 1024 x 2048 image: wider than 96 -> the TRANSPOSED walk (key tile = a column of the grid)
+    (2, 40, 100, 2, 64),         # transposed, ragged everything
+    (1, 90, 112, 1, 80)])        # transposed onto the 96-slot tiles (height in (64, 96])
 def test_vit_attention_split_against_materialised_scores(B, gh, gw, heads, hd):
     """the reference's own formulation with the (N x N) score tensor materialised in fp64 on the device, random fp32 operands with
     LARGE logits (|q.k| up to ~25: a single-fp16 q or k would move the probabilities by 1e-2)."""
@@ -969,6 +972,14 @@ def test_topk_ties_take_the_lowest_indices_in_order():
     got = ops.topk(yv, 50).cpu()
     want = torch.topk(y[:, :2000], 50, dim=1)[1]
     assert torch.equal(got, want)
+    # canonical keys: a NEGATIVE-signed NaN (0 * -inf) is still the largest value; -0.0 ties with +0.0 and the tie goes to the lower index
+    z = -torch.rand(2, 1500, generator=torch.Generator().manual_seed(78)) - 1.0
+    z[0, 700] = float("nan")
+    z[0, 700] = -z[0, 700].abs() if False else torch.tensor(float("nan")).copysign(torch.tensor(-1.0))
+    z[1, 40], z[1, 20], z[1, 30] = 0.0, -0.0, 0.0
+    got = ops.topk(z.cuda(), 4).cpu()
+    assert got[0, 0].item() == 700
+    assert got[1, :3].tolist() == [20, 30, 40]
 
 
 @pytest.mark.gpu

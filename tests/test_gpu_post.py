@@ -277,3 +277,41 @@ def test_post_product_with_maskclip_matches_reference():
     assert info == g.meta["segments"]
     assert (pan.cpu().long() != g["post_panoptic"].long()).float().mean() < 1e-3
     assert rel_err(g.like("post_semseg", r["sem_seg"].cpu().float()), g["post_semseg"]) < 1e-3
+
+
+def test_post_maskclip_mixed_sizes_match_single_image_runs():
+    """MODEL.CLIP.ENABLED in a MIXED-size batch: MaskCLIP resizes image and mask logits independently, so image i must be scored with
+    the logits of its own canvas -- every image of the batch gets the result of its own B = 1 run (the only case the reference has)."""
+    from hipie_amd.postprocess import inference
+    from util import rel_err
+    g, m = _clip_setup(True)
+    P = g.meta["post"]
+    sizes = [(96, 160), (160, 96)]
+    a22 = _synth.synth_a22(sizes, P["n_bg"], P["n_fg"], P["n_md"], P["L"], seed=P["seed"] + 1)
+    pmap = {int(k): v for k, v in g.meta["pmap"].items()}
+    is_thing = {int(k): v for k, v in g.meta["is_thing"].items()}
+    imgs = _synth.synth_images(sizes, seed=97)
+    model = fake_model(P["n_bg"], clip_alpha=0.4, clip_beta=0.45, clip_agg_mode="MUL", clip_fg_a=0.3, clip_fg_b=1.7, pano_temp_fg=0.06)
+    model.enable_clip, model.clip, model.train_labels = True, m, g.meta["train_labels"]
+    s = model.cfg.mask_stride
+
+    def item(i):
+        return {"task": "detection", "positive_map_label_to_token": pmap, "is_thing": is_thing, "image": imgs[i].cuda(),
+                "open_seg_labels": g.meta["test_labels"]}
+    out = {k: v.cuda() for k, v in a22.items()}
+    out["image_sizes"] = sizes
+    both = inference(model, out, [item(0), item(1)])
+    assert out["pred_masks"].shape[-2:] == (160 // s, 160 // s)
+    for i in range(2):
+        hm, wm = -(-sizes[i][0] // 32) * 32 // s, -(-sizes[i][1] // 32) * 32 // s
+        one = {k: v[i:i + 1].cuda() for k, v in a22.items()}
+        one["pred_masks"] = one["pred_masks"][..., :hm, :wm].contiguous()
+        one["pred_masks_maskdino"] = one["pred_masks_maskdino"][..., :hm, :wm].contiguous()
+        one["image_sizes"] = [sizes[i]]
+        alone = inference(model, one, [item(i)])[0]["instances"]
+        got = both[i]["instances"]
+        n = int((alone.scores > 0).sum())
+        assert n > 20
+        assert torch.equal(got.pred_classes[:n], alone.pred_classes[:n])
+        assert rel_err(got.scores.cpu(), alone.scores.cpu()) < 1e-4
+        assert rel_err(got.pred_boxes.tensor[:n].cpu(), alone.pred_boxes.tensor[:n].cpu()) < 1e-5

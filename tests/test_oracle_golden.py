@@ -45,7 +45,7 @@ def vit_attn_case(g, name):
     return c, sd, x
 
 
-@pytest.mark.parametrize("name", ["window14", "global16", "global64", "global_rect", "global84"])
+@pytest.mark.parametrize("name", ["window14", "global16", "global64", "global_rect", "global84", "global128"])
 def test_vit_attention(name):
     g = Golden("vit_attn")
     c, sd, x = vit_attn_case(g, name)
