@@ -172,6 +172,34 @@ def cpu_baseline(cfg_dict, size, L, n_classes, budget_s=150.0, emit=None):
                       % (note, size, size, L, cfg_dict["vit_depth"], s_img, t_win, t_glob)}
 
 
+def cpu_baseline_r50(size=512):
+    """BASELINE configs[0] on the host cores ("the reference's CPU-runnable case"): the oracle's whole path behind the ResNet-50
+    backbone on ONE 512 x 512 image with ONE referring expression, 1 warm-up + median of 3."""
+    from oracle import model as om
+    from hipie_amd.config import HipieConfig, Precision
+    from hipie_amd.hipie_img import HIPIE_IMG
+    threads = min(effective_cores(), 64)
+    torch.set_num_threads(threads)
+    torch.set_grad_enabled(False)
+    cfg = HipieConfig.r50()
+    c = cfg.to_dict()
+    m = HIPIE_IMG(cfg, Precision.parity(), device="cpu")
+    randomize_degenerate_inits(m)
+    sd = {k: v.float() for k, v in m.state_dict().items()}
+    del m
+    batch = synth_batch(None, 1, size, 1, 12, "cpu", seed=1, task="grounding")
+    ids, mask = batch[0]["input_ids"][None], batch[0]["attention_mask"][None]
+
+    def full_forward():
+        lang = om.bert_encoder(ids, mask, sd, "text_encoder.body.model.", c)
+        om.coco_inference([batch[0]["image"]], lang, sd, c, task="grounding")
+    t = _median_time(full_forward, runs=3, warmup=1)
+    return {"value": round(1.0 / t, 4), "unit": "images/sec", "cores": threads, "kind": "port", "extrapolated": False,
+            "sample": "BASELINE configs[0]: oracle/ (fp32 PyTorch CPU restatement of the reference) with the ResNet-50 backbone, ONE %dx%d image + "
+                      "ONE text prompt (L=%d), full forward (text encoder, backbone, both heads): %.2f s, median of 3 after 1 warm-up, "
+                      "torch.set_num_threads(%d)" % (size, size, int(ids.shape[1]), t, threads)}
+
+
 def parity_error(policy, device, full_size=True):
     """max|a-b| / max|b| of every a22 output under `policy` against the fixtures produced by the reference's own
     DDETRSegmUniDN.coco_inference (top-k pinned): tests/golden/e2e_full.npz (the headline configuration itself: full ViT-H, shipped
@@ -237,10 +265,23 @@ def main():
                     "(hipie_amd/tuning/*.csv: the hipBLASLt solution picked per ViT-H linear shape; library plumbing)")
     ap.add_argument("--timed-only", action="store_true", help="stop right after the timed region (for kernel traces: no "
                     "extra roofline / post-processing passes at the end of the trace)")
+    ap.add_argument("--config", type=int, default=None, choices=[0, 1, 2, 3, 4],
+                    help="literal BASELINE.json configs[i] (overrides --model/--size/--batch/--classes/--text-len/--task): 0 = R50, one 512x512 "
+                         "image + one text prompt; 1 = R50, 1024^2, bs 4, 80 classes; 2 = ViT-H, 1024^2, bs 8, 80 classes (the default, the "
+                         "configuration the metric is quoted on); 3 = ViT-H, 1024^2, bs 8 per GPU (64 images at --gpus 8), 150 ADE prompts "
+                         "(L=815: chunked BERT); 4 = ViT-H, 1344^2 canvas (1333 long edge), global bs 8 (8 // gpus per GPU), 1203 LVIS prompts cut at L=4096")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--breakdown", action="store_true", help="after the timed region, time every hand-written kernel class "
                     "and the main stages of one extra step (stderr)")
     args = ap.parse_args()
+    if args.config is not None:
+        preset = {0: dict(model="r50", size=512, batch=1, classes=1, text_len=12, task="grounding"),
+                  1: dict(model="r50", size=1024, batch=4, classes=80, text_len=194, task="detection"),
+                  2: dict(model="vit_huge", size=1024, batch=8, classes=80, text_len=194, task="detection"),
+                  3: dict(model="vit_huge", size=1024, batch=8, classes=150, text_len=815, task="detection"),
+                  4: dict(model="vit_huge", size=1344, batch=max(1, 8 // max(args.gpus, 1)), classes=1203, text_len=4096, task="detection")}[args.config]
+        for k, v in preset.items():
+            setattr(args, k, v)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: re-launch under torch.distributed.run, one rank per GPU, loopback rendezvous
@@ -258,6 +299,11 @@ def main():
         cfg = getattr(HipieConfig, args.model)()
         def emit(d):
             print("CPU_BASELINE " + json.dumps(d), flush=True)
+        # the CPU figure of configs[0] (R50, one 512 x 512 image, one text prompt; seconds) first, then the ViT-H one
+        try:
+            print("CPU_BASELINE_R50 " + json.dumps(cpu_baseline_r50()), flush=True)
+        except Exception as e:
+            print("CPU_BASELINE_R50 " + json.dumps({"value": None, "error": repr(e)[:200]}), flush=True)
         emit(cpu_baseline(cfg.to_dict(), args.size, 194, 80, emit=emit))
         return
 
@@ -474,10 +520,13 @@ def main():
             "dtype": {"split": "f16x3 (split-fp16 operands, fp32 accumulate: fp32-class)", "fast": "f16", "parity": "f32+f16attn", "bf16": "bf16",
                       "default": "bf16+f32head"}[args.precision],
             "data": "synthetic (uint8-valued random images resident in HBM, synthetic BERT token ids, random-init weights)",
-            "config": {"workload": "BASELINE.json configs[%s]: %s, %dx%d, batch %d per GPU, %d class prompts (L=%d), detection"
-                                   % ({80: "1" if args.model == "r50" else ("2" if world == 1 else "3 (global batch, 80-class prompt)"), 150: "3",
+            "config": {"workload": "BASELINE.json configs[%s]: %s, %dx%d, batch %d per GPU, %d %s (L=%d), %s"
+                                   % (str(args.config) if args.config is not None else
+                                      {80: "1" if args.model == "r50" else ("2" if world == 1 else "2 per GPU (weak scaling of the metric's workload: "
+                                            "%d images, 80-class prompt; configs[3] literally = --config 3)" % (args.batch * world)), 150: "3",
                                        1203: "4"}.get(n_classes, "-"),
-                                      args.model, args.size, args.size, args.batch, n_classes, L),
+                                      args.model, args.size, args.size, args.batch, n_classes,
+                                      "text prompt" if args.task == "grounding" else "class prompts", L, args.task),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "precision_policy": args.precision,
                        "launch": "hipGraph replay" if graph is not None else "eager",
                        "constants": "weight- and geometry-only tensors (rel-pos tables, position embeddings, valid ratios) are "
@@ -505,6 +554,9 @@ def main():
                 tag = [l for l in out_txt.splitlines() if l.startswith("CPU_BASELINE ")]
                 line["cpu_baseline"] = json.loads(tag[-1][len("CPU_BASELINE "):]) if tag else \
                     {"value": None, "error": (err_txt or out_txt)[-300:]}
+                tag = [l for l in out_txt.splitlines() if l.startswith("CPU_BASELINE_R50 ")]
+                if tag:
+                    line["cpu_baseline_r50_512"] = json.loads(tag[-1][len("CPU_BASELINE_R50 "):])
             except Exception as e:
                 line["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
         print(json.dumps(line))
