@@ -50,7 +50,7 @@ class Precision:
         """the TIMED policy: the reference's fp32 arithmetic reproduced on the 16-bit matrix pipe.  Every linear runs as the split-fp16
         GEMM (hipie_gemm, HIPIE_HL8 operands: x.w = x_lo.w_hi + x_hi.w_lo + x_hi.w_hi with fp32 accumulation, ~2^-22 operand error);
         the ViT attention forms its logits AND its P.V product the same way (hipie_vit_attn_split: q, k, P, V are fp16 pairs); BERT and
-        the decoders' query self-attention run in exact fp32 (hipie_attn_f32); the image -> text direction of the vision-language fusion
+        the decoders' query self-attention run at fp32-class accuracy on fp16 pairs split in the kernel (hipie_attn_split; round 3: exact fp32 FMA chains, hipie_attn_f32); the image -> text direction of the vision-language fusion
         as batched split GEMMs around a masked softmax (ops.bi_i2t_split), the text -> image direction on fp16 operands with fp32 output;
         streams / norms / softmax / deformable sampling / convolutions fp32 as in the parity policy, the mask contraction as three bf16
         products of split operands.  Measured against the reference's own coco_inference: 1.6e-4 at the headline configuration

@@ -159,7 +159,7 @@ class BertModel(nn.Module):
 
     def _forward_split(self, input_ids, attention_mask):
         """Precision.split3: every dense layer as the split-fp16 GEMM (fused QKV, fp32-class), the attention core in fp32
-        (hipie_attn_f32: tests/study/prec_sim.py on the full-size fixture -- single-fp16 q / k / v here move pred_masks by 4e-3), the post-norm
+        (hipie_attn_split: tests/study/prec_sim.py on the full-size fixture -- single-fp16 q / k / v here move pred_masks by 4e-3), the post-norm
         stream fp32; the LayerNorm passes emit the next GEMM operand as HL8, the intermediate GEMM applies the exact-erf GELU and
         writes HL8 for the output GEMM.  8 launches per layer."""
         emb = self.embeddings
@@ -174,14 +174,14 @@ class BertModel(nn.Module):
         xh = ops.to_hl8(x)
         for layer in self.encoder.layer:
             at = layer.attention.self
-            exact = ops.attn_f32_ok(hd)          # the attention core in fp32 (hipie_attn_f32): at the headline configuration fp16 q / k / v
+            exact = ops.attn_f32_ok(hd)          # the attention core at fp32-class accuracy (hipie_attn_split): at the headline configuration single-fp16 q / k / v
             qkv = ops.split_linear(xh, at, "qkv", at.query.weight, None, out_fmt=ops.F32 if exact else ops.F16, x_hl8=True,   # here cost 4e-3
                                    weight_fn=lambda at=at: torch.cat([at.query.weight, at.key.weight, at.value.weight]),
                                    bias_fn=lambda at=at: torch.cat([at.query.bias, at.key.bias, at.value.bias]),
                                    params=(at.query.weight, at.key.weight, at.value.weight, at.query.bias, at.key.bias, at.value.bias)
                                    ).view(B, L, 3, heads, hd)
             if exact:
-                ctx = ops.attn_f32(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 1.0 / math.sqrt(hd), key_mask=kmask)
+                ctx = ops.attn_split(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 1.0 / math.sqrt(hd), key_mask=kmask)
             else:
                 ctx = ops.flash_attn(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 1.0 / math.sqrt(hd), key_mask=kmask, out_f32=True)
             so = layer.attention.output

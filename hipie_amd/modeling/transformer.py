@@ -573,11 +573,11 @@ class MultiheadAttention(nn.Module):
         hd = C // self.n_heads
         split = getattr(self, "split", False)
         if split and x_qk.is_cuda and w.dtype == torch.float32 and ops.attn_f32_ok(hd):
-            # split policy: fp32 projections (split GEMM) and the EXACT fp32 attention core -- the query self-attention is 0.1 % of the
+            # split policy: fp32 projections (split GEMM) and the fp32-CLASS attention core (hipie_attn_split) -- the query self-attention is 0.1 % of the
             # step's flops, and fp16 q / k / v here cost 5e-4 .. 1e-3 on the decoder states at the headline configuration
             qk = _lin(self, "in_qk", x_qk, w[:2 * C], b[:2 * C]).view(B, N, 2, self.n_heads, hd)
             v = _lin(self, "in_v", x_v, w[2 * C:], b[2 * C:]).view(B, N, self.n_heads, hd)
-            return self.out_proj(ops.attn_f32(qk[:, :, 0], qk[:, :, 1], v, hd ** -0.5))
+            return self.out_proj(ops.attn_split(qk[:, :, 0], qk[:, :, 1], v, hd ** -0.5))
         of = ops.F16 if (split and self.attn_dtype == torch.float16) else ops.F32
         qk = _lin(self, "in_qk", x_qk, w[:2 * C], b[:2 * C], out_fmt=of).to(self.attn_dtype).view(B, N, 2, self.n_heads, hd)
         v = _lin(self, "in_v", x_v, w[2 * C:], b[2 * C:], out_fmt=of).to(self.attn_dtype).view(B, N, self.n_heads, hd)

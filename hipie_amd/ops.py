@@ -249,10 +249,7 @@ def bi_i2t_split(q_hl8, k, vl, text_mask, heads, clamp=50000.0):
     return out
 
 
-@_timed("attn_f32")
-def attn_f32(q, k, v, scale, key_mask=None):
-    """hipie_attn_f32: exact fp32 softmax attention.  q (B,Nq,H,hd), k, v (B,Nk,H,hd) fp32 views with hd contiguous and heads hd apart
-    (column blocks of one projection output are fine); hd 32 | 64; key_mask (B,Nk) bool / uint8 -> (B, Nq, H*hd) fp32."""
+def _small_attn(fn_name, q, k, v, scale, key_mask):
     lib = _lib.load()
     B, Nq, H, hd = q.shape
     Nk = k.shape[1]
@@ -260,16 +257,30 @@ def attn_f32(q, k, v, scale, key_mask=None):
         if not t.is_cuda:
             raise RuntimeError("Not implemented on the CPU (%s)" % n)
         if t.dtype != torch.float32 or t.stride(-1) != 1 or (H > 1 and t.stride(2) != hd):
-            raise RuntimeError("attn_f32: %s must be fp32 (B, N, H, hd) with hd contiguous and heads hd apart" % n)
+            raise RuntimeError("%s: %s must be fp32 (B, N, H, hd) with hd contiguous and heads hd apart" % (fn_name, n))
     out = torch.empty(B, Nq, H * hd, dtype=torch.float32, device=q.device)
     mp = None
     if key_mask is not None:
         key_mask = key_mask.to(torch.uint8).contiguous()
         mp = key_mask.data_ptr()
-    rc = lib.hipie_attn_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, out.data_ptr(), B, H, Nq, Nk, hd, q.stride(0), q.stride(1),
-                            k.stride(0), k.stride(1), v.stride(0), v.stride(1), float(scale), _stream())
-    _lib.check(rc, "hipie_attn_f32")
+    rc = getattr(lib, fn_name)(q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, out.data_ptr(), B, H, Nq, Nk, hd, q.stride(0), q.stride(1),
+                               k.stride(0), k.stride(1), v.stride(0), v.stride(1), float(scale), _stream())
+    _lib.check(rc, fn_name)
     return out
+
+
+@_timed("attn_f32")
+def attn_f32(q, k, v, scale, key_mask=None):
+    """hipie_attn_f32: exact fp32 softmax attention.  q (B,Nq,H,hd), k, v (B,Nk,H,hd) fp32 views with hd contiguous and heads hd apart
+    (column blocks of one projection output are fine); hd 32 | 64; key_mask (B,Nk) bool / uint8 -> (B, Nq, H*hd) fp32."""
+    return _small_attn("hipie_attn_f32", q, k, v, scale, key_mask)
+
+
+@_timed("attn_split")
+def attn_split(q, k, v, scale, key_mask=None):
+    """hipie_attn_split: the same attention on the matrix pipe at fp32-class accuracy (operands split into fp16 pairs in the kernel, three
+    products per logit, probabilities as an fp16 pair): what the split policy runs for BERT and the decoders' query self-attention."""
+    return _small_attn("hipie_attn_split", q, k, v, scale, key_mask)
 
 
 def attn_f32_ok(hd):

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPIE_ABI_VERSION 7
+#define HIPIE_ABI_VERSION 8
 
 /* element types of activations */
 #define HIPIE_F32 0
@@ -446,6 +446,16 @@ int hipie_softmax_hl8(const float* S, int64_t lds, void* P, int64_t ldp, int64_t
  *           models/maskdino/transformer_decoder/dino_decoder.py:222-240), which the reference computes in fp32.
  */
 int hipie_attn_f32(const float* q, const float* k, const float* v, const unsigned char* key_mask, float* out, int B, int H, int Nq, int Nk,
+                   int head_dim, int64_t q_sb, int64_t q_st, int64_t k_sb, int64_t k_st, int64_t v_sb, int64_t v_st, float scale,
+                   void* stream);
+
+/*
+ * The same attention (same operands, same output, same mask semantics) on the matrix pipe at fp32-CLASS accuracy: q (pre-multiplied by
+ * scale * log2 e), k, v are split in the kernel into fp16 pairs (22 mantissa bits), logits = three-product sums with fp32 accumulation, the
+ * probabilities an fp16 pair, O += V_hi.(P_hi + P_lo) + V_lo.P_hi -- the arithmetic of hipie_vit_attn_split.  Within 2e-6 of
+ * hipie_attn_f32; what the split policy runs (27 launches per step: 4.4 -> ~1 ms).  Replaces: the same reference code as hipie_attn_f32.
+ */
+int hipie_attn_split(const float* q, const float* k, const float* v, const unsigned char* key_mask, float* out, int B, int H, int Nq, int Nk,
                    int head_dim, int64_t q_sb, int64_t q_st, int64_t k_sb, int64_t k_st, int64_t v_sb, int64_t v_st, float scale,
                    void* stream);
 

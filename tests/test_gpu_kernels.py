@@ -1112,10 +1112,13 @@ def test_msda_backward_through_the_reference_module_name_and_contended_pixels():
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,Nq,Nk,H,hd,masked", [(2, 194, 194, 12, 64, True), (3, 910, 910, 8, 32, False), (2, 300, 300, 8, 32, False),
                                                  (1, 5, 37, 2, 64, True), (2, 512, 512, 12, 64, True)])
-def test_attn_f32_exact(B, Nq, Nk, H, hd, masked):
-    """hipie_attn_f32 (BERT / decoder query self-attention in the split policy) vs softmax attention in double; q / k / v are column blocks
-    of ONE projection output, large logits (|s| up to ~30), a padded tail and one fully masked sequence."""
+@pytest.mark.parametrize("which", ["attn_f32", "attn_split"])
+def test_attn_f32_exact(B, Nq, Nk, H, hd, masked, which):
+    """hipie_attn_f32 (exact fp32 FMA chains) and hipie_attn_split (the same attention on the matrix pipe from fp16 PAIRS, what the split
+    policy runs for BERT / the decoders' query self-attention) vs softmax attention in double; q / k / v are column blocks of ONE projection
+    output, large logits (|s| up to ~30), a padded tail and one fully masked sequence.  Same bound for both."""
     from hipie_amd import ops
+    attn = getattr(ops, which)
     g = torch.Generator().manual_seed(B * 1000 + Nq + hd)
     C = H * hd
     qkv = torch.randn(B, Nk, 3 * C, generator=g) * 1.5
@@ -1134,15 +1137,15 @@ def test_attn_f32_exact(B, Nq, Nk, H, hd, masked):
     want = torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), v.double()).reshape(B, Nq, C)
     dev = qkv.to(DEV)
     qd, kd, vd = (dev[:, :, i * C:(i + 1) * C].view(B, Nk, H, hd) for i in range(3))
-    got = ops.attn_f32(qd[:, :Nq], kd, vd, scale, key_mask=None if mask is None else mask.to(DEV))
+    got = attn(qd[:, :Nq], kd, vd, scale, key_mask=None if mask is None else mask.to(DEV))
     e = rel_err(got.cpu(), want.float())
-    print("attn_f32 %dx%d hd %d: %.2e" % (Nq, Nk, hd, e))
+    print("%s %dx%d hd %d: %.2e" % (which, Nq, Nk, hd, e))
     # fp32 scores of magnitude ~40 (log2 domain) carry 4e-6 of rounding into the exponent: the same bound as any fp32 evaluation
     assert got.dtype == torch.float32 and e < 1e-5
     if masked:                                     # a sequence with every key masked: zeros, not NaN
         m2 = mask.clone()
         m2[0] = False
-        got2 = ops.attn_f32(qd[:, :Nq], kd, vd, scale, key_mask=m2.to(DEV))
+        got2 = attn(qd[:, :Nq], kd, vd, scale, key_mask=m2.to(DEV))
         assert torch.isfinite(got2).all() and float(got2[0].abs().max()) == 0.0
 
 
