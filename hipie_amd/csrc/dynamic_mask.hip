@@ -157,7 +157,10 @@ static int launch_dm(const float* feats, const float* refs, const float* params,
 // One WAVE owns (4 instances, R low-res rows): it walks the rows, keeps the logits of the last two rows in a private LDS
 // ring and emits the two output rows of aligned_bilinear(x2) per step with 16-byte stores.  No workgroup barrier.
 
-template <typename T, typename OutT, int R, int TU>
+// SPLIT (round 4; T = fp16): the fp32-class form for the split policy.  Every weight and every activation is an fp16 PAIR x = hi + lo and
+// each product is the three-term sum  W_hi.x_hi + W_lo.x_hi + W_hi.x_lo  (fp32 accumulation; the coordinate columns are exact pairs
+// already): 15 MFMAs per tile instead of 5, ReLU in fp32 before the split.  Retires the fp32 VALU kernel (1.57 ms per step) in that policy.
+template <typename T, typename OutT, int R, int TU, bool SPLIT>
 __global__ __launch_bounds__(256) void dynamic_mask_mfma_kernel(const float* __restrict__ feats, const float* __restrict__ refs,
                                                                 const float* __restrict__ params, OutT* __restrict__ out,
                                                                 int Q, int H, int W, int stride) {
@@ -182,6 +185,8 @@ __global__ __launch_bounds__(256) void dynamic_mask_mfma_kernel(const float* __r
   const float* pm = params + (ibase + min(q0 + myinst, Q - 1)) * 169;
   const float* p3 = params + (ibase + min(q0 + (n & 3), Q - 1)) * 169;
   frag A1, A2[2], A3[2];
+  frag A1l, A2l[2], A3l[2];                              // SPLIT: the lo halves of the weights (coordinate columns: none)
+  auto lo_of = [](const float x) -> T { return (T)(x - (float)(T)x); };
   {
     float v[8];
     if (g == 0) {
@@ -195,15 +200,22 @@ __global__ __launch_bounds__(256) void dynamic_mask_mfma_kernel(const float* __r
       for (int c = 0; c < 4; ++c) { v[c] = 0.f; v[4 + c] = pm[o * 10 + 6 + c]; }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) A1[j] = (T)v[j];
+    for (int j = 0; j < 8; ++j) {
+      A1[j] = (T)v[j];
+      A1l[j] = (SPLIT && j >= 4) ? lo_of(v[j]) : (T)0.f;
+    }
   }
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int inst2 = 2 * s + (j >> 2), ch = 4 * g + (j & 3);
-      A2[s][j] = (T)(inst2 == myinst ? pm[80 + o * 8 + ch] : 0.f);
-      A3[s][j] = (T)((n < 4 && inst2 == n) ? p3[144 + ch] : 0.f);
+      const float w2 = inst2 == myinst ? pm[80 + o * 8 + ch] : 0.f;
+      const float w3 = (n < 4 && inst2 == n) ? p3[144 + ch] : 0.f;
+      A2[s][j] = (T)w2;
+      A3[s][j] = (T)w3;
+      A2l[s][j] = SPLIT ? lo_of(w2) : (T)0.f;
+      A3l[s][j] = SPLIT ? lo_of(w3) : (T)0.f;
     }
   }
   f32x16 c1, c2, c3;
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(256) void dynamic_mask_mfma_kernel(const float* __r
     const float npy = g == 0 ? -((float)(stride * row) + half) : 0.f;
     // ---- low-resolution logits of this row, TU 32-pixel tiles in flight ----
     for (int t = 0; t < NT; t += TU) {
-      frag X[TU];
+      frag X[TU], Xl[TU];
 #pragma unroll
       for (int u = 0; u < TU; ++u) {
         const int col = min((t + u) * 32 + n, W - 1);
@@ -247,37 +259,51 @@ __global__ __launch_bounds__(256) void dynamic_mask_mfma_kernel(const float* __r
         const float npx = g == 0 ? -((float)(stride * col) + half) : 0.f;
         X[u][0] = (T)npx; X[u][1] = (T)npx; X[u][2] = (T)npy; X[u][3] = (T)npy;      // zero in the upper lane half
         X[u][4] = (T)f0; X[u][5] = (T)f1; X[u][6] = (T)f2; X[u][7] = (T)f3;
+        if (SPLIT) {
+          Xl[u][0] = (T)0.f; Xl[u][1] = (T)0.f; Xl[u][2] = (T)0.f; Xl[u][3] = (T)0.f;
+          Xl[u][4] = lo_of(f0); Xl[u][5] = lo_of(f1); Xl[u][6] = lo_of(f2); Xl[u][7] = lo_of(f3);
+        }
       }
       f32x16 h[TU];
 #pragma unroll
-      for (int u = 0; u < TU; ++u) h[u] = M::mma(A1, X[u], c1);
+      for (int u = 0; u < TU; ++u) {
+        h[u] = M::mma(A1, X[u], c1);
+        if (SPLIT) h[u] = M::mma(A1, Xl[u], M::mma(A1l, X[u], h[u]));
+      }
       // ReLU after the rounding (the same value: rounding is monotonic and keeps 0): one packed integer max per two
       // activations -- a negative 16-bit float is a negative int16
-      frag Hb[TU][2];
+      frag Hb[TU][2], Hl[TU][2];
+      auto activate = [&]() {
 #pragma unroll
-      for (int u = 0; u < TU; ++u)
+        for (int u = 0; u < TU; ++u)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          f32x8 w8;
+          for (int s = 0; s < 2; ++s) {
+            f32x8 w8;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) w8[j] = h[u][8 * s + j];
-          Hb[u][s] = __builtin_convertvector(w8, frag);          // packed conversions (v_cvt_pk_*), round to nearest even
-          Hb[u][s] = __builtin_bit_cast(frag, __builtin_elementwise_max(__builtin_bit_cast(s16x8, Hb[u][s]), zero8));
-        }
+            for (int j = 0; j < 8; ++j) w8[j] = SPLIT ? fmaxf(h[u][8 * s + j], 0.f) : h[u][8 * s + j];
+            Hb[u][s] = __builtin_convertvector(w8, frag);          // packed conversions (v_cvt_pk_*), round to nearest even
+            if (SPLIT) {
+              f32x8 r8;
 #pragma unroll
-      for (int u = 0; u < TU; ++u) h[u] = M::mma(A2[1], Hb[u][1], M::mma(A2[0], Hb[u][0], c2));
+              for (int j = 0; j < 8; ++j) r8[j] = w8[j] - (float)Hb[u][s][j];
+              Hl[u][s] = __builtin_convertvector(r8, frag);
+            } else {
+              Hb[u][s] = __builtin_bit_cast(frag, __builtin_elementwise_max(__builtin_bit_cast(s16x8, Hb[u][s]), zero8));
+            }
+          }
+      };
+      activate();
 #pragma unroll
-      for (int u = 0; u < TU; ++u)
+      for (int u = 0; u < TU; ++u) {
+        h[u] = M::mma(A2[1], Hb[u][1], M::mma(A2[0], Hb[u][0], c2));
+        if (SPLIT) h[u] = M::mma(A2[1], Hl[u][1], M::mma(A2[0], Hl[u][0], M::mma(A2l[1], Hb[u][1], M::mma(A2l[0], Hb[u][0], h[u]))));
+      }
+      activate();
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          f32x8 w8;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) w8[j] = h[u][8 * s + j];
-          Hb[u][s] = __builtin_convertvector(w8, frag);          // packed conversions (v_cvt_pk_*), round to nearest even
-          Hb[u][s] = __builtin_bit_cast(frag, __builtin_elementwise_max(__builtin_bit_cast(s16x8, Hb[u][s]), zero8));
-        }
-#pragma unroll
-      for (int u = 0; u < TU; ++u) h[u] = M::mma(A3[1], Hb[u][1], M::mma(A3[0], Hb[u][0], c3));
+      for (int u = 0; u < TU; ++u) {
+        h[u] = M::mma(A3[1], Hb[u][1], M::mma(A3[0], Hb[u][0], c3));
+        if (SPLIT) h[u] = M::mma(A3[1], Hl[u][1], M::mma(A3[0], Hl[u][0], M::mma(A3l[1], Hb[u][1], M::mma(A3l[0], Hb[u][0], h[u]))));
+      }
 #pragma unroll
       for (int u = 0; u < TU; ++u) {
         const int col = (t + u) * 32 + n;
@@ -330,20 +356,21 @@ __global__ __launch_bounds__(256) void dynamic_mask_mfma_kernel(const float* __r
   }
 }
 
-template <typename T, typename OutT, int R, int TU>
+template <typename T, typename OutT, int R, int TU, bool SPLIT = false>
 static int launch_dm_mfma_v(const float* feats, const float* refs, const float* params, void* out, int B, int Q, int H, int W,
                             int stride, hipStream_t st) {
   const int strips = (H + R - 1) / R;
   dim3 grid((strips + 3) / 4, B * ((Q + 3) / 4));
   const size_t lds = (size_t)4 * 2 * 4 * (W + 8) * sizeof(float);
-  hipLaunchKernelGGL((dynamic_mask_mfma_kernel<T, OutT, R, TU>), grid, dim3(256), lds, st, feats, refs, params, (OutT*)out, Q, H, W, stride);
+  hipLaunchKernelGGL((dynamic_mask_mfma_kernel<T, OutT, R, TU, SPLIT>), grid, dim3(256), lds, st, feats, refs, params, (OutT*)out, Q, H, W, stride);
   return check_launch("dynamic_mask16");
 }
 
-template <typename T, typename OutT>
+template <typename T, typename OutT, bool SPLIT = false>
 static int launch_dm_mfma(const float* feats, const float* refs, const float* params, void* out, int B, int Q, int H, int W,
                           int stride, hipStream_t st) {
   // measured at B = 8, Q = 910, 128 x 128 (f16 out): 16 rows / 4 tiles in flight 0.321 ms; 16 / 2 0.356; 32 / 4 0.347; 32 / 2 0.373
+  if (SPLIT) return launch_dm_mfma_v<T, OutT, 16, 2, SPLIT>(feats, refs, params, out, B, Q, H, W, stride, st);
   if (W > 64) return launch_dm_mfma_v<T, OutT, 16, 4>(feats, refs, params, out, B, Q, H, W, stride, st);
   return launch_dm_mfma_v<T, OutT, 16, 2>(feats, refs, params, out, B, Q, H, W, stride, st);
 }
@@ -373,7 +400,7 @@ extern "C" int hipie_dynamic_mask16(const float* feats, const float* refs, const
   using namespace hipie;
   HIPIE_REQUIRE(feats && refs && params && out, "dynamic_mask16: null pointer");
   HIPIE_REQUIRE(B >= 0 && Q >= 0 && H > 0 && W > 0 && stride > 0, "dynamic_mask16: bad shape");
-  HIPIE_REQUIRE(dtype == HIPIE_F16 || dtype == HIPIE_BF16, "dynamic_mask16: operand dtype must be f16 or bf16");
+  HIPIE_REQUIRE(dtype == HIPIE_F16 || dtype == HIPIE_BF16 || dtype == HIPIE_HL8, "dynamic_mask16: operand dtype must be f16, bf16 or HL8 (split fp16 pairs)");
   HIPIE_REQUIRE(W % 4 == 0 && W <= DM_MAXW, "dynamic_mask16: W=%d must be a multiple of 4 and <= %d", W, DM_MAXW);
   HIPIE_REQUIRE(stride % 4 == 0 && (long)stride * W <= 8192 && (long)stride * H <= 8192,
                 "dynamic_mask16: pixel coordinates must be exact in 16 bit (stride %% 4 == 0, stride * size <= 8192)");
@@ -386,6 +413,13 @@ extern "C" int hipie_dynamic_mask16(const float* feats, const float* refs, const
     case HIPIE_F16: return launch_dm_mfma<T, f16_t>(feats, refs, params, out, B, Q, H, W, stride, st);                    \
     case HIPIE_BF16: return launch_dm_mfma<T, bf16_t>(feats, refs, params, out, B, Q, H, W, stride, st);                  \
     default: return set_err(HIPIE_EINVAL, "dynamic_mask16: bad out_dtype %d", out_dtype);                                 \
+  }
+  if (dtype == HIPIE_HL8) {            // fp32-class: weights and activations as fp16 pairs, three products each
+    switch (out_dtype) {
+      case HIPIE_F32: return launch_dm_mfma<f16_t, float, true>(feats, refs, params, out, B, Q, H, W, stride, st);
+      case HIPIE_F16: return launch_dm_mfma<f16_t, f16_t, true>(feats, refs, params, out, B, Q, H, W, stride, st);
+      default: return set_err(HIPIE_EINVAL, "dynamic_mask16 (split): out_dtype %d (fp32 | fp16)", out_dtype);
+    }
   }
   if (dtype == HIPIE_F16) { HIPIE_DM16(f16_t) } else { HIPIE_DM16(bf16_t) }
 #undef HIPIE_DM16

@@ -48,7 +48,9 @@ class DDETRSegmUniDN(nn.Module):
         self.mask_dino = MaskDINOHead(cfg, detr.backbone.num_channels, precision)
         self.mask_logit_dtype = precision.act      # mask logits leave in the activation dtype (fp32 in the parity policy)
         # 16-bit head policies: the dynamic 10-8-8-1 layers on the matrix pipe (hipie_dynamic_mask16); fp32: the VALU kernel
-        self.mask_mlp_dtype = precision.head if precision.head in (torch.float16, torch.bfloat16) else None
+        # split policy: the same kernel on fp16 pairs (fp32-class)
+        self.mask_mlp_dtype = "split" if getattr(precision, "split", False) else (
+            precision.head if precision.head in (torch.float16, torch.bfloat16) else None)
         self.feature_keys = ["res3", "res4", "res5"]
         self.mask_dino_cls_embed = _get_clones(self.detr.class_embed[0], cfg.md_dec_layers + 2)
         self.cfg = cfg

@@ -398,7 +398,9 @@ class BiMultiHeadAttention(nn.Module):
         keep = attention_mask_l != 0
         vh = ops.to_hl8(v.float().contiguous())                                 # the visual stream once, for its three projections
         q_hl8 = _lin(self, "q_scaled", vh, wq, bq, out_fmt=ops.HL8, x_hl8=True)
-        q16 = _lin(self, "q_scaled", vh, wq, bq, out_fmt=ops.F16, x_hl8=True).view(B, Nv, H, hd)
+        # the text -> image direction reads the same scaled projection as single fp16: that is the `hi` half of every HL8 group (hi = fp16(x)
+        # by construction of hl_split) -- one strided copy instead of a second 174080 x 2048 x 256 GEMM
+        q16 = q_hl8.view(B * Nv, H * hd // 8, 2, 8)[:, :, 0, :].reshape(B, Nv, H, hd)
         vv16 = self.values_v_proj(vh, x_hl8=True, out_fmt=ops.F16).view(B, Nv, H, hd)
         k32 = self.l_proj(l)
         vl32 = self.values_l_proj(l)

@@ -415,17 +415,19 @@ def mask_einsum16(mask_embed, mask_features, split=True, out_dtype=None, row_bia
 def dynamic_mask(mask_feats, ref_points, params, num_queries, stride=8, up=2, out_dtype=torch.float32, mlp_dtype=None):
     """mask_feats (B,8,H,W) f32; ref_points (B*Q,2) f32 pixels; params (B*Q,169) f32 -> (B*Q, up*H, up*W).
     mlp_dtype fp16 / bf16: the three layers on the matrix pipe with operands of that type (hipie_dynamic_mask16; up = 2,
-    W % 4 == 0, stride % 4 == 0); None / fp32: the fp32 VALU kernel."""
+    W % 4 == 0, stride % 4 == 0); "split": the same kernel on fp16 PAIRS (weights and activations hi + lo, three products each: fp32-class,
+    the split policy); None / fp32: the fp32 VALU kernel."""
     lib = _lib.load()
     B, C, H, W = mask_feats.shape
     if C != 8 or params.shape[-1] != 169:
         raise RuntimeError("dynamic_mask: expects 8 feature channels and 169 parameters per instance")
     n = B * num_queries
     out = torch.empty(n, up * H, up * W, dtype=out_dtype, device=mask_feats.device)
-    if mlp_dtype in (torch.float16, torch.bfloat16) and up == 2 and W % 4 == 0 and stride % 4 == 0 and stride * max(H, W) <= 8192:
+    split = mlp_dtype == "split" and out_dtype in (torch.float32, torch.float16)
+    if (split or mlp_dtype in (torch.float16, torch.bfloat16)) and up == 2 and W % 4 == 0 and stride % 4 == 0 and stride * max(H, W) <= 8192:
         rc = lib.hipie_dynamic_mask16(_chk(mask_feats, "mask_feats", torch.float32), _chk(ref_points, "ref_points", torch.float32),
                                       _chk(params, "params", torch.float32), out.data_ptr(), B, num_queries, H, W,
-                                      int(stride), _DT[mlp_dtype], _DT[out_dtype], _stream())
+                                      int(stride), HL8 if split else _DT[mlp_dtype], _DT[out_dtype], _stream())
         _lib.check(rc, "hipie_dynamic_mask16")
         return out
     rc = lib.hipie_dynamic_mask(_chk(mask_feats, "mask_feats", torch.float32), _chk(ref_points, "ref_points", torch.float32),

@@ -206,6 +206,41 @@ def test_dynamic_mask16_golden(name, dt, tol):
     assert rel_err(g.like(name + "_out", got), g[name + "_out"]) < tol
 
 
+@pytest.mark.parametrize("name", ["sq", "rect"])
+def test_dynamic_mask_split_golden(name):
+    """the split form of the matrix-pipe kernel (weights and activations as fp16 pairs, three products per layer: what the split policy
+    runs) against the reference's fp32 output and the oracle at the fp32 kernel's own tolerance class."""
+    from hipie_amd import ops
+    g = Golden("dynamic_mask")
+    c, feats, refs, params = dyn_case(g, name)
+    if c["W"] % 4:
+        pytest.skip("hipie_dynamic_mask16 needs W % 4 == 0")
+    got = ops.dynamic_mask(feats.to(DEV), refs[0].contiguous().to(DEV), params[0].contiguous().to(DEV), c["Q"], stride=8, up=2,
+                           mlp_dtype="split").cpu()
+    got = got.view(1, c["B"] * c["Q"], 2 * c["H"], 2 * c["W"])
+    e = rel_err(g.like(name + "_out", got), g[name + "_out"])
+    print("dynamic_mask split %s: %.2e" % (name, e))
+    assert e < 2e-5
+
+
+@pytest.mark.parametrize("B,Q,H,W", [(2, 9, 16, 32), (1, 6, 37, 168), (3, 5, 20, 44), (1, 910, 8, 128)])
+def test_dynamic_mask_split_ragged_vs_fp32_kernel(B, Q, H, W):
+    """ragged shapes (Q % 4 != 0, W % 32 != 0, H % 16 != 0): the split matrix-pipe form against the fp32 VALU kernel and the oracle"""
+    from hipie_amd import ops
+    gen = torch.Generator().manual_seed(B * 1000 + Q + 7)
+    feats = torch.randn(B, 8, H, W, generator=gen)
+    refs = torch.rand(B * Q, 2, generator=gen) * torch.tensor([8.0 * W, 8.0 * H])
+    params = torch.randn(B * Q, 169, generator=gen) * 0.3
+    params[:, 0:80:10] *= 0.01
+    params[:, 1:80:10] *= 0.01
+    got = ops.dynamic_mask(feats.to(DEV), refs.to(DEV), params.to(DEV), Q, stride=8, up=2, mlp_dtype="split").cpu()
+    ref = ops.dynamic_mask(feats.to(DEV), refs.to(DEV), params.to(DEV), Q, stride=8, up=2).cpu()
+    full = oo.dynamic_mask(feats, refs[None], params[None], [Q] * B, stride=8, up=2)[0]
+    e1, e2 = rel_err(got, ref), rel_err(got, full)
+    print("dynamic_mask split %dx%dx%dx%d: vs fp32 kernel %.2e, vs oracle %.2e" % (B, Q, H, W, e1, e2))
+    assert e1 < 2e-5 and e2 < 2e-5          # the tolerance class of the fp32 kernels of this library (DESIGN.md section 6)
+
+
 @pytest.mark.parametrize("B,Q,H,W,dt,odt", [(2, 9, 16, 32, torch.float16, torch.float32), (1, 6, 37, 168, torch.float16, torch.float16),
                                             (3, 5, 20, 44, torch.bfloat16, torch.float32), (1, 910, 8, 128, torch.float16, torch.float32)])
 def test_dynamic_mask16_matches_rounded_formulation(B, Q, H, W, dt, odt):
