@@ -216,12 +216,14 @@ def parity_error(policy, device, full_size=True):
             "pred_boxes_maskdino"]
     res, worst = {}, 0.0
     fixtures = ["e2e_deep", "e2e_tiny"]
+    if full_size and os.path.exists(os.path.join(ROOT, "tests", "golden", "e2e_full_refinit.npz")):
+        fixtures.insert(0, "e2e_full_refinit")      # the headline configuration with weights from the reference's OWN initialisation
     if full_size and os.path.exists(os.path.join(ROOT, "tests", "golden", "e2e_full.npz")):
-        fixtures.insert(0, "e2e_full")
+        fixtures.insert(0, "e2e_full")              # ... and from the (harder) default synthetic distribution: the gate
     for fixture in fixtures:
         g = Golden(fixture)
         model = HIPIE_IMG(HipieConfig.from_dict(g.meta["cfg"]), policy, device=device)
-        model.load_state_dict(_synth.synth_full_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}), strict=True)
+        model.load_state_dict(_synth.synth_full_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}, dist=g.meta.get("dist")), strict=True)
         imgs = _synth.synth_images([tuple(s) for s in g.meta["sizes"]], seed=73)
         ids, mask, pmap = _synth.synth_token_ids(2, g.meta["detection"]["n_classes"], 64, seed=74)
         model.pin_topk(g["detection_topk_fg"], g["detection_topk_md"])
@@ -232,9 +234,12 @@ def parity_error(policy, device, full_size=True):
         worst = max(worst, max(errs.values()))
         del model
         torch.cuda.empty_cache()
-    return {"max": float("%.2e" % worst), "tolerance": 1e-3, "within_tolerance": bool(worst <= 1e-3), "fixtures": res,
+    return {"max": float("%.2e" % worst), "tolerance": 1e-3, "within_tolerance": bool(worst <= 1e-3),
+            "within_tolerance_on": [f for f in fixtures if res[f]["max"] <= 1e-3], "fixtures": res,
             "against": "tests/golden/{%s}.npz: the reference's own coco_inference on the CPU, pinned top-k (e2e_full = full ViT-H at "
-                       "1024x1024, e2e_deep = the shipped depths on a narrow ViT)" % ",".join(fixtures)}
+                       "1024x1024 with the default synthetic weights -- the gate; e2e_full_refinit = the same with weights drawn from the "
+                       "reference's own initialisation, tests/golden/refinit_stats.json; e2e_deep = the shipped depths on a narrow ViT)"
+                       % ",".join(fixtures)}
 
 
 def main():
@@ -427,9 +432,20 @@ def main():
         post_ms = (time.perf_counter() - t1) * 1e3
         del out
 
+    if args.breakdown and rank == 0:
+        ops.PROFILE.enable("all")
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        local_step()                     # no collective here: only rank 0 runs the breakdown
+        torch.cuda.synchronize()
+        print("BREAKDOWN step %.1f ms" % ((time.perf_counter() - t1) * 1e3), file=sys.stderr)
+        for tag, (mean, n, tot) in sorted(ops.PROFILE.summary().items()):
+            print("BREAKDOWN %-18s n=%4d mean=%8.3f ms total=%8.2f ms" % (tag, n, mean, tot), file=sys.stderr)
+        ops.PROFILE.disable()
+
     # the timed arithmetic carries its own error (both reference-generated fixtures); the out-of-tolerance fp16 mode is timed beside
     # it for reference: same model, same batch, same step definition (N = 1, rank 0 only)
-    parity_err = other = None
+    parity_err = other = mixed = None
     if rank == 0 and world == 1 and not args.no_parity_leg:
         try:
             parity_err = parity_error(prec, dev)
@@ -454,20 +470,35 @@ def main():
                 other = {"precision_policy": "fast", "dtype": "f16", "value": round(args.batch / pdt, 3), "unit": "images/sec",
                          "ms_per_step": round(pdt * 1e3, 2), "steps": args.steps, "parity_err": parity_error(Precision.fast(), dev, full_size=False),
                          "note": "single-fp16 operands everywhere: OUTSIDE the 1e-3 tolerance, not the headline"}
-                model = pm
+                # the `mixed` policy: split linears + single-fp16 ViT attention core.  In tolerance with weights from the reference's own
+                # initialisation, out of tolerance on the harder default synthetic distribution -- both reported, never the headline
+                del pm
+                torch.cuda.empty_cache()
+                torch.manual_seed(0)
+                mm = HIPIE_IMG(cfg, Precision.mixed(), device=dev)
+                randomize_degenerate_inits(mm)
+                mm.finalize()
+
+                def mstep():
+                    return inference_compact(mm, mm.forward_raw(batch), batch, topk=100)
+                for _ in range(2):
+                    mstep()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    mstep()
+                torch.cuda.synchronize()
+                mdt = (time.perf_counter() - t1) / args.steps
+                del mm
+                torch.cuda.empty_cache()
+                mixed = {"precision_policy": "mixed", "dtype": "f16x3 linears + f16 ViT attention core", "value": round(args.batch / mdt, 3),
+                         "unit": "images/sec", "ms_per_step": round(mdt * 1e3, 2), "steps": args.steps,
+                         "parity_err": parity_error(Precision.mixed(), dev),
+                         "note": "NOT the headline: within 1e-3 only on the fixtures listed in parity_err.within_tolerance_on (the reference's own "
+                                 "initialisation distribution), not on the harder default synthetic weights that gate the timed policy"}
+                model = None
         except Exception as e:          # never lose the measured line to the side legs
             print("bench: parity leg failed: %r" % (e,), file=sys.stderr)
-
-    if args.breakdown and rank == 0:
-        ops.PROFILE.enable("all")
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        local_step()                     # no collective here: only rank 0 runs the breakdown
-        torch.cuda.synchronize()
-        print("BREAKDOWN step %.1f ms" % ((time.perf_counter() - t1) * 1e3), file=sys.stderr)
-        for tag, (mean, n, tot) in sorted(ops.PROFILE.summary().items()):
-            print("BREAKDOWN %-18s n=%4d mean=%8.3f ms total=%8.2f ms" % (tag, n, mean, tot), file=sys.stderr)
-        ops.PROFILE.disable()
 
     if rank == 0:
         std = args.model == "vit_huge" and args.batch == 8 and args.size == 1024
@@ -537,6 +568,7 @@ def main():
             "postprocess_full_ms": None if post_ms is None else round(post_ms, 2),
             "parity_err": parity_err,
             "fast_policy": other,
+            "mixed_policy": mixed,
         }
         if not args.no_cpu_baseline and world == 1 and args.model != "r50" and args.classes == 80:   # rank 0 at N = 1 only (bounded ~20 s CPU sample)
             import subprocess

@@ -160,6 +160,20 @@ class Attention(nn.Module):
             b = self.qkv.bias.detach().float().clone()
             b[:C] *= c1
             return b
+        if getattr(self.precision, "vit_attn16", False) and ops.vit_attn_rel_ok((H, W), C // nh):
+            # `mixed` policy: split linears around the single-fp16 attention core (hipie_vit_attn_rel; its output goes back to HL8 with a
+            # zero lo half for the projection GEMM)
+            qkv16 = ops.split_linear(y, self, "qkv", self.qkv.weight, self.qkv.bias, out_fmt=ops.F16, x_hl8=True, weight_fn=wq, bias_fn=bq,
+                                     tag="gemm_qkv")
+            key = (H, W, "f16", self._versions())
+            if getattr(self, "_tabs16_key", None) != key:
+                self._tabs16 = ((resize_rel_pos(H, self.rel_pos_h.detach().float()) / self.scale).half().contiguous(),
+                                (resize_rel_pos(W, self.rel_pos_w.detach().float()) / self.scale).half().contiguous())
+                self._tabs16_key = key
+            o16 = ops.vit_attn_rel(qkv16.view(B, H * W, 3 * C), self._tabs16[0], self._tabs16[1], (H, W), nh, fast=True)
+            o = ops.to_hl8(o16.view(B * H * W, C))
+            return ops.split_linear(o, self, "proj", self.proj.weight, self.proj.bias, x_hl8=True, tag="gemm_proj",
+                                    resid=resid, out=resid, out_row=out_row)
         qkv = ops.split_linear(y, self, "qkv", self.qkv.weight, self.qkv.bias, out_fmt=ops.HL8, x_hl8=True, weight_fn=wq, bias_fn=bq,
                                tag="gemm_qkv")
         key = (H, W, self._versions())

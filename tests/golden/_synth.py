@@ -40,11 +40,70 @@ def canonical_key(name):
     return name
 
 
-def synth_tensor(name, shape, seed=0, dtype=torch.float32):
+# ---- second weight distribution (round 4): the reference's OWN initialisation ----------------------------------------------------
+# tests/golden/refinit_stats.json is a table {canonical key: statistics} measured by gen_golden.py on the reference's modules right after
+# their constructors ran (their own _reset_parameters / _init_weights / default nn init; BertModel's init for the text encoder):
+#   ["c", value]            constant tensor (LayerNorm 1 / 0, zero biases, layer-scale gammas ...)
+#   ["n", mean, std]        bell-shaped (normal_ / trunc_normal_)
+#   ["u", mean, std]        uniform (xavier_uniform_, kaiming_uniform_, default nn.Linear / nn.Conv2d)
+#   ["v", [values]]         small or structured tensors stored verbatim (<= 64 elements: e.g. bbox_embed's bias [0, 0, -2, -2])
+#   ["g"]                   MSDeformAttn's sampling_offsets.bias grid (ms_deform_attn.py:64-70), rebuilt from its formula
+# Tensors the reference zero-initialises and that would make a kernel trivial (rel_pos_{h,w}, sampling_offsets.weight,
+# attention_weights.*, the last bbox_embed layer) are drawn N(0, 0.02) as in the default distribution's spirit.  Both sides (generator and
+# tests) rebuild the same values from (key, shape, seed, table); a fixture made with the table says so in meta["dist"].
+_REFINIT = None
+_DEGENERATE = ("rel_pos_h", "rel_pos_w", "sampling_offsets.weight", "attention_weights.weight", "attention_weights.bias")
+
+
+def refinit_stats():
+    global _REFINIT
+    if _REFINIT is None:
+        import json
+        import os
+        _REFINIT = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "refinit_stats.json")))
+    return _REFINIT
+
+
+def msda_grid_bias(n_heads=8, n_levels=4, n_points=4):
+    """MSDeformAttn._reset_parameters (ms_deform_attn.py:64-70): head h looks in direction 2 pi h / n_heads (normalised to the unit
+    square), point i at i + 1 pixels."""
+    import math
+    thetas = torch.arange(n_heads, dtype=torch.float32) * (2.0 * math.pi / n_heads)
+    grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+    grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(n_heads, 1, 1, 2).repeat(1, n_levels, n_points, 1)
+    for i in range(n_points):
+        grid[:, :, i, :] *= i + 1
+    return grid.reshape(-1)
+
+
+def _refinit_tensor(name, shape, g, entry, dtype):
+    leaf2 = ".".join(name.split(".")[-2:])
+    if any(name.endswith(d) for d in _DEGENERATE) or (entry[0] == "c" and entry[1] == 0.0 and ".bbox_embed." in "." + name and name.split(".")[-2] == "2"):
+        return (0.02 * torch.randn(shape, generator=g)).to(dtype)
+    kind = entry[0]
+    if kind == "c":
+        return torch.full(shape, float(entry[1]), dtype=dtype)
+    if kind == "v":
+        return torch.tensor(entry[1], dtype=dtype).reshape(shape)
+    if kind == "g":
+        t = msda_grid_bias()
+        assert t.numel() == int(np.prod(shape)), (name, shape)
+        return t.reshape(shape).to(dtype)
+    if kind == "n":
+        return (float(entry[1]) + float(entry[2]) * torch.randn(shape, generator=g)).to(dtype)
+    if kind == "u":
+        half = float(entry[2]) * 3.0 ** 0.5
+        return (float(entry[1]) + half * (2.0 * torch.rand(shape, generator=g) - 1.0)).to(dtype)
+    raise KeyError(kind)
+
+
+def synth_tensor(name, shape, seed=0, dtype=torch.float32, dist=None):
     name = canonical_key(name)
     shape = tuple(int(s) for s in shape)
     g = _gen(seed, name)
     leaf = name.split(".")[-1]
+    if dist is not None and name in dist and not (len(shape) == 0 or "position_ids" in name or "token_type_ids" in name or "num_batches" in name):
+        return _refinit_tensor(name, shape, g, dist[name], dtype)
     if len(shape) == 0:
         if leaf == "logit_scale":          # CLIP's learned temperature: exp(.) near the OpenAI value 1 / 0.07
             return (2.659 + 0.1 * torch.randn((), generator=g)).to(dtype)
@@ -81,19 +140,21 @@ def synth_tensor(name, shape, seed=0, dtype=torch.float32):
     return (std * torch.randn(shape, generator=g)).to(dtype)
 
 
-def synth_state_dict(manifest, seed=0):
-    """manifest: {key: shape} (e.g. {k: tuple(v.shape) for k, v in module.state_dict().items()})."""
-    return {k: synth_tensor(k, shp, seed) for k, shp in manifest.items()}
+def synth_state_dict(manifest, seed=0, dist=None, prefix=""):
+    """manifest: {key: shape} (e.g. {k: tuple(v.shape) for k, v in module.state_dict().items()}).  dist: the reference-init statistics
+    table (its keys carry `prefix`: "detr." / "text_encoder.body.")."""
+    d = None if dist is None else {k[len(prefix):]: v for k, v in dist.items() if k.startswith(prefix)}
+    return {k: synth_tensor(k, shp, seed, dist=d) for k, shp in manifest.items()}
 
 
 def manifest_of(module):
     return {k: tuple(v.shape) for k, v in module.state_dict().items()}
 
 
-def load_synth(module, seed=0):
+def load_synth(module, seed=0, dist=None, prefix=""):
     """Fill ``module`` in place with synthetic weights; returns the manifest."""
     man = manifest_of(module)
-    sd = synth_state_dict(man, seed)
+    sd = synth_state_dict(man, seed, dist, prefix)
     cur = module.state_dict()
     for k in sd:
         sd[k] = sd[k].to(cur[k].dtype)
@@ -153,16 +214,21 @@ def subsample(t, step):
     return t.reshape(-1)[::step]
 
 
-def synth_full_state_dict(manifest, seed_detr=71, seed_text=72):
+def synth_full_state_dict(manifest, seed_detr=71, seed_text=72, dist=None):
     """State dict of the whole HIPIE_IMG model ("detr.*" + "text_encoder.body.*" keys) with the
     same values gen_golden.py loaded into the reference's DDETRSegmUniDN / BertEncoder (which it built
-    separately, so the seeds and key prefixes differ)."""
+    separately, so the seeds and key prefixes differ).  dist = "refinit" (or the table itself): the reference's own initialisation
+    distribution (refinit_stats.json) instead of the default rules."""
+    if dist == "refinit":
+        dist = refinit_stats()
+    dd = None if dist is None else {canonical_key(k[len("detr."):]): v for k, v in dist.items() if k.startswith("detr.")}
+    dt = None if dist is None else {k[len("text_encoder.body."):]: v for k, v in dist.items() if k.startswith("text_encoder.body.")}
     out = {}
     for k, shp in manifest.items():
         if k.startswith("detr."):
-            out[k] = synth_tensor(k[len("detr."):], shp, seed_detr)
+            out[k] = synth_tensor(k[len("detr."):], shp, seed_detr, dist=dd)
         elif k.startswith("text_encoder.body."):
-            out[k] = synth_tensor(k[len("text_encoder.body."):], shp, seed_text)
+            out[k] = synth_tensor(k[len("text_encoder.body."):], shp, seed_text, dist=dt)
         else:
             raise KeyError(k)
     return out

@@ -365,12 +365,75 @@ def build_ref_model(c):
     return model.eval()
 
 
-def gen_e2e(c=None, name="e2e_tiny", tasks=(("detection", 9), ("grounding", 1)), sizes=((200, 256), (256, 224))):
+def gen_refinit_stats():
+    """tests/golden/refinit_stats.json: per-tensor statistics of the reference's OWN initialisation at the headline configuration -- the
+    reference's classes are constructed (their constructors run _reset_parameters / _init_weights / the default nn init; the text encoder
+    is transformers' BertModel(config)) and every state_dict entry is summarised as constant / normal / uniform / verbatim (see _synth.py).
+    The second weight distribution of the parity study ("default module init (+N(0,0.02) for zero tensors)")."""
+    torch.manual_seed(20260927)
+    model = build_ref_model(FULL)
+    bert = build_ref_bert(FULL)
+    grid = _synth.msda_grid_bias()
+    table = {}
+
+    def summarise(prefix, module, canon):
+        for k, v in module.state_dict().items():
+            key = prefix + (canon(k) if canon else k)
+            if not v.is_floating_point() or v.dim() == 0:
+                continue
+            x = v.detach().float().reshape(-1)
+            if key in table:
+                continue
+            if k.endswith("sampling_offsets.bias") and x.numel() == grid.numel() and torch.allclose(x, grid, atol=1e-6):
+                table[key] = ["g"]
+            elif float(x.max()) == float(x.min()):
+                table[key] = ["c", float(x[0])]
+            elif x.numel() <= 64:
+                table[key] = ["v", [float(t) for t in x]]
+            else:
+                mean, std = float(x.mean()), float(x.std())
+                peak = float((x - mean).abs().max()) / std
+                table[key] = ["u" if peak < 1.85 else "n", float("%.6g" % (mean if abs(mean) > 0.05 * std else 0.0)), float("%.6g" % std)]
+    summarise("detr.", model, _synth.canonical_key)
+    summarise("text_encoder.body.", bert, None)
+    path = os.path.join(HERE, "refinit_stats.json")
+    json.dump(table, open(path, "w"), indent=0, sort_keys=True)
+    kinds = {}
+    for v in table.values():
+        kinds[v[0]] = kinds.get(v[0], 0) + 1
+    print("wrote refinit_stats.json: %d tensors %s, %.1f KB" % (len(table), kinds, os.path.getsize(path) / 1024))
+    # self-check: the table-driven draw has the statistics of the reference's draw, tensor by tensor
+    sd = model.state_dict()
+    dd = {k[len("detr."):]: v for k, v in table.items() if k.startswith("detr.")}
+    worst = 0.0
+    for k, v in sd.items():
+        if not v.is_floating_point() or v.numel() < 4096:
+            continue
+        ck = _synth.canonical_key(k)
+        mine = _synth.synth_tensor(k, v.shape, seed=71, dist=dd).float()
+        if any(ck.endswith(d) for d in _synth._DEGENERATE) or (dd[ck][0] == "c" and float(mine.std()) > 0):
+            continue                                 # the zero tensors that are deliberately redrawn
+        a, b = float(v.float().std()), float(mine.std())
+        if a > 0:
+            worst = max(worst, abs(b / a - 1.0))
+    print("refinit self-check: largest relative std mismatch over the big tensors %.3f" % worst)
+    assert worst < 0.05
+
+
+def gen_e2e_full_refinit():
+    """e2e_full with the weights drawn from the reference's own initialisation distribution (refinit_stats.json)."""
+    import time
+    t0 = time.time()
+    gen_e2e(FULL, "e2e_full_refinit", (("detection", 9),), sizes=((1024, 1024),), dist=_synth.refinit_stats())
+    print("e2e_full_refinit: %.0f s" % (time.time() - t0))
+
+
+def gen_e2e(c=None, name="e2e_tiny", tasks=(("detection", 9), ("grounding", 1)), sizes=((200, 256), (256, 224)), dist=None):
     c = c or TINY
     model = build_ref_model(c)
     bert = build_ref_bert(c)
-    man = _synth.load_synth(model, seed=71)
-    man_b = _synth.load_synth(bert, seed=72)
+    man = _synth.load_synth(model, seed=71, dist=dist, prefix="detr.")
+    man_b = _synth.load_synth(bert, seed=72, dist=dist, prefix="text_encoder.body.")
     full_man = {"detr." + k: v for k, v in man.items()}
     full_man.update({"text_encoder.body." + k: v for k, v in man_b.items()})
     sizes = [tuple(s_) for s_ in sizes]
@@ -385,6 +448,8 @@ def gen_e2e(c=None, name="e2e_tiny", tasks=(("detection", 9), ("grounding", 1)),
         batched[i, :, :x.shape[1], :x.shape[2]] = x
     images = _ImageList(batched, sizes)
     arrays, meta = {}, dict(cfg=c, manifest=man_json(full_man), sizes=sizes)
+    if dist is not None:
+        meta["dist"] = "refinit"
     topk_log = []
     real_topk = torch.topk
 
@@ -701,7 +766,7 @@ def gen_manifest_full():
 
 
 ALL = dict(manifest_full=gen_manifest_full, prompts=gen_prompts, post=gen_post, resnet50=gen_resnet50, msda=gen_msda, msda_bwd=gen_msda_bwd, vit_attn=gen_vit_attn, vit_backbone=gen_vit_backbone, bi_attn=gen_bi_attn, bert=gen_bert,
-           dynamic_mask=gen_dynamic_mask, e2e=gen_e2e, stages=gen_stages, stages_full=gen_stages_full, e2e_r50=gen_e2e_r50, e2e_long=gen_e2e_long, e2e_deep=gen_e2e_deep, e2e_full=gen_e2e_full, maskclip=gen_maskclip)
+           dynamic_mask=gen_dynamic_mask, e2e=gen_e2e, stages=gen_stages, stages_full=gen_stages_full, e2e_r50=gen_e2e_r50, e2e_long=gen_e2e_long, e2e_deep=gen_e2e_deep, e2e_full=gen_e2e_full, maskclip=gen_maskclip, refinit_stats=gen_refinit_stats, e2e_full_refinit=gen_e2e_full_refinit)
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)

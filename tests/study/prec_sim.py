@@ -230,7 +230,7 @@ def main():
     fixture = os.environ.get("PREC_FIXTURE", "e2e_deep")
     g = Golden(fixture)
     cfg = g.meta["cfg"]
-    sd = _synth.synth_full_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()})
+    sd = _synth.synth_full_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}, dist=g.meta.get("dist"))
     imgs = _synth.synth_images([tuple(s) for s in g.meta["sizes"]], seed=73)
     ids, mask, _ = _synth.synth_token_ids(2, g.meta["detection"]["n_classes"], g.meta["detection"].get("max_len", 64), seed=74,
                                           pad_to=g.meta["detection"].get("pad_to"))

@@ -29,7 +29,7 @@ def build(precision, fixture="e2e_tiny"):
     g = Golden(fixture)
     cfg = HipieConfig.from_dict(g.meta["cfg"])
     model = HIPIE_IMG(cfg, precision, device="cuda")
-    sd = _synth.synth_full_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()})
+    sd = _synth.synth_full_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}, dist=g.meta.get("dist"))
     model.load_state_dict(sd, strict=True)
     return g, model.finalize()
 

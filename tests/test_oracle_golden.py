@@ -112,7 +112,7 @@ def test_aligned_bilinear():
 
 def e2e_inputs(g, task):
     cfg = g.meta["cfg"]
-    sd = _synth.synth_full_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()})
+    sd = _synth.synth_full_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}, dist=g.meta.get("dist"))
     imgs = _synth.synth_images([tuple(s) for s in g.meta["sizes"]], seed=73)
     ids, mask, pmap = _synth.synth_token_ids(2, g.meta[task]["n_classes"], g.meta[task].get("max_len", 64), seed=74,
                                              pad_to=g.meta[task].get("pad_to"))

@@ -22,7 +22,7 @@ kw = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
 fx, stg = kw.get("fixture", "e2e_full"), kw.get("stages", "stages_full")
 g, st = Golden(fx), Golden(stg)
 model = HIPIE_IMG(HipieConfig.from_dict(g.meta["cfg"]), Precision.split3(), device="cuda")
-model.load_state_dict(_synth.synth_full_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}), strict=True)
+model.load_state_dict(_synth.synth_full_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}, dist=g.meta.get("dist")), strict=True)
 model.finalize()
 model.pin_topk(g["detection_topk_fg"], g["detection_topk_md"])
 
