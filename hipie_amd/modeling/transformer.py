@@ -503,7 +503,10 @@ def _enc_layer_forward_split(self, src, pos, reference_points, spatial_shapes, l
     src2 = attn.forward_projected(q_h, reference_points, value.contiguous(), spatial_shapes, level_start_index, x_hl8=True)
     n = self.norm1
     src, s_h, _ = ops.add_layernorm_dec(src, src2.contiguous(), n.weight, n.bias, n.eps, "hl8", want16=True)
-    src2 = self.linear2(self.linear1.forward_relu(s_h, out_fmt=ops.HL8, x_hl8=True), x_hl8=True)
+    if ops.ffn_fused_ok(s_h, self.linear1, self.linear2):
+        src2 = ops.ffn_fused(s_h, self.linear1, self.linear2)          # one launch, the (tokens x 2048) hidden tensor never exists
+    else:
+        src2 = self.linear2(self.linear1.forward_relu(s_h, out_fmt=ops.HL8, x_hl8=True), x_hl8=True)
     n = self.norm2
     if not want_query:
         return ops.add_layernorm_dec(src, src2, n.weight, n.bias, n.eps, "hl8")[0]

@@ -905,6 +905,40 @@ def split_weight(owner, key, params, weight_fn, bias_fn=None):
     return e[1], e[2], e[3]
 
 
+_FFN_PERM = {}
+
+
+def ffn_fused_ok(x_hl8, lin1, lin2):
+    """the shape hipie_ffn_fused is built for: 256 -> 2048 -> 256 on at least a few thousand tokens (the two deformable encoders)"""
+    return (x_hl8.is_cuda and lin1.weight.shape == (2048, 256) and lin2.weight.shape == (256, 2048) and lin1.bias is not None
+            and lin2.bias is not None and lin1.weight.dtype == torch.float32 and x_hl8.numel() // 512 >= 4096)
+
+
+@_timed("ffn_fused")
+def ffn_fused(x_hl8, lin1, lin2):
+    """linear2(relu(linear1(x))) in ONE launch at the split policy's accuracy (hipie_ffn_fused): x (..., 2*256) HL8 -> (..., 256) fp32.
+    The hidden activations stay in registers; W2's columns are permuted once per parameter version into the order the MFMA C layout
+    hands them over (rows 0-3, 8-11, 4-7, 12-15 of every 16)."""
+    lib = _lib.load()
+    w1, b1, _ = split_weight(lin1, "w", [lin1.weight, lin1.bias], lambda: lin1.weight, lambda: lin1.bias)
+    F_ = lin2.weight.shape[1]
+    perm = _FFN_PERM.get(F_)
+    if perm is None:
+        base = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
+        perm = _FFN_PERM[F_] = (torch.arange(0, F_, 16)[:, None] + base[None, :]).reshape(-1)
+    w2, b2, _ = split_weight(lin2, "w_ffn_perm", [lin2.weight, lin2.bias], lambda: lin2.weight[:, perm.to(lin2.weight.device)], lambda: lin2.bias)
+    lead = x_hl8.shape[:-1]
+    x2 = x_hl8.reshape(-1, x_hl8.shape[-1])
+    if x2.dtype != torch.float16 or x2.stride(-1) != 1 or x2.shape[-1] != 512:
+        raise RuntimeError("ffn_fused: x must be HL8 rows of 2 * 256 fp16 values")
+    M = x2.shape[0]
+    out = torch.empty(M, 256, dtype=torch.float32, device=x2.device)
+    rc = lib.hipie_ffn_fused(x2.data_ptr(), x2.stride(0), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), out.data_ptr(), 256,
+                             M, 256, F_, _stream())
+    _lib.check(rc, "hipie_ffn_fused")
+    return out.view(*lead, 256)
+
+
 def split_ok(K):
     return K % 32 == 0
 

@@ -460,6 +460,21 @@ int hipie_attn_split(const float* q, const float* k, const float* v, const unsig
                    void* stream);
 
 /*
+ * The FFN of a deformable encoder layer in ONE launch at the split policy's accuracy:  out = W2 . relu(W1 . x + b1) + b2.
+ *   x    (M, 2 D) HIPIE_HL8 rows (row stride ldx in fp16 elements);  w1 (F, 2 D) HL8;  b1 (F) fp32;
+ *   w2p  (D, 2 F) HL8 of W2 with its COLUMNS permuted inside every block of 16 into the order 0-3, 8-11, 4-7, 12-15 (the order in which
+ *        the MFMA C layout of the hidden tile hands its rows to the next product);  b2 (D) fp32;  out (M, D) fp32, row stride ldo.
+ *   D = 256, F = 2048 (the shipped sizes of both deformable encoders).
+ * Each product is the three-term split sum with fp32 accumulation; the hidden activations (ReLU, then split into an fp16 pair exactly as
+ * hipie_gemm's HL8 epilogue does) never leave the registers -- no (M, F) tensor exists.
+ * Replaces: linear2(dropout(relu(linear1(src)))) of DeformableTransformerEncoderLayer.forward_ffn
+ *           (models/deformable_detr/deformable_transformer_dino.py:378-394) and MSDeformAttnTransformerEncoderLayer.forward_ffn
+ *           (models/maskdino/pixel_decoder/maskdino_encoder.py:142-157), fp32 nn.Linear in the reference.
+ */
+int hipie_ffn_fused(const void* x, int64_t ldx, const void* w1, const float* b1, const void* w2p, const float* b2, float* out, int64_t ldo,
+                    int M, int D, int F, void* stream);
+
+/*
  * Row-wise top-k of fp32 scores, k <= 1024: idx_out (rows, k) int64 in descending value order (ascending index among equal values;
  * NaN sorts as the largest value), val_out (rows, k) f32 or NULL.  One launch, hipGraph-replay safe.
  * Replaces: torch.topk in the two-stage query selections (models/deformable_detr/deformable_transformer_dino.py:222-230, 900 of Nv;

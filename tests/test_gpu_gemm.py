@@ -250,3 +250,29 @@ def test_pointwise_conv_on_the_split_gemm(cin, cout, hw):
     assert len(ops.PROFILE.events.get("gemm", [])) == 0
     ops.PROFILE.disable()
     assert rel_err(y2.cpu(), want.float().cpu()) < 1e-4
+
+
+@pytest.mark.parametrize("M", [4096, 21760 + 37, 128 * 3 + 5])
+def test_ffn_fused_matches_two_split_gemms(M):
+    """hipie_ffn_fused (linear1 -> ReLU -> linear2 of the deformable encoder layers in one launch, hidden activations in registers) against
+    the fp64 evaluation and against the two hipie_gemm launches it replaces (same operand splits: identical up to the fp32 summation order
+    inside a 16-wide MFMA step); ragged token count, biases, negative pre-activations."""
+    import types
+    from hipie_amd import ops
+    g = torch.Generator().manual_seed(M)
+    D, F_ = 256, 2048
+    x = torch.randn(M, D, generator=g)
+    lin1 = types.SimpleNamespace(weight=(torch.randn(F_, D, generator=g) * D ** -0.5).cuda(), bias=(torch.randn(F_, generator=g) * 0.3).cuda())
+    lin2 = types.SimpleNamespace(weight=(torch.randn(D, F_, generator=g) * F_ ** -0.5).cuda(), bias=(torch.randn(D, generator=g) * 0.3).cuda())
+    xs = ops.to_hl8(x.cuda())
+    if M >= 4096:
+        assert ops.ffn_fused_ok(xs, lin1, lin2)
+    got = ops.ffn_fused(xs, lin1, lin2).cpu()
+    want = (torch.relu(x.double() @ lin1.weight.cpu().double().t() + lin1.bias.cpu().double()) @ lin2.weight.cpu().double().t()
+            + lin2.bias.cpu().double())
+    e64 = float((got.double() - want).abs().max() / want.abs().max())
+    h = ops.gemm(xs, ops.hl8_pack(lin1.weight), lin1.bias, out_fmt=ops.HL8, act=ops.ACT_RELU, split=True)
+    two = ops.gemm(h, ops.hl8_pack(lin2.weight), lin2.bias, out_fmt=ops.F32, split=True).cpu()
+    e2 = float((got - two).abs().max() / two.abs().max())
+    print("ffn_fused M=%d: vs fp64 %.2e, vs the two split GEMMs %.2e" % (M, e64, e2))
+    assert e64 < 5e-6 and e2 < 5e-6
