@@ -503,9 +503,10 @@ def main():
     if rank == 0:
         std = args.model == "vit_huge" and args.batch == 8 and args.size == 1024
         pmc = {}
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_kernels.json")
-        if os.path.exists(pmc_path) and std:
-            pmc = json.load(open(pmc_path))
+        for pmc_file in ("r03_pmc_kernels.json", "r04_pmc_kernels.json"):      # the newer round's rows (split GEMM, fused FFN) win
+            pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_file)
+            if os.path.exists(pmc_path) and std:
+                pmc.update(json.load(open(pmc_path)))
         images = args.batch * world * args.steps
         N = (args.size // 16) ** 2
         E = cfg.vit_embed_dim
@@ -539,8 +540,8 @@ def main():
                     "avg_launch_ms": round(g_ms / g_n, 4), "flop_per_launch": g_flop / g_n,
                     "per_shape_ms": {t: round(gemm[t][0], 4) for t in shapes if gemm.get(t, (None, 0))[0]},
                     "traffic": pmc.get("gemm_qkv_split", {}).get("traffic_bytes_per_launch"),
-                    "traffic_note": "bytes per launch of the qkv shape (0.85 ms), rocprofv3 PMC FETCH_SIZE (x2, guide correction) + WRITE_SIZE, "
-                                    "separate passes: profiles/r03_pmc.md"}
+                    "traffic_note": "bytes per launch of the qkv shape (0.81 ms; 691 MB algorithmic), rocprofv3 PMC FETCH_SIZE (x2, guide correction) + "
+                                    "WRITE_SIZE, separate passes: profiles/r04_pmc_kernels.json"}
         else:
             roof = roof_attn
         line = {

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""encoder FFN at bs 8 (174080 tokens): the two split GEMMs (linear1 -> ReLU -> HL8, linear2) against hipie_ffn_fused.
+    python tools/bench_ffn_fused.py [two|fused]    (one side only: for PMC passes)"""
 import torch, types, sys
 sys.path.insert(0, ".")
 from hipie_amd import ops
@@ -10,7 +13,10 @@ def two():
     h=ops.gemm(x,w1,l1.bias,out_fmt=ops.HL8,act=ops.ACT_RELU,split=True)
     return ops.gemm(h,w2,l2.bias,out_fmt=ops.F32,split=True)
 def one(): return ops.ffn_fused(x,l1,l2)
+only = sys.argv[1] if len(sys.argv) > 1 else None
 for f,n in ((two,"two GEMMs"),(one,"fused")):
+    if only and not n.startswith(only):
+        continue
     for _ in range(3): f()
     a,b=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); a.record()
