@@ -623,6 +623,11 @@ extern "C" int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw
 #ifdef HIPIE_GEMM_VARIANTS
   { const char* e = getenv("HIPIE_GEMM_VARIANT"); p.variant = e ? atoi(e) : 0; }
   p.prio_mode = gemm2_prio();
+  if (split && gemm2_mode() == 4) {
+    const bool w160 = (N % 160 == 0);
+    if (a_f32) return w160 ? launch_gemm4<5, 2>(p, st) : launch_gemm4<4, 2>(p, st);
+    return w160 ? launch_gemm4<5, 0>(p, st) : launch_gemm4<4, 0>(p, st);
+  }
   if (split && gemm2_mode() == 2) {
     const bool w160 = (N % 160 == 0);
     if (a_f32) return w160 ? launch_gemm3<5, 2>(p, st) : launch_gemm3<4, 2>(p, st);
