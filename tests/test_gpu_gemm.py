@@ -252,6 +252,7 @@ def test_pointwise_conv_on_the_split_gemm(cin, cout, hw):
     assert rel_err(y2.cpu(), want.float().cpu()) < 1e-4
 
 
+@gpu
 @pytest.mark.parametrize("M", [4096, 21760 + 37, 128 * 3 + 5])
 def test_ffn_fused_matches_two_split_gemms(M):
     """hipie_ffn_fused (linear1 -> ReLU -> linear2 of the deformable encoder layers in one launch, hidden activations in registers) against

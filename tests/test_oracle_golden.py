@@ -224,3 +224,33 @@ def test_msda_backward_oracle(case):
     assert rel_err(gl, g[case + "_gloc"]) < 1e-10
     assert rel_err(ga, g[case + "_gattn"]) < 1e-12
 
+
+
+def test_refinit_distribution_table_covers_the_model_and_is_reproducible():
+    """tests/golden/refinit_stats.json (statistics of the reference's OWN initialisation, measured by gen_golden.py on the reference's
+    constructors) has an entry for every floating-point tensor of the full ViT-H model; drawing from it is deterministic, zero biases /
+    unit LayerNorm scales stay constants, the tensors the reference zero-initialises that would make a kernel trivial are N(0, 0.02)."""
+    g = Golden("e2e_full_refinit")
+    assert g.meta.get("dist") == "refinit"
+    table = _synth.refinit_stats()
+    man = {k: tuple(v) for k, v in g.meta["manifest"].items()}
+    missing = []
+    for k, shp in man.items():
+        pre = "detr." if k.startswith("detr.") else "text_encoder.body."
+        ck = pre + (_synth.canonical_key(k[len(pre):]) if pre == "detr." else k[len(pre):])
+        if len(shp) and "position_ids" not in k and "token_type_ids" not in k and "num_batches" not in k and ck not in table:
+            missing.append(k)
+    assert not missing, missing[:5]
+    keys = ["detr.detr.backbone.0.backbone.blocks.0.attn.qkv.weight", "detr.detr.backbone.0.backbone.blocks.0.attn.qkv.bias",
+            "detr.detr.backbone.0.backbone.blocks.0.attn.rel_pos_h", "detr.detr.transformer.encoder.layers.0.linear1.weight",
+            "detr.detr.transformer.encoder.layers.0.self_attn.sampling_offsets.bias"]
+    sub = {k: man[k] for k in keys}
+    a = _synth.synth_full_state_dict(sub, dist="refinit")
+    b = _synth.synth_full_state_dict(sub, dist="refinit")
+    for k in keys:
+        assert torch.equal(a[k], b[k])
+    assert abs(float(a[keys[0]].std()) - 0.02) < 1e-3                 # trunc_normal_(std=0.02) (backbone/vit.py:350)
+    assert float(a[keys[1]].abs().max()) == 0.0                       # zero bias
+    assert abs(float(a[keys[2]].std()) - 0.02) < 4e-3                 # zero in the reference -> N(0, 0.02) (SURVEY 8d)
+    assert abs(float(a[keys[3]].std()) - (2.0 / (256 + 2048)) ** 0.5) < 2e-3      # xavier_uniform_ (deformable_transformer_dino.py:109-112)
+    assert torch.allclose(a[keys[4]], _synth.msda_grid_bias().view_as(a[keys[4]]))
