@@ -429,7 +429,9 @@ int hipie_gemm_batched(const void* A, int64_t lda, int64_t a_outer, int64_t a_in
 /*
  * Row softmax of fp32 logits written as an HL8 operand:  P[r, :Lp] = softmax over the L valid columns of clamp(S[r, :L], +-clamp) with
  * columns masked by mask[r / rows_per_batch, :] (uint8, 1 = keep; NULL = all) or beyond L set to 0.  S rows lds floats apart, P rows
- * ldp fp16 elements apart (>= 2 * Lp);  Lp a multiple of 8, <= 4096.  A row with no valid column gives zeros.
+ * ldp fp16 elements apart (>= 2 * Lp);  Lp a multiple of 8, <= 4096.  A row with no valid column gives zeros (DEVIATION, never reached
+ * on the path: the reference's additive -9e15 mask makes such a row a UNIFORM average over all L columns; a caption always keeps [CLS]
+ * and [SEP], so every text has valid tokens -- same convention in hipie_attn_f32 / hipie_attn_split / hipie_flash_attn).
  * Replaces: attn_weights_v = softmax(clamp(attn_weights) + attention_mask) of BiMultiHeadAttention.forward (fuse_helper.py:97-111).
  */
 int hipie_softmax_hl8(const float* S, int64_t lds, void* P, int64_t ldp, int64_t rows, int L, int Lp, const unsigned char* mask,
