@@ -17,7 +17,7 @@ def main():
     torch.set_grad_enabled(False)
     dev = torch.device("cuda", 0)
     cfg = HipieConfig.vit_huge()
-    model = HIPIE_IMG(cfg, Precision.fast(), device=dev)
+    model = HIPIE_IMG(cfg, getattr(Precision, os.environ.get("POLICY", "split3"))(), device=dev)
     bench.randomize_degenerate_inits(model)
     model.finalize()
     batch = bench.synth_batch(cfg, 8, 1024, 80, 194, dev)
