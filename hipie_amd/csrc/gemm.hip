@@ -48,6 +48,10 @@ struct GemmParams {
   // batched form (hipie_gemm_batched): blockIdx.y = outer * nbi + inner; operand / output base offsets in BYTES per outer / inner index
   int nbi;
   long a_bo, a_bi, w_bo, w_bi, o_bo, o_bi;
+  // 3 x 3 convolution as an implicit GEMM on a zero-PADDED pixel grid (hipie_conv3x3_split): K = 9 taps x C channels, the A rows of k tile kt
+  // come from the pixel row shifted by tap (dy, dx): byte offset ((dy - 1) * conv_wp + (dx - 1)) * lda_b + (kt % conv_kpt) * 128 -- the same
+  // for every row, so only the scalar source base of the A tile changes.  conv_kpt = k tiles per tap (0: plain GEMM).
+  int conv_kpt, conv_wp;
   int variant;                // timing experiments (HIPIE_GEMM_VARIANTS builds only)
   int prio_mode;              // gemm2: 0 none, 1 blocks 256..511 at low priority (phase offset), 2 by dispatch-round parity
 };
@@ -244,7 +248,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams pin) {
 
   auto dma = [&](const int i, const int kt, const int stage) {
     const bool isa = (8 * (8 * i + wave)) < BM;           // wave-uniform: an instruction is all-A or all-W (BM % 64 == 0)
-    const char* sb = (isa ? abase : wbase) + (long)kt * 128;
+    long ko = (long)kt * 128;
+    if (isa && p.conv_kpt) {                              // implicit 3 x 3 convolution: tap of this k tile -> row shift on the padded grid
+      const int tap = kt / p.conv_kpt, r = kt - tap * p.conv_kpt, dy = tap / 3;
+      ko = ((long)(dy - 1) * p.conv_wp + (tap - 3 * dy - 1)) * p.lda_b + (long)r * 128;
+    }
+    const char* sb = (isa ? abase : wbase) + ko;
     gm_dma16(sb, dvoff[i], __builtin_amdgcn_readfirstlane(lds0 + (unsigned int)(stage * STAGE + 1024 * (8 * i + wave))));
   };
 
@@ -607,6 +616,7 @@ extern "C" int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw
   p.M = M; p.N = N; p.K = K; p.nkt = K / kq;
   p.out_fmt = out_fmt; p.act = act; p.alpha = alpha; p.oscale = oscale;
   p.nbi = 1; p.a_bo = p.a_bi = p.w_bo = p.w_bi = p.o_bo = p.o_bi = 0;
+  p.conv_kpt = 0; p.conv_wp = 0;
   hipStream_t st = (hipStream_t)stream;
   const bool wide = (N % 320 == 0);
   // problems that fill less than 3/8 of the CUs with 256-row tiles go to the 64 x 128 tile kernel (HIPIE_GEMM_SMALL=0: never; A/B timing)
@@ -663,6 +673,7 @@ extern "C" int hipie_gemm_batched(const void* A, int64_t lda, int64_t a_outer, i
   p.lda_b = lda * 2; p.ldw_b = ldw * 2; p.ldr = 0; p.ldo = ldo;
   p.M = M; p.N = N; p.K = K; p.nkt = K / 32;
   p.out_fmt = out_fmt; p.act = 0; p.alpha = alpha; p.oscale = 1.f;
+  p.conv_kpt = 0; p.conv_wp = 0;
   const long osz = out_fmt == HIPIE_F32 ? 4 : 2;
   p.nbi = n_inner;
   p.a_bo = a_outer * 2; p.a_bi = a_inner * 2; p.w_bo = w_outer * 2; p.w_bi = w_inner * 2; p.o_bo = o_outer * osz; p.o_bi = o_inner * osz;
@@ -674,6 +685,35 @@ extern "C" int hipie_gemm_batched(const void* A, int64_t lda, int64_t a_outer, i
   if (gemm2_mode() == 1) return (N % 160 == 0) ? launch_gemm2<5, 0>(p, st, batches) : launch_gemm2<4, 0>(p, st, batches);
 #endif
   return (N % 320 == 0) ? launch_gemm<320, true>(p, st, batches) : launch_gemm<256, true>(p, st, batches);
+}
+
+extern "C" int hipie_conv3x3_split(const void* x, int64_t ldx, const void* w, const float* bias, void* out, int64_t ldo, int64_t rows, int Wp,
+                                   int C, int N, int in_fmt, int out_fmt, int act, void* stream) {
+  HIPIE_REQUIRE(x && w && out, "conv3x3_split: null pointer");
+  HIPIE_REQUIRE(in_fmt == HIPIE_HL8 || in_fmt == HIPIE_F32, "conv3x3_split: input format %d (HIPIE_HL8 | HIPIE_F32 rows)", in_fmt);
+  HIPIE_REQUIRE(out_fmt == HIPIE_F32 || out_fmt == HIPIE_HL8, "conv3x3_split: output format %d (HIPIE_F32 | HIPIE_HL8)", out_fmt);
+  HIPIE_REQUIRE(act >= 0 && act <= 2, "conv3x3_split: activation %d", act);
+  HIPIE_REQUIRE(rows > 0 && rows < (1L << 31) && Wp >= 3 && C > 0 && C % 32 == 0 && N > 0 && N % 8 == 0, "conv3x3_split: rows=%ld Wp=%d C=%d N=%d",
+                (long)rows, Wp, C, N);
+  if (in_fmt == HIPIE_F32) ldx *= 2;                 // from here on in fp16 units (the same bytes per row as HL8)
+  HIPIE_REQUIRE(ldx >= 2 * C && ldx % 8 == 0, "conv3x3_split: input row stride %ld", (long)ldx);
+  HIPIE_REQUIRE((long)(256 + Wp + 2) * ldx * 2 < (1L << 31), "conv3x3_split: row stride too large");
+  const int opr = out_fmt == HIPIE_HL8 ? 2 * N : N;
+  HIPIE_REQUIRE(ldo >= opr && ldo % 4 == 0, "conv3x3_split: output row stride %ld", (long)ldo);
+  HIPIE_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)bias % 16) == 0,
+                "conv3x3_split: pointers must be 16-byte aligned");
+  GemmParams p;
+  p.A = (const char*)x; p.W = (const char*)w; p.bias = bias; p.resid = nullptr; p.out = (char*)out; p.out_row = nullptr;
+  p.lda_b = ldx * 2; p.ldw_b = (long)2 * 9 * C * 2; p.ldr = 0; p.ldo = ldo;
+  p.M = (int)rows; p.N = N; p.K = 9 * C; p.nkt = 9 * C / 32;
+  p.out_fmt = out_fmt; p.act = act; p.alpha = 1.f; p.oscale = 1.f;
+  p.nbi = 1; p.a_bo = p.a_bi = p.w_bo = p.w_bi = p.o_bo = p.o_bi = 0;
+  p.conv_kpt = C / 32; p.conv_wp = Wp;
+  p.prio_mode = 0; p.variant = 0;
+  hipStream_t st = (hipStream_t)stream;
+  const bool wide = (N % 320 == 0);
+  if (in_fmt == HIPIE_F32) return wide ? launch_gemm<320, true, 2>(p, st) : launch_gemm<256, true, 2>(p, st);
+  return wide ? launch_gemm<320, true>(p, st) : launch_gemm<256, true>(p, st);
 }
 
 extern "C" int hipie_to_hl8(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int K, int x_dtype, float scale, void* stream) {

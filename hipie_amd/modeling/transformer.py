@@ -76,6 +76,10 @@ class PConv2d(nn.Conv2d):
                 w = self.weight
                 y = ops.split_linear(xb.float().reshape(B * H * W, C), self, "w1x1", w, self.bias, weight_fn=lambda: w.reshape(w.shape[0], C))
                 return y.view(B, H, W, -1).permute(0, 3, 1, 2).to(self.out_dtype)
+        if self.split and ops.conv3x3_split_ok(x, self):
+            # split policy: 3 x 3 convolutions with full 256-column tiles as an implicit GEMM of the split kernel (K = 9 C_in), instead of
+            # the library's fp32 implicit GEMM (1.3 ms -> ~0.5 ms for 256 -> 256 at 128 x 128, bs 8)
+            return ops.conv3x3_split(x, self).to(self.out_dtype)
         x = x.to(self.weight.dtype)
         if self.nhwc:
             x = x.contiguous(memory_format=torch.channels_last)

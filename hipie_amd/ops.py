@@ -905,6 +905,36 @@ def split_weight(owner, key, params, weight_fn, bias_fn=None):
     return e[1], e[2], e[3]
 
 
+def conv3x3_split_ok(x, conv):
+    """3 x 3, stride 1, padding 1, dense: the shapes hipie_conv3x3_split runs well (full 256-column tiles)"""
+    return (x.is_cuda and x.dim() == 4 and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.weight.dtype == torch.float32 and conv.in_channels % 32 == 0 and conv.out_channels % 256 == 0
+            and x.shape[0] * (x.shape[2] + 2) * (x.shape[3] + 2) >= 16384)
+
+
+@_timed("conv3x3_split")
+def conv3x3_split(x, conv, act=ACT_NONE):
+    """conv(x) for a 3 x 3 / stride 1 / padding 1 nn.Conv2d at the split policy's accuracy (hipie_conv3x3_split: implicit GEMM, K = 9 C).
+    x (B, C, H, W) in any memory format -> (B, N, H, W) fp32 in channels-last memory.  The input is copied once onto a zero-padded pixel grid
+    (with guard rows), the kernel computes on that grid and the interior is cropped."""
+    lib = _lib.load()
+    B, C, H, W = x.shape
+    N = conv.out_channels
+    Hp, Wp = H + 2, W + 2
+    guard = Wp + 1
+    rows = B * Hp * Wp
+    buf = torch.zeros(rows + 2 * guard, C, dtype=torch.float32, device=x.device)
+    buf[guard:guard + rows].view(B, Hp, Wp, C)[:, 1:-1, 1:-1].copy_(x.permute(0, 2, 3, 1))
+    w, b, _ = split_weight(conv, "w3x3", [conv.weight] + ([conv.bias] if conv.bias is not None else []),
+                           lambda: conv.weight.permute(0, 2, 3, 1).reshape(N, 9 * C), (lambda: conv.bias) if conv.bias is not None else None)
+    out = torch.empty(rows, N, dtype=torch.float32, device=x.device)
+    xin = buf[guard:]
+    rc = lib.hipie_conv3x3_split(xin.data_ptr(), C, w.data_ptr(), None if b is None else b.data_ptr(), out.data_ptr(), N, rows, Wp, C, N,
+                                 F32, F32, int(act), _stream())
+    _lib.check(rc, "hipie_conv3x3_split")
+    return out.view(B, Hp, Wp, N)[:, 1:-1, 1:-1].permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+
+
 _FFN_PERM = {}
 
 

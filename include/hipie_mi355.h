@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPIE_ABI_VERSION 8
+#define HIPIE_ABI_VERSION 9
 
 /* element types of activations */
 #define HIPIE_F32 0
@@ -475,6 +475,19 @@ int hipie_attn_split(const float* q, const float* k, const float* v, const unsig
  */
 int hipie_ffn_fused(const void* x, int64_t ldx, const void* w1, const float* b1, const void* w2p, const float* b2, float* out, int64_t ldo,
                     int M, int D, int F, void* stream);
+
+/*
+ * 3 x 3 convolution (stride 1, padding 1, no groups) at the split policy's accuracy as an IMPLICIT GEMM of hipie_gemm's kernel: K = 9 taps x C.
+ * The caller provides the input on a zero-PADDED pixel grid: x = row 0 of a (B, H + 2, W + 2, C) channels-last tensor (rows = pixels, fp32 or
+ * HIPIE_HL8, row stride ldx elements) with at least Wp + 1 readable rows before and after it (Wp = W + 2); tap (dy, dx) of output row r reads
+ * input row r + (dy - 1) * Wp + (dx - 1).  w (N, 9 * C) as HIPIE_HL8 with k = (3 * dy + dx) * C + c, bias (N) fp32 or NULL; out = `rows`
+ * rows on the SAME padded grid (the border rows are meaningless and cropped by the caller), fp32 or HL8, row stride ldo; act 0 | 1 GELU | 2 ReLU.
+ * C a multiple of 32.  Three products per tap and channel with fp32 accumulation, like every split linear.
+ * Replaces: the fp32 nn.Conv2d 3 x 3 of the MaskDINO pixel decoder's FPN output (detectron2 Conv2d + GN, maskdino_encoder.py:294-310) and of
+ * MaskHeadSmallConv (ddetrs_dn.py:1633-1689), MIOpen implicit-GEMM fp32 kernels before (1.3 ms per 256 -> 256 map at 128 x 128, bs 8).
+ */
+int hipie_conv3x3_split(const void* x, int64_t ldx, const void* w, const float* bias, void* out, int64_t ldo, int64_t rows, int Wp, int C,
+                        int N, int in_fmt, int out_fmt, int act, void* stream);
 
 /*
  * Row-wise top-k of fp32 scores, k <= 1024: idx_out (rows, k) int64 in descending value order (ascending index among equal values;

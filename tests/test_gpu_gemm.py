@@ -277,3 +277,27 @@ def test_ffn_fused_matches_two_split_gemms(M):
     e2 = float((got - two).abs().max() / two.abs().max())
     print("ffn_fused M=%d: vs fp64 %.2e, vs the two split GEMMs %.2e" % (M, e64, e2))
     assert e64 < 5e-6 and e2 < 5e-6
+
+
+@gpu
+@pytest.mark.parametrize("B,C,N,H,W,bias", [(2, 256, 256, 128, 128, True), (1, 64, 256, 33, 47, False), (3, 32, 512, 64, 20, True)])
+def test_conv3x3_split_matches_fp64(B, C, N, H, W, bias):
+    """hipie_conv3x3_split (3 x 3 / stride 1 / padding 1 convolution as an implicit GEMM on a zero-padded pixel grid, three-product split
+    arithmetic) against F.conv2d in double: ragged maps, borders, bias, NCHW and channels-last inputs."""
+    import torch.nn.functional as F
+    from hipie_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + C + H)
+    conv = torch.nn.Conv2d(C, N, 3, padding=1, bias=bias)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(N, C, 3, 3, generator=g) * (9 * C) ** -0.5)
+        if bias:
+            conv.bias.copy_(torch.randn(N, generator=g) * 0.3)
+    conv = conv.cuda()
+    x = torch.randn(B, C, H, W, generator=g)
+    want = F.conv2d(x.double(), conv.weight.detach().cpu().double(), None if not bias else conv.bias.detach().cpu().double(), padding=1)
+    for xin in (x.cuda(), x.cuda().contiguous(memory_format=torch.channels_last)):
+        got = ops.conv3x3_split(xin, conv)
+        assert got.shape == (B, N, H, W)
+        e = float((got.double().cpu() - want).abs().max() / want.abs().max())
+        print("conv3x3_split %dx%dx%dx%d -> %d: %.2e" % (B, C, H, W, N, e))
+        assert e < 3e-6
