@@ -51,6 +51,7 @@ SIGNATURES = {
     "hipie_vit_attn_split": [c_p, c_p, c_p, c_p] + [c_i] * 5 + [c_p],
     "hipie_msda_backward": [c_p] * 9 + [c_i] * 8 + [c_p],
     "hipie_gemm_batched": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l] + [c_i] * 6 + [c_f, c_p],
+    "hipie_gemm_batched_softmax": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l] + [c_i] * 5 + [c_p, c_i, c_f, c_f, c_p],
     "hipie_softmax_hl8": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_f, c_p],
     "hipie_attn_f32": [c_p] * 5 + [c_i] * 5 + [c_l] * 6 + [c_f, c_p],
     "hipie_attn_split": [c_p] * 5 + [c_i] * 5 + [c_l] * 6 + [c_f, c_p],

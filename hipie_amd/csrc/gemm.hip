@@ -52,6 +52,12 @@ struct GemmParams {
   // come from the pixel row shifted by tap (dy, dx): byte offset ((dy - 1) * conv_wp + (dx - 1)) * lda_b + (kt % conv_kpt) * 128 -- the same
   // for every row, so only the scalar source base of the A tile changes.  conv_kpt = k tiles per tap (0: plain GEMM).
   int conv_kpt, conv_wp;
+  // row softmax in the epilogue (hipie_gemm_batched_softmax: the logits GEMM of the image -> text fusion attention, N = text length <= 256
+  // = ONE column tile): out = HL8 of softmax_j( clamp(acc) masked ) per row; sm_mask (n_outer, sm_L) uint8 or null, column j valid iff
+  // j < sm_L && mask[outer][j].  0 = off.
+  int softmax, sm_L;
+  float sm_clamp;
+  const unsigned char* sm_mask;
   int variant;                // timing experiments (HIPIE_GEMM_VARIANTS builds only)
   int prio_mode;              // gemm2: 0 none, 1 blocks 256..511 at low priority (phase offset), 2 by dispatch-round parity
 };
@@ -201,6 +207,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams pin) {
     p.A += bo * p.a_bo + bi * p.a_bi;
     p.W += bo * p.w_bo + bi * p.w_bi;
     p.out += bo * p.o_bo + bi * p.o_bi;
+    if (p.sm_mask != nullptr) p.sm_mask += (long)bo * p.sm_L;
   }
   constexpr int BM = 256;
   constexpr int ROWS = BM + BN;                // rows of one LDS stage: the A tile then the W tile
@@ -368,6 +375,70 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams pin) {
   // LDS reads the compiler can schedule freely between the global stores (a global read behind every store serialised the epilogue)
   float* sbias = reinterpret_cast<float*>(smem);
   if (tid < BN) sbias[tid] = (p.bias != nullptr && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
+  if (SPLIT && VAR == 0 && BN == 256 && p.softmax) {
+    // ---- row softmax over the tile's columns (the whole row: one column tile).  A lane owns 64 of its token's 256 columns per token
+    //      tile (its lane half's 4 of every 8, this wave's 128-column half): lane-local reduction, one exchange with the other lane half
+    //      (xor 32), one with the partner wave (wn ^ 1) through LDS.  Column validity enters as a 0 / -inf table. ----
+    float* kb = sbias + 256;                    // [256] 0 | -inf per column
+    float* red = kb + 256;                      // [2 wn][256 tokens] partial max, then partial sums
+    if (tid < 256) kb[tid] = (tid < p.sm_L && (p.sm_mask == nullptr || p.sm_mask[tid] != 0)) ? 0.f : -INFINITY;
+    __syncthreads();
+    const float cl = p.sm_clamp;
+    float mx[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 k4 = *reinterpret_cast<const f32x4*>(kb + wn * (BN / 2) + j * 32 + 8 * g + 4 * hi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = acc[j][t][4 * g + e] * p.alpha;
+            if (cl > 0.f) x = __builtin_amdgcn_fmed3f(x, -cl, cl);
+            x += k4[e];
+            acc[j][t][4 * g + e] = x;
+            mx[t] = fmaxf(mx[t], x);
+          }
+        }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      mx[t] = fmaxf(mx[t], __shfl_xor(mx[t], 32));
+      if (hi == 0) red[wn * 256 + wm * 64 + t * 32 + li] = mx[t];
+    }
+    __syncthreads();
+    float sm[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float m = fmaxf(mx[t], red[(wn ^ 1) * 256 + wm * 64 + t * 32 + li]);
+      const float m2 = (m == -INFINITY) ? 0.f : m * 1.4426950408889634f;
+      float su = 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(acc[j][t][r] * 1.4426950408889634f - m2);     // exp2(-inf) = 0 on masked columns
+          acc[j][t][r] = pv;
+          su += pv;
+        }
+      sm[t] = su + __shfl_xor(su, 32);
+    }
+    __syncthreads();                             // everybody has read the partial maxima
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (hi == 0) red[wn * 256 + wm * 64 + t * 32 + li] = sm[t];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float tot = sm[t] + red[(wn ^ 1) * 256 + wm * 64 + t * 32 + li];
+      const float inv = tot > 0.f ? 1.f / tot : 0.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][t][r] *= inv;
+    }
+    p.alpha = 1.f;                               // the values are final: the store path below adds the (zero) bias and writes HL8
+  }
   __syncthreads();
   // residual rows: the four quads of block (t, j + 1) are requested before block (t, j) is processed
   float4 rq[2][4];
@@ -616,7 +687,7 @@ extern "C" int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw
   p.M = M; p.N = N; p.K = K; p.nkt = K / kq;
   p.out_fmt = out_fmt; p.act = act; p.alpha = alpha; p.oscale = oscale;
   p.nbi = 1; p.a_bo = p.a_bi = p.w_bo = p.w_bi = p.o_bo = p.o_bi = 0;
-  p.conv_kpt = 0; p.conv_wp = 0;
+  p.conv_kpt = 0; p.conv_wp = 0; p.softmax = 0; p.sm_L = 0; p.sm_clamp = 0.f; p.sm_mask = nullptr;
   hipStream_t st = (hipStream_t)stream;
   const bool wide = (N % 320 == 0);
   // problems that fill less than 3/8 of the CUs with 256-row tiles go to the 64 x 128 tile kernel (HIPIE_GEMM_SMALL=0: never; A/B timing)
@@ -673,7 +744,7 @@ extern "C" int hipie_gemm_batched(const void* A, int64_t lda, int64_t a_outer, i
   p.lda_b = lda * 2; p.ldw_b = ldw * 2; p.ldr = 0; p.ldo = ldo;
   p.M = M; p.N = N; p.K = K; p.nkt = K / 32;
   p.out_fmt = out_fmt; p.act = 0; p.alpha = alpha; p.oscale = 1.f;
-  p.conv_kpt = 0; p.conv_wp = 0;
+  p.conv_kpt = 0; p.conv_wp = 0; p.softmax = 0; p.sm_L = 0; p.sm_clamp = 0.f; p.sm_mask = nullptr;
   const long osz = out_fmt == HIPIE_F32 ? 4 : 2;
   p.nbi = n_inner;
   p.a_bo = a_outer * 2; p.a_bi = a_inner * 2; p.w_bo = w_outer * 2; p.w_bi = w_inner * 2; p.o_bo = o_outer * osz; p.o_bi = o_inner * osz;
@@ -685,6 +756,30 @@ extern "C" int hipie_gemm_batched(const void* A, int64_t lda, int64_t a_outer, i
   if (gemm2_mode() == 1) return (N % 160 == 0) ? launch_gemm2<5, 0>(p, st, batches) : launch_gemm2<4, 0>(p, st, batches);
 #endif
   return (N % 320 == 0) ? launch_gemm<320, true>(p, st, batches) : launch_gemm<256, true>(p, st, batches);
+}
+
+extern "C" int hipie_gemm_batched_softmax(const void* A, int64_t lda, int64_t a_outer, int64_t a_inner, const void* W, int64_t ldw, int64_t w_outer,
+                                          int64_t w_inner, void* out, int64_t ldo, int64_t o_outer, int64_t o_inner, int n_outer, int n_inner,
+                                          int M, int N, int K, const unsigned char* mask, int L, float clamp, float alpha, void* stream) {
+  HIPIE_REQUIRE(A && W && out, "gemm_batched_softmax: null pointer");
+  HIPIE_REQUIRE(M > 0 && N > 0 && N <= 256 && N % 8 == 0 && K > 0 && K % 32 == 0 && L > 0 && L <= N,
+                "gemm_batched_softmax: M=%d N=%d K=%d L=%d (N <= 256: the row must fit one column tile)", M, N, K, L);
+  HIPIE_REQUIRE(n_outer > 0 && n_inner > 0 && (long)n_outer * n_inner <= 65535, "gemm_batched_softmax: %d x %d problems", n_outer, n_inner);
+  HIPIE_REQUIRE(lda >= 2 * K && ldw >= 2 * K && lda % 8 == 0 && ldw % 8 == 0, "gemm_batched_softmax: operand row strides %ld / %ld", (long)lda, (long)ldw);
+  HIPIE_REQUIRE((long)256 * lda * 2 < (1L << 31) && (long)320 * ldw * 2 < (1L << 31), "gemm_batched_softmax: row stride too large");
+  HIPIE_REQUIRE(ldo >= 2 * N && ldo % 4 == 0, "gemm_batched_softmax: output row stride %ld (HL8: >= %d)", (long)ldo, 2 * N);
+  HIPIE_REQUIRE(((a_outer | a_inner | w_outer | w_inner) % 8) == 0 && ((o_outer | o_inner) % 4) == 0, "gemm_batched_softmax: batch offsets must keep 16-byte alignment");
+  HIPIE_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0, "gemm_batched_softmax: pointers must be 16-byte aligned");
+  GemmParams p;
+  p.A = (const char*)A; p.W = (const char*)W; p.bias = nullptr; p.resid = nullptr; p.out = (char*)out; p.out_row = nullptr;
+  p.lda_b = lda * 2; p.ldw_b = ldw * 2; p.ldr = 0; p.ldo = ldo;
+  p.M = M; p.N = N; p.K = K; p.nkt = K / 32;
+  p.out_fmt = HIPIE_HL8; p.act = 0; p.alpha = alpha; p.oscale = 1.f;
+  p.nbi = n_inner;
+  p.a_bo = a_outer * 2; p.a_bi = a_inner * 2; p.w_bo = w_outer * 2; p.w_bi = w_inner * 2; p.o_bo = o_outer * 2; p.o_bi = o_inner * 2;
+  p.conv_kpt = 0; p.conv_wp = 0; p.prio_mode = 0; p.variant = 0;
+  p.softmax = 1; p.sm_L = L; p.sm_clamp = clamp; p.sm_mask = mask;
+  return launch_gemm<256, true>(p, (hipStream_t)stream, n_outer * n_inner);
 }
 
 extern "C" int hipie_conv3x3_split(const void* x, int64_t ldx, const void* w, const float* bias, void* out, int64_t ldo, int64_t rows, int Wp,
@@ -708,7 +803,7 @@ extern "C" int hipie_conv3x3_split(const void* x, int64_t ldx, const void* w, co
   p.M = (int)rows; p.N = N; p.K = 9 * C; p.nkt = 9 * C / 32;
   p.out_fmt = out_fmt; p.act = act; p.alpha = 1.f; p.oscale = 1.f;
   p.nbi = 1; p.a_bo = p.a_bi = p.w_bo = p.w_bi = p.o_bo = p.o_bi = 0;
-  p.conv_kpt = C / 32; p.conv_wp = Wp;
+  p.conv_kpt = C / 32; p.conv_wp = Wp; p.softmax = 0; p.sm_L = 0; p.sm_clamp = 0.f; p.sm_mask = nullptr;
   p.prio_mode = 0; p.variant = 0;
   hipStream_t st = (hipStream_t)stream;
   const bool wide = (N % 320 == 0);

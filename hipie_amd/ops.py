@@ -216,8 +216,8 @@ def bi_i2t_split(q_hl8, k, vl, text_mask, heads, clamp=50000.0):
     """image -> text direction of the vision-language fusion at fp32-class accuracy (fuse_helper.py:77-121):
         out_v[b, i, h] = softmax_j( clamp(q[b,i,h] . k[b,j,h]) over the text tokens kept by text_mask ) . vl[b, j, h]
     q_hl8 (B, Nv, 2*E) HL8 (E = heads * hd; the scaled v_proj output straight from the GEMM epilogue), k, vl (B, L, E) fp32,
-    text_mask (B, L) -> (B, Nv, E) fp32.  Three launches on the data path: S = Q_h.K_h^T for every (image, head) as ONE batched split
-    GEMM, the masked row softmax written as HL8, P_h.V_h as the second batched GEMM; the text-side operands (L x E) are padded to a
+    text_mask (B, L) -> (B, Nv, E) fp32.  Texts of up to 256 tokens: TWO launches -- the batched logits GEMM with the masked row softmax in
+    its epilogue (P as HL8; S never exists) and P_h.V_h as the second batched GEMM; longer texts: S = Q_h.K_h^T, hipie_softmax_hl8, P_h.V_h; the text-side operands (L x E) are padded to a
     multiple of 32 tokens and split on the way."""
     lib = _lib.load()
     B, Nv, E2 = q_hl8.shape
@@ -234,14 +234,21 @@ def bi_i2t_split(q_hl8, k, vl, text_mask, heads, clamp=50000.0):
     vt = torch.zeros(B, heads, hd, Lp, dtype=torch.float32, device=dev)
     vt[..., :L] = vl.reshape(B, L, heads, hd).permute(0, 2, 3, 1)
     vt_hl8 = to_hl8(vt)                                                       # (B, heads, hd, 2 Lp): V_h^T, K = tokens
-    S = torch.empty(B, heads, Nv, Lp, dtype=torch.float32, device=dev)
-    rc = lib.hipie_gemm_batched(q_hl8.data_ptr(), 2 * E, Nv * 2 * E, 2 * hd, k_hl8.data_ptr(), 2 * E, Lp * 2 * E, 2 * hd,
-                                S.data_ptr(), Lp, heads * Nv * Lp, Nv * Lp, B, heads, Nv, Lp, hd, F32, 1.0, _stream())
-    _lib.check(rc, "hipie_gemm_batched")
     P = torch.empty(B, heads, Nv, 2 * Lp, dtype=torch.float16, device=dev)
     mk = text_mask.to(torch.uint8).contiguous()
-    rc = lib.hipie_softmax_hl8(S.data_ptr(), Lp, P.data_ptr(), 2 * Lp, B * heads * Nv, L, Lp, mk.data_ptr(), heads * Nv, float(clamp), _stream())
-    _lib.check(rc, "hipie_softmax_hl8")
+    if Lp <= 256:
+        # a text of up to 256 tokens is ONE column tile: the masked softmax runs in the logits GEMM's epilogue, S never exists
+        rc = lib.hipie_gemm_batched_softmax(q_hl8.data_ptr(), 2 * E, Nv * 2 * E, 2 * hd, k_hl8.data_ptr(), 2 * E, Lp * 2 * E, 2 * hd,
+                                            P.data_ptr(), 2 * Lp, heads * Nv * 2 * Lp, Nv * 2 * Lp, B, heads, Nv, Lp, hd, mk.data_ptr(), L,
+                                            float(clamp), 1.0, _stream())
+        _lib.check(rc, "hipie_gemm_batched_softmax")
+    else:
+        S = torch.empty(B, heads, Nv, Lp, dtype=torch.float32, device=dev)
+        rc = lib.hipie_gemm_batched(q_hl8.data_ptr(), 2 * E, Nv * 2 * E, 2 * hd, k_hl8.data_ptr(), 2 * E, Lp * 2 * E, 2 * hd,
+                                    S.data_ptr(), Lp, heads * Nv * Lp, Nv * Lp, B, heads, Nv, Lp, hd, F32, 1.0, _stream())
+        _lib.check(rc, "hipie_gemm_batched")
+        rc = lib.hipie_softmax_hl8(S.data_ptr(), Lp, P.data_ptr(), 2 * Lp, B * heads * Nv, L, Lp, mk.data_ptr(), heads * Nv, float(clamp), _stream())
+        _lib.check(rc, "hipie_softmax_hl8")
     out = torch.empty(B, Nv, E, dtype=torch.float32, device=dev)
     rc = lib.hipie_gemm_batched(P.data_ptr(), 2 * Lp, heads * Nv * 2 * Lp, Nv * 2 * Lp, vt_hl8.data_ptr(), 2 * Lp, heads * hd * 2 * Lp, hd * 2 * Lp,
                                 out.data_ptr(), E, Nv * E, hd, B, heads, Nv, hd, Lp, F32, 1.0, _stream())

@@ -427,6 +427,17 @@ int hipie_gemm_batched(const void* A, int64_t lda, int64_t a_outer, int64_t a_in
                        int K, int out_fmt, float alpha, void* stream);
 
 /*
+ * hipie_gemm_batched whose epilogue is the masked row softmax (N <= 256: the whole row is one column tile) -- the logits of the image -> text
+ * fusion attention never reach HBM:  P[b][h] = softmax_j( clamp(alpha * A . W^T, +-clamp) over the columns j < L with mask[b][j] ) written as
+ * HIPIE_HL8 (the A operand of the P . V product that follows); masked and padding columns (L <= j < N) are 0, a row without a valid column is 0.
+ * mask (n_outer, L) uint8 or NULL.  Replaces hipie_gemm_batched(F32 out) + hipie_softmax_hl8 for texts of up to 256 tokens
+ * (attn_weights_v of BiMultiHeadAttention.forward, models/deformable_detr/fuse_helper.py:77-111).
+ */
+int hipie_gemm_batched_softmax(const void* A, int64_t lda, int64_t a_outer, int64_t a_inner, const void* W, int64_t ldw, int64_t w_outer,
+                               int64_t w_inner, void* out, int64_t ldo, int64_t o_outer, int64_t o_inner, int n_outer, int n_inner, int M,
+                               int N, int K, const unsigned char* mask, int L, float clamp, float alpha, void* stream);
+
+/*
  * Row softmax of fp32 logits written as an HL8 operand:  P[r, :Lp] = softmax over the L valid columns of clamp(S[r, :L], +-clamp) with
  * columns masked by mask[r / rows_per_batch, :] (uint8, 1 = keep; NULL = all) or beyond L set to 0.  S rows lds floats apart, P rows
  * ldp fp16 elements apart (>= 2 * Lp);  Lp a multiple of 8, <= 4096.  A row with no valid column gives zeros (DEVIATION, never reached
