@@ -38,6 +38,7 @@ namespace hipie {
 struct GemmParams {
   const char* A; const char* W; const float* bias; const float* resid; char* out;
   const int32_t* out_row;     // optional: row m of the product goes to output / residual row out_row[m] (< 0: dropped) -- window un-partition
+  const int32_t* a_row;       // optional: row m of the product READS operand row a_row[m] (gather; hipie_gemm_gather) -- the real tokens of a padded window layout
   long lda_b, ldw_b;          // row strides of A / W in BYTES
   long ldr, ldo;              // row strides of resid (fp32 elements) / out (elements of the output format: fp32 | fp16; HL8: fp16 elements)
   int M, N, K;
@@ -245,11 +246,14 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams pin) {
     for (int i = 0; i < NI; ++i) {
       const int r = 8 * (8 * i + wave) + rl;              // stage row
       const int c = cp ^ ((r >> 1) & 7);                  // logical chunk stored at this position
-      if (r < BM) dvoff[i] = (unsigned int)((long)min(r, p.M - 1 - m0) * p.lda_b + 16 * c);
-      else dvoff[i] = (unsigned int)((long)min(r - BM, p.N - 1 - n0) * p.ldw_b + 16 * c);
+      if (r < BM) {
+        const int mr = min(r, p.M - 1 - m0);
+        // gather: the offset is taken from the START of A (all of A within 4 GB: checked on the host)
+        dvoff[i] = p.a_row != nullptr ? (unsigned int)((long)p.a_row[m0 + mr] * p.lda_b + 16 * c) : (unsigned int)((long)mr * p.lda_b + 16 * c);
+      } else dvoff[i] = (unsigned int)((long)min(r - BM, p.N - 1 - n0) * p.ldw_b + 16 * c);
     }
   }
-  const char* abase = p.A + (long)m0 * p.lda_b;
+  const char* abase = p.a_row != nullptr ? p.A : p.A + (long)m0 * p.lda_b;
   const char* wbase = p.W + (long)n0 * p.ldw_b;
   const unsigned int lds0 = (unsigned int)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
 
@@ -658,9 +662,9 @@ __global__ __launch_bounds__(256) void to_hl8_kernel(const T* __restrict__ x, f1
 
 using namespace hipie;
 
-extern "C" int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* resid, int64_t ldr,
-                          void* out, int64_t ldo, const int32_t* out_row, int M, int N, int K, int in_fmt, int out_fmt, int act, float alpha,
-                          float oscale, void* stream) {
+static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* resid, int64_t ldr,
+                     void* out, int64_t ldo, const int32_t* out_row, const int32_t* a_row, int64_t a_rows, int M, int N, int K, int in_fmt,
+                     int out_fmt, int act, float alpha, float oscale, void* stream) {
   HIPIE_REQUIRE(A && W && out, "gemm: null pointer");
   HIPIE_REQUIRE(in_fmt == HIPIE_F16 || in_fmt == HIPIE_HL8 || in_fmt == HIPIE_F32, "gemm: operand format %d (HIPIE_F16 | HIPIE_HL8 | HIPIE_F32)",
                 in_fmt);
@@ -682,7 +686,7 @@ extern "C" int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw
   HIPIE_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
                 ((uintptr_t)bias % 16) == 0 && ((uintptr_t)resid % 16) == 0, "gemm: pointers must be 16-byte aligned");
   GemmParams p;
-  p.A = (const char*)A; p.W = (const char*)W; p.bias = bias; p.resid = resid; p.out = (char*)out; p.out_row = out_row;
+  p.A = (const char*)A; p.W = (const char*)W; p.bias = bias; p.resid = resid; p.out = (char*)out; p.out_row = out_row; p.a_row = a_row;
   p.lda_b = lda * 2; p.ldw_b = ldw * 2; p.ldr = ldr; p.ldo = ldo;
   p.M = M; p.N = N; p.K = K; p.nkt = K / kq;
   p.out_fmt = out_fmt; p.act = act; p.alpha = alpha; p.oscale = oscale;
@@ -720,10 +724,25 @@ extern "C" int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw
     return w160 ? launch_gemm2<5, 0>(p, st) : launch_gemm2<4, 0>(p, st);
   }
 #endif
-  if (split && small_ok) return a_f32 ? launch_gemm_small<2>(p, st) : launch_gemm_small<0>(p, st);
+  if (split && small_ok && a_row == nullptr) return a_f32 ? launch_gemm_small<2>(p, st) : launch_gemm_small<0>(p, st);
   if (a_f32) return wide ? launch_gemm<320, true, 2>(p, st) : launch_gemm<256, true, 2>(p, st);
   if (split) return wide ? launch_gemm<320, true>(p, st) : launch_gemm<256, true>(p, st);
   return wide ? launch_gemm<320, false>(p, st) : launch_gemm<256, false>(p, st);
+}
+
+extern "C" int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* resid, int64_t ldr,
+                          void* out, int64_t ldo, const int32_t* out_row, int M, int N, int K, int in_fmt, int out_fmt, int act, float alpha,
+                          float oscale, void* stream) {
+  return gemm_impl(A, lda, W, ldw, bias, resid, ldr, out, ldo, out_row, nullptr, 0, M, N, K, in_fmt, out_fmt, act, alpha, oscale, stream);
+}
+
+extern "C" int hipie_gemm_gather(const void* A, int64_t lda, int64_t a_rows, const int32_t* a_row, const void* W, int64_t ldw, const float* bias,
+                                 const float* resid, int64_t ldr, void* out, int64_t ldo, const int32_t* out_row, int M, int N, int K, int in_fmt,
+                                 int out_fmt, int act, float alpha, float oscale, void* stream) {
+  HIPIE_REQUIRE(a_row != nullptr && a_rows > 0, "gemm_gather: a_row map / operand row count missing");
+  HIPIE_REQUIRE(in_fmt == HIPIE_HL8 || in_fmt == HIPIE_F32, "gemm_gather: split operands only (HIPIE_HL8 | HIPIE_F32 rows)");
+  HIPIE_REQUIRE((long)a_rows * lda * (in_fmt == HIPIE_F32 ? 4 : 2) < (1L << 32), "gemm_gather: the gathered operand must stay below 4 GiB");
+  return gemm_impl(A, lda, W, ldw, bias, resid, ldr, out, ldo, out_row, a_row, a_rows, M, N, K, in_fmt, out_fmt, act, alpha, oscale, stream);
 }
 
 extern "C" int hipie_gemm_batched(const void* A, int64_t lda, int64_t a_outer, int64_t a_inner, const void* W, int64_t ldw, int64_t w_outer,
@@ -740,7 +759,7 @@ extern "C" int hipie_gemm_batched(const void* A, int64_t lda, int64_t a_outer, i
   HIPIE_REQUIRE(((a_outer | a_inner | w_outer | w_inner) % 8) == 0 && ((o_outer | o_inner) % 4) == 0, "gemm_batched: batch offsets must keep 16-byte alignment");
   HIPIE_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0, "gemm_batched: pointers must be 16-byte aligned");
   GemmParams p;
-  p.A = (const char*)A; p.W = (const char*)W; p.bias = nullptr; p.resid = nullptr; p.out = (char*)out; p.out_row = nullptr;
+  p.A = (const char*)A; p.W = (const char*)W; p.bias = nullptr; p.resid = nullptr; p.out = (char*)out; p.out_row = nullptr; p.a_row = nullptr;
   p.lda_b = lda * 2; p.ldw_b = ldw * 2; p.ldr = 0; p.ldo = ldo;
   p.M = M; p.N = N; p.K = K; p.nkt = K / 32;
   p.out_fmt = out_fmt; p.act = 0; p.alpha = alpha; p.oscale = 1.f;
@@ -771,7 +790,7 @@ extern "C" int hipie_gemm_batched_softmax(const void* A, int64_t lda, int64_t a_
   HIPIE_REQUIRE(((a_outer | a_inner | w_outer | w_inner) % 8) == 0 && ((o_outer | o_inner) % 4) == 0, "gemm_batched_softmax: batch offsets must keep 16-byte alignment");
   HIPIE_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0, "gemm_batched_softmax: pointers must be 16-byte aligned");
   GemmParams p;
-  p.A = (const char*)A; p.W = (const char*)W; p.bias = nullptr; p.resid = nullptr; p.out = (char*)out; p.out_row = nullptr;
+  p.A = (const char*)A; p.W = (const char*)W; p.bias = nullptr; p.resid = nullptr; p.out = (char*)out; p.out_row = nullptr; p.a_row = nullptr;
   p.lda_b = lda * 2; p.ldw_b = ldw * 2; p.ldr = 0; p.ldo = ldo;
   p.M = M; p.N = N; p.K = K; p.nkt = K / 32;
   p.out_fmt = HIPIE_HL8; p.act = 0; p.alpha = alpha; p.oscale = 1.f;
@@ -798,7 +817,7 @@ extern "C" int hipie_conv3x3_split(const void* x, int64_t ldx, const void* w, co
   HIPIE_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)bias % 16) == 0,
                 "conv3x3_split: pointers must be 16-byte aligned");
   GemmParams p;
-  p.A = (const char*)x; p.W = (const char*)w; p.bias = bias; p.resid = nullptr; p.out = (char*)out; p.out_row = nullptr;
+  p.A = (const char*)x; p.W = (const char*)w; p.bias = bias; p.resid = nullptr; p.out = (char*)out; p.out_row = nullptr; p.a_row = nullptr;
   p.lda_b = ldx * 2; p.ldw_b = (long)2 * 9 * C * 2; p.ldr = 0; p.ldo = ldo;
   p.M = (int)rows; p.N = N; p.K = 9 * C; p.nkt = 9 * C / 32;
   p.out_fmt = out_fmt; p.act = act; p.alpha = 1.f; p.oscale = 1.f;

@@ -141,7 +141,7 @@ class Attention(nn.Module):
             o = ops.vit_attn(qkv16, rel_h, rel_w, (H, W), nh, self.scale)
         return self.proj(o.to(x.dtype)).view(B, H, W, C)
 
-    def forward_split(self, y, B, H, W, resid, out_row=None):
+    def forward_split(self, y, B, H, W, resid, out_row=None, tok2win=None):
         """the split policy: y (B*H*W, 2C) HL8 (LayerNorm output) -> resid + proj(attention(qkv(y))), written IN PLACE into the fp32
         residual stream ``resid`` (rows, C).  qkv leaves its GEMM as HL8 (q rows pre-scaled, fold cached per parameter version), the
         attention forms logits and bias from both halves of both operands (hipie_vit_attn_split) and writes HL8, which the projection
@@ -174,14 +174,33 @@ class Attention(nn.Module):
             o = ops.to_hl8(o16.view(B * H * W, C))
             return ops.split_linear(o, self, "proj", self.proj.weight, self.proj.bias, x_hl8=True, tag="gemm_proj",
                                     resid=resid, out=resid, out_row=out_row)
-        qkv = ops.split_linear(y, self, "qkv", self.qkv.weight, self.qkv.bias, out_fmt=ops.HL8, x_hl8=True, weight_fn=wq, bias_fn=bq,
-                               tag="gemm_qkv")
+        if tok2win is not None:
+            # windowed block: the qkv rows of the PADDING tokens are the bias (their LayerNorm output is zero, utils.py:29-37) and their
+            # projections are discarded -- the two GEMMs run over the real tokens only (gather / scatter through the window row map) and the
+            # padding rows are filled with the HL8 bias row
+            rows = y.shape[0]
+            qkv = torch.empty(rows, 6 * C, dtype=torch.float16, device=y.device)
+            w_, b_, _ = ops.split_weight(self, "qkv", [self.qkv.weight, self.qkv.bias], wq, bq)
+            pk = (rows, out_row.data_ptr(), self._versions())
+            if getattr(self, "_pad_key", None) != pk:
+                self._pad_rows = torch.nonzero(out_row < 0).flatten()
+                self._pad_bias = ops.to_hl8(b_.view(1, -1))
+                self._pad_key = pk
+            qkv[self._pad_rows] = self._pad_bias
+            ops.split_linear(y, self, "qkv", self.qkv.weight, self.qkv.bias, out_fmt=ops.HL8, x_hl8=True, weight_fn=wq, bias_fn=bq,
+                             tag="gemm_qkv", out=qkv, out_row=tok2win, a_row=tok2win)
+        else:
+            qkv = ops.split_linear(y, self, "qkv", self.qkv.weight, self.qkv.bias, out_fmt=ops.HL8, x_hl8=True, weight_fn=wq, bias_fn=bq,
+                                   tag="gemm_qkv")
         key = (H, W, self._versions())
         if getattr(self, "_tabs_key", None) != key:
             self._tabs = (ops.hl8_pack(resize_rel_pos(H, self.rel_pos_h.detach().float()) / self.scale),
                           ops.hl8_pack(resize_rel_pos(W, self.rel_pos_w.detach().float()) / self.scale))
             self._tabs_key = key
         o = ops.vit_attn_split(qkv.view(B, H * W, 6 * C), self._tabs[0], self._tabs[1], (H, W), nh)
+        if tok2win is not None:          # the projection reads the real tokens' rows out of the window layout and writes token order
+            return ops.split_linear(o.view(B * H * W, 2 * C), self, "proj", self.proj.weight, self.proj.bias, x_hl8=True, tag="gemm_proj",
+                                    resid=resid, out=resid, a_row=tok2win)
         return ops.split_linear(o.view(B * H * W, 2 * C), self, "proj", self.proj.weight, self.proj.bias, x_hl8=True, tag="gemm_proj",
                                 resid=resid, out=resid, out_row=out_row)
 
@@ -294,7 +313,8 @@ def _block_forward_split(self, x, delta):
             raise NotImplementedError("split policy: window size %d" % ws)
         out_src, delta_row, nwin = window_row_maps(B, H, W, ws, x.device)
         y = ops.add_layernorm(x, None, n1.weight, n1.bias, n1.eps, "hl8", out_src=out_src)[1]
-        self.attn.forward_split(y, nwin, ws, ws, xs, out_row=out_src)
+        trim = not getattr(self.attn.precision, "vit_attn16", False)
+        self.attn.forward_split(y, nwin, ws, ws, xs, out_row=out_src, tok2win=delta_row if trim else None)
     h = ops.add_layernorm(x, None, n2.weight, n2.bias, n2.eps, "hl8")[1]
     self.mlp.forward_split(h.view(B * H * W, 2 * C), xs)
     return x, None

@@ -815,7 +815,7 @@ def _gemm_tag(a, w, *args, **kw):
 
 @_timed(_gemm_tag)
 def gemm(a, w, bias=None, resid=None, out_fmt=F32, act=ACT_NONE, alpha=1.0, oscale=1.0, split=None, out=None, tag="gemm", out_row=None,
-         out_rows=None):
+         out_rows=None, a_row=None):
     """out = ((act(alpha * a . w^T + bias)) + resid) * oscale on hipie_gemm.
     a (..., K) fp16 and w (N, K) fp16 (one product), or both HL8: a (..., 2K), w (N, 2K) fp16 (three products, fp32-class);
     `split` tells which (default: inferred -- pass it when K is ambiguous).  With split=True a may also be PLAIN fp32 (..., K) rows
@@ -836,6 +836,11 @@ def gemm(a, w, bias=None, resid=None, out_fmt=F32, act=ACT_NONE, alpha=1.0, osca
     if a_f32 and (a2.stride(0) % 4 or a2.data_ptr() % 16):
         raise RuntimeError("gemm: fp32 a rows must be 16-byte aligned")
     M = a2.shape[0]
+    if a_row is not None:            # gather: product row m reads operand row a_row[m] (hipie_gemm_gather); M = the map's length
+        if a_row.dtype != torch.int32 or not a_row.is_contiguous() or not split:
+            raise RuntimeError("gemm: a_row must be a contiguous int32 vector (split operands only)")
+        M = a_row.numel()
+        lead = (M,)
     if out_row is not None:
         if out is None:
             lead = (int(out_rows),)
@@ -856,6 +861,13 @@ def gemm(a, w, bias=None, resid=None, out_fmt=F32, act=ACT_NONE, alpha=1.0, osca
             raise RuntimeError("gemm: resid must be fp32 with contiguous rows")
     if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
         raise RuntimeError("gemm: bias must be contiguous fp32")
+    if a_row is not None:
+        rc = lib.hipie_gemm_gather(a2.data_ptr(), a2.stride(0), a2.shape[0], a_row.data_ptr(), _chk(w, "w"), w.shape[1],
+                                   None if bias is None else bias.data_ptr(), None if r2 is None else r2.data_ptr(), 0 if r2 is None else r2.stride(0),
+                                   o2.data_ptr(), o2.stride(0), None if out_row is None else out_row.data_ptr(), M, N, Kw,
+                                   F32 if a_f32 else HL8, int(out_fmt), int(act), float(alpha), float(oscale), _stream())
+        _lib.check(rc, "hipie_gemm_gather")
+        return out
     rc = lib.hipie_gemm(a2.data_ptr(), a2.stride(0), _chk(w, "w"), w.shape[1], None if bias is None else bias.data_ptr(),
                         None if r2 is None else r2.data_ptr(), 0 if r2 is None else r2.stride(0), o2.data_ptr(), o2.stride(0),
                         None if out_row is None else out_row.data_ptr(), M, N, Kw, F32 if a_f32 else (HL8 if split else F16), int(out_fmt), int(act), float(alpha), float(oscale), _stream())
@@ -981,7 +993,7 @@ def split_ok(K):
 
 
 def split_linear(x, owner, key, weight, bias=None, act=ACT_NONE, out_fmt=F32, resid=None, x_hl8=False, weight_fn=None, bias_fn=None,
-                 tag="gemm", params=None, out=None, out_row=None):
+                 tag="gemm", params=None, out=None, out_row=None, a_row=None):
     """F.linear(x, weight, bias) at fp32-class accuracy on hipie_gemm's split operands.  x fp32 / fp16 (converted with hipie_to_hl8)
     or already HL8 (x_hl8).  weight_fn / bias_fn: derived weights (folded constants, concatenations) built once per parameter version."""
     if params is None:
@@ -993,10 +1005,10 @@ def split_linear(x, owner, key, weight, bias=None, act=ACT_NONE, out_fmt=F32, re
         a = x if x.dim() <= 2 or x.is_contiguous() else x.contiguous()      # fp32 rows: split inside the GEMM
     else:
         a = to_hl8(x if x.dtype in (torch.float32, torch.float16) else x.float())
-    if out is not None or out_row is not None:
+    if out is not None or out_row is not None or a_row is not None:
         if N != w.shape[0]:
             raise RuntimeError("split_linear: in-place / row-mapped outputs need N % 8 == 0")
-        return gemm(a, w, b, resid, out_fmt=out_fmt, act=act, split=True, tag=tag, out=out, out_row=out_row)
+        return gemm(a, w, b, resid, out_fmt=out_fmt, act=act, split=True, tag=tag, out=out, out_row=out_row, a_row=a_row)
     out = gemm(a, w, b, resid, out_fmt=out_fmt, act=act, split=True, tag=tag)
     if N != w.shape[0]:
         out = out[..., :(2 * N if out_fmt == HL8 else N)].contiguous()

@@ -401,6 +401,16 @@ int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const flo
                float oscale, void* stream);
 
 /*
+ * hipie_gemm whose product row m READS operand row a_row[m] (0 <= a_row[m] < a_rows; A is a_rows x K; split formats only; the whole operand
+ * below 4 GiB): the linears of the windowed ViT blocks run over the REAL tokens only and pick them out of / scatter them into (out_row) the
+ * zero-padded window layout (window_partition pads 64 x 64 tokens to 70 x 70: 19.6 % more rows, whose qkv is the bias and whose projection
+ * is discarded -- hipie/backbone/utils.py:16-60, hipie/backbone/vit.py:212-230).
+ */
+int hipie_gemm_gather(const void* A, int64_t lda, int64_t a_rows, const int32_t* a_row, const void* W, int64_t ldw, const float* bias,
+                      const float* resid, int64_t ldr, void* out, int64_t ldo, const int32_t* out_row, int M, int N, int K, int in_fmt,
+                      int out_fmt, int act, float alpha, float oscale, void* stream);
+
+/*
  * hipie_vit_attn_rel on SPLIT operands (fp32-class logits): qkv (B, gh*gw, 3, heads, hd) as HIPIE_HL8 rows (2 * 3 * heads * hd fp16
  * per token) with the q rows pre-scaled by scale * log2(e); tab_h (2*gh-1, hd), tab_w (2*gw-1, hd) = the rel-pos tables / scale, HL8.
  * Scores and both bias terms are three-product sums (q_lo.k_hi + q_hi.k_lo + q_hi.k_hi), the probabilities one fp16, V both halves;

@@ -301,3 +301,29 @@ def test_conv3x3_split_matches_fp64(B, C, N, H, W, bias):
         e = float((got.double().cpu() - want).abs().max() / want.abs().max())
         print("conv3x3_split %dx%dx%dx%d -> %d: %.2e" % (B, C, H, W, N, e))
         assert e < 3e-6
+
+
+@gpu
+def test_gemm_gather_and_scatter_rows():
+    """hipie_gemm_gather: product row m reads operand row a_row[m] and (with out_row) lands in output row out_row[m] -- the windowed ViT
+    blocks run their linears over the real tokens of the zero-padded window layout this way; rows that are not written keep their content."""
+    from hipie_amd import ops
+    g = torch.Generator().manual_seed(11)
+    rows, M, K, N = 1200, 700, 320, 640
+    x = torch.randn(rows, K, generator=g)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g)
+    a_row = torch.randperm(rows, generator=g)[:M].to(torch.int32)
+    out_row = torch.randperm(rows, generator=g)[:M].to(torch.int32)
+    xs, ws = ops.to_hl8(x.cuda()), ops.hl8_pack(w.cuda())
+    want = x[a_row.long()].double() @ w.double().t() + b.double()
+    got = ops.gemm(xs, ws, b.cuda(), split=True, a_row=a_row.cuda()).cpu()
+    assert got.shape == (M, N) and rel_err(got, want.float()) < 3e-6
+    out = torch.full((rows, N), 7.0, device="cuda")
+    ops.gemm(xs, ws, b.cuda(), split=True, a_row=a_row.cuda(), out_row=out_row.cuda(), out=out)
+    ref = torch.full((rows, N), 7.0, dtype=torch.float64)
+    ref[out_row.long()] = want
+    assert rel_err(out.cpu(), ref.float()) < 3e-6
+    xf = x.cuda()                                   # fp32 operand rows split in the kernel
+    got32 = ops.gemm(xf, ws, b.cuda(), split=True, a_row=a_row.cuda()).cpu()
+    assert rel_err(got32, want.float()) < 3e-6
