@@ -179,14 +179,15 @@ class Attention(nn.Module):
             # projections are discarded -- the two GEMMs run over the real tokens only (gather / scatter through the window row map) and the
             # padding rows are filled with the HL8 bias row
             rows = y.shape[0]
-            qkv = torch.empty(rows, 6 * C, dtype=torch.float16, device=y.device)
             w_, b_, _ = ops.split_weight(self, "qkv", [self.qkv.weight, self.qkv.bias], wq, bq)
-            pk = (rows, out_row.data_ptr(), self._versions())
+            pk = (rows, out_row.data_ptr(), str(y.device), self._versions())
             if getattr(self, "_pad_key", None) != pk:
-                self._pad_rows = torch.nonzero(out_row < 0).flatten()
-                self._pad_bias = ops.to_hl8(b_.view(1, -1))
+                # a per-block qkv buffer in the window layout whose padding rows hold the bias ONCE (0.6 GB per windowed block at bs 8:
+                # HBM is sized for it; refilling 99 MB of padding rows per block and step cost 1 ms per step)
+                self._qkv_buf = torch.empty(rows, 6 * C, dtype=torch.float16, device=y.device)
+                self._qkv_buf[torch.nonzero(out_row < 0).flatten()] = ops.to_hl8(b_.view(1, -1))
                 self._pad_key = pk
-            qkv[self._pad_rows] = self._pad_bias
+            qkv = self._qkv_buf
             ops.split_linear(y, self, "qkv", self.qkv.weight, self.qkv.bias, out_fmt=ops.HL8, x_hl8=True, weight_fn=wq, bias_fn=bq,
                              tag="gemm_qkv", out=qkv, out_row=tok2win, a_row=tok2win)
         else:
