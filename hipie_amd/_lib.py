@@ -30,6 +30,8 @@ SIGNATURES = {
     "hipie_bi_xattn_ws": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l] + [c_i] * 5 + [c_f, c_i, c_p],
     "hipie_bi_xattn_workspace": [c_i] * 5,
     "hipie_mask_einsum": [c_p, c_p, c_p] + [c_i] * 6 + [c_p],
+    "hipie_mask_einsum_workspace": [c_i, c_i, c_i],
+    "hipie_mask_einsum_ws": [c_p, c_p, c_p, c_p, c_p, c_l] + [c_i] * 6 + [c_p],
     "hipie_mask_einsum16": [c_p, c_p, c_p, c_p, c_p] + [c_i] * 6 + [c_p],
     "hipie_dynamic_mask": [c_p, c_p, c_p, c_p] + [c_i] * 7 + [c_p],
     "hipie_dynamic_mask16": [c_p, c_p, c_p, c_p] + [c_i] * 7 + [c_p],
@@ -93,7 +95,7 @@ def load():
             raise HipieLibraryError("%s does not export %s (stale build?)" % (LIB_PATH, name))
         fn.argtypes = argtypes
         fn.restype = (ctypes.c_char_p if name == "hipie_last_error" else
-                      ctypes.c_int64 if name == "hipie_bi_xattn_workspace" else ctypes.c_int)
+                      ctypes.c_int64 if name in ("hipie_bi_xattn_workspace", "hipie_mask_einsum_workspace") else ctypes.c_int)
     _lib = lib
     return lib
 

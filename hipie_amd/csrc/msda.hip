@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void msda_d32_kernel(const T* __restrict__ val
                                                        const A* __restrict__ loc_or_off, const A* __restrict__ w_or_logit,
                                                        const float* __restrict__ ref, T* __restrict__ out, int S, int M,
                                                        int L, int Lq, int P, int ref_dim, long total_groups,
-                                                       long off_stride, long w_stride, long vrow) {
+                                                       long off_stride, long w_stride, long vrow, int map) {
   extern __shared__ __attribute__((aligned(16))) float recs[];   // 32 groups x (LP * 8 + 4) words
   // XCD-aware block order: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md); give every XCD one CONTIGUOUS range of
   // (image, query) groups so that neighbouring queries -- which sample neighbouring value pixels -- share that XCD's L2
@@ -164,8 +164,45 @@ __global__ __launch_bounds__(256) void msda_d32_kernel(const T* __restrict__ val
   const long nblk = gridDim.x, qn = nblk >> 3, rn = nblk & 7;
   const long xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   const long blk = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
-  const long g = blk * 32 + (threadIdx.x >> 3);
-  const bool live = g < total_groups;
+  // Which 32 (query, head) groups this workgroup owns (placement only: every group computes the same thing wherever it runs).
+  //   map 0  heads fastest: a wave = the 8 heads of ONE query.  Its 8 lane groups fetch 8 unrelated 128-byte lines per corner
+  //          and nothing is reused inside a wave; the L1 hit rate is what co-resident neighbour queries happen to share.
+  //   map 1  queries fastest: a workgroup = 32 CONSECUTIVE queries of ONE head, a wave = 8 of them.  Neighbouring queries of a
+  //          pyramid sample neighbouring pixels of that head, so the x+1 corner of one lane group is the x corner of the next
+  //          and a corner instruction of a coarse level touches 2-5 distinct lines instead of 8.
+  //   map 2  (queries are the pyramid's own pixels, Lq == S, and every level is a multiple of 4 rows x 8 columns) a workgroup =
+  //          an 8-wide x 4-high TILE of one level, wave w = row w of the tile: the y+1 corners of a wave are the y corners of
+  //          the next wave.  Falls back to map 1 when a level does not divide.
+  long g;
+  bool live;
+  if (map == 0) {
+    g = blk * 32 + (threadIdx.x >> 3);
+    live = g < total_groups;
+  } else {
+    const long chunk = blk / M;
+    const int mh = (int)(blk - chunk * M);
+    long bqn = chunk * 32 + (threadIdx.x >> 3);
+    if (map == 2) {
+      bool tiles = true;
+      for (int l = 0; l < L; ++l) tiles = tiles && (shapes[2 * l] % 4 == 0) && (shapes[2 * l + 1] % 8 == 0);
+      if (tiles) {
+        const long cpi = Lq / 32;                        // tiles per image (every level divides, so does their sum)
+        const long bi = chunk / cpi;
+        long ci = chunk - bi * cpi;
+        int l = 0;
+        for (; l < L - 1; ++l) {
+          const long nt = (shapes[2 * l] / 4) * (shapes[2 * l + 1] / 8);
+          if (ci < nt) break;
+          ci -= nt;
+        }
+        const long Wl = shapes[2 * l + 1], tw = Wl / 8;
+        const long ty = ci / tw, tx = ci - ty * tw;
+        bqn = bi * Lq + lstart[l] + (ty * 4 + (threadIdx.x >> 6)) * Wl + tx * 8 + ((threadIdx.x >> 3) & 7);
+      }
+    }
+    live = bqn < total_groups / M;
+    g = (live ? bqn : total_groups / M - 1) * M + mh;
+  }
   const long gc = live ? g : total_groups - 1;         // dead groups recompute the last one (the shuffles need every lane)
   const int sub = threadIdx.x & 7;
   const int m = (int)(gc % M);
@@ -315,11 +352,16 @@ static int launch_msda(const void* value, const int64_t* shapes, const int64_t* 
   if (groups == 0) return HIPIE_OK;
   const long vrow = g_value_row > 0 ? g_value_row : (long)M * D;
   if (D == 32) {
-    const long blocks = (groups + 31) / 32;
+    // group -> workgroup map (see the kernel): tiles of the pyramid when the queries are its pixels, else runs of 32 queries of
+    // one head; HIPIE_MSDA_MAP=0 restores the heads-fastest order (A/B timing: tools/bench_msda.py)
+    const char* me = getenv("HIPIE_MSDA_MAP");
+    const int map_env = me ? atoi(me) : -1;
+    const int map = map_env >= 0 ? (map_env == 2 && Lq != S ? 1 : map_env) : (Lq == S ? 2 : 1);
+    const long blocks = map == 0 ? (groups + 31) / 32 : (((long)B * Lq + 31) / 32) * M;
     const size_t lds = (size_t)32 * (L * P * 8 + 4) * sizeof(float);
     // unroll 2 of the record loop: 0.467 ms vs 0.480 (1, 4, 8) on the bs-8 encoder geometry (tools/bench_msda.py)
     hipLaunchKernelGGL((msda_d32_kernel<T, A, FUSED, 2>), dim3((unsigned)blocks), dim3(256), lds, st, (const T*)value, shapes,
-                       lstart, (const A*)a, (const A*)w, ref, (T*)out, S, M, L, Lq, P, ref_dim, groups, off_stride, w_stride, vrow);
+                       lstart, (const A*)a, (const A*)w, ref, (T*)out, S, M, L, Lq, P, ref_dim, groups, off_stride, w_stride, vrow, map);
   } else {
     const long n = groups * D;
     const long blocks = (n + 255) / 256;

@@ -33,7 +33,8 @@ class NormConv2d(PConv2d):
 
 
 class FoldedMaskFeatures(object):
-    """the mask_features head without its last 1x1 convolution (weight (256,256), bias (256)): `pre` (B,256,H/4,W/4) NCHW."""
+    """the mask_features head without its last 1x1 convolution (weight (256,256), bias (256)): `pre` (B,256,H/4,W/4) NCHW, fp32 or
+    the 16-bit activation dtype."""
 
     def __init__(self, pre, weight, bias):
         self.pre, self.weight, self.bias = pre, weight, bias
@@ -100,9 +101,8 @@ class MaskDINOEncoder(nn.Module):
         without its bias, which enters the GroupNorm pass as a per-channel pre-bias together with the ReLU (one read + one write
         of the (B,256,H/4,W/4) map instead of the bias, norm and ReLU passes)."""
         ct, gn = self.mask_features[0], self.mask_features[1]
-        z = z.contiguous()              # NCHW in, NCHW out: the map leaves pixel-fastest, the mask contraction's operand layout
-        C = ct.weight.shape[0]
-        if getattr(self.precision, "split", False) and z.is_cuda and ct.weight.dtype == torch.float32 and ops.split_ok(C):
+        C = ct.weight.shape[0]              # any layout in (channels-last from the 3x3 conv + GroupNorm in front), NCHW out: the map leaves
+        if getattr(self.precision, "split", False) and z.is_cuda and ct.weight.dtype == torch.float32 and ops.split_ok(C):   # pixel-fastest
             # split policy: ConvTranspose2d(k = 2, s = 2) is ONE linear per input pixel (C -> 4 C: tap-major columns) + a pixel shuffle;
             # the linear runs on hipie_gemm's split operands (the library's fp32 transposed convolution took 1.26 ms here, this 0.5)
             B, _, H, W = z.shape
@@ -111,7 +111,7 @@ class MaskDINOEncoder(nn.Module):
             y = ops.split_linear(rows.float().contiguous(), ct, "convt", wt, None, weight_fn=lambda: wt.permute(2, 3, 1, 0).reshape(-1, C))
             y = y.view(B, H, W, 2, 2, -1).permute(0, 5, 1, 3, 2, 4).reshape(B, -1, 2 * H, 2 * W)
         else:
-            y = F.conv_transpose2d(z.to(ct.weight.dtype), ct.weight, None, ct.stride, ct.padding, ct.output_padding, ct.groups, ct.dilation)
+            y = F.conv_transpose2d(z.contiguous().to(ct.weight.dtype), ct.weight, None, ct.stride, ct.padding, ct.output_padding, ct.groups, ct.dilation)
         if out_dtype is not None:
             y = y.to(out_dtype)
         return gn(y, relu=True, prebias=ct.bias.float())
@@ -125,11 +125,17 @@ class MaskDINOEncoder(nn.Module):
         y, shapes = self.transformer(srcs, pos)
         B = y.shape[0]
         out, st = [], 0
+        y = y.contiguous()
         for (H, W) in shapes:
-            out.append(y[:, st:st + H * W].transpose(1, 2).reshape(B, -1, H, W))
+            # (B,C,H,W) VIEWS of the token-major encoder memory (channels-last strides): the decoder flattens them straight back to
+            # tokens and the FPN sum below reads them in place -- no (B,256,H,W) transposes through HBM in either direction
+            out.append(y[:, st:st + H * W].transpose(1, 2).unflatten(2, (H, W)))
             st += H * W
         cur = self.adapter_1(f3)
-        z = cur + F.interpolate(out[0], size=cur.shape[-2:], mode="bilinear", align_corners=False)
+        top = out[0]
+        if tuple(top.shape[-2:]) != tuple(cur.shape[-2:]):      # same size (always, for /32-padded inputs): bilinear resampling with
+            top = F.interpolate(top, size=cur.shape[-2:], mode="bilinear", align_corners=False)   # align_corners=False is the identity
+        z = cur + top
         z = self.layer_1(z)
         if self.precision.einsum >= 3:
             # 16-bit policies: stop in front of the head's last 1x1 convolution.  mask logits = emb . (W x + b) = (emb . W) . x +
@@ -138,6 +144,13 @@ class MaskDINOEncoder(nn.Module):
             x = self._mask_features_front(z)
             conv = self.mask_features[3]
             mf = FoldedMaskFeatures(x.to(self.precision.act).contiguous(), conv.weight.reshape(conv.weight.shape[0], -1), conv.bias)
+        elif self.precision.einsum in (1, 2) and z.is_cuda:
+            # fp32 features on the split contraction: the same fold (hipie_mask_einsum_bias adds emb . b per query row), so the
+            # library's 1x1 convolution over the (B,256,H/4,W/4) map (0.76 ms at the headline shape) and its second copy of the
+            # map disappear; x stays fp32, NCHW
+            x = self._mask_features_front(z, torch.float32)
+            conv = self.mask_features[3]
+            mf = FoldedMaskFeatures(x.float().contiguous(), conv.weight.reshape(conv.weight.shape[0], -1), conv.bias)
         else:
             mf = self.mask_features[3](self._mask_features_front(z, torch.float32))
             mf = mf.float().contiguous()  # NCHW fp32, pixel fastest: hipie_mask_einsum's operand layout, produced once for both calls
@@ -187,11 +200,14 @@ class MaskDINODecoder(nn.Module):
         masks = None
         if pred_mask:
             emb = self.mask_embed(dec)
-            if isinstance(mask_features, FoldedMaskFeatures):      # 16-bit features: 3 = single product, 4 = embedding split hi + lo
+            if isinstance(mask_features, FoldedMaskFeatures):      # 16-bit features: 3 = single product, 4 = embedding split hi + lo; fp32: 1 | 2
                 e32 = emb.float()
                 w, b = mask_features.weight.float(), mask_features.bias.float()
                 pre = mask_features.pre
-                if e32.shape[1] <= 320 and (pre.shape[-1] * pre.shape[-2]) % 8 == 0:
+                if pre.dtype == torch.float32:                      # fp32 features: the bf16-split contraction with a row bias
+                    masks = ops.mask_einsum((e32 @ w).contiguous(), pre, precision=self.precision.einsum, out_dtype=self.precision.act,
+                                            row_bias=e32 @ b)
+                elif e32.shape[1] <= 320 and (pre.shape[-1] * pre.shape[-2]) % 8 == 0:
                     masks = ops.mask_einsum16(e32 @ w, pre, split=self.precision.einsum == 4, row_bias=e32 @ b)
                 else:       # more queries than the 16-bit kernel's tile (or an odd pixel count): the fp32-feature kernel, bias added after
                     masks = ops.mask_einsum((e32 @ w).contiguous(), pre.float().contiguous(), precision=1, out_dtype=self.precision.act)

@@ -383,17 +383,37 @@ def bi_xattn(q, k, vv, vl, text_mask, clamp=50000.0, out_f32=False):
     return out_v, out_l
 
 
+_ME_WS = {}
+
+
 @_timed("mask_einsum")
-def mask_einsum(mask_embed, mask_features, precision=1, out_dtype=torch.float32):
+def mask_einsum(mask_embed, mask_features, precision=1, out_dtype=torch.float32, row_bias=None, workspace=True):
     """einsum("bqc,bchw->bqhw"): mask_embed (B,Q,C) f32, mask_features (B,C,H,W) f32 -> (B,Q,H,W) out_dtype.
-    precision 0 = exact fp32 MFMA, 1 = bf16x3 split (default; ~2^-16), 2 = plain bf16."""
+    precision 0 = exact fp32 MFMA, 1 = bf16x3 split (default; ~2^-16), 2 = plain bf16.  Precisions 1 | 2 run hipie_mask_einsum_ws (the
+    embedding split once into a cached scratch buffer and staged by LDS-DMA) and take row_bias (B,Q) f32, added to every pixel of
+    its query row; workspace=False: the workspace-free entry point hipie_mask_einsum (every workgroup splits the embedding)."""
     lib = _lib.load()
     B, Q, C = mask_embed.shape
     _, _, Hh, Ww = mask_features.shape
     out = torch.empty(B, Q, Hh, Ww, dtype=out_dtype, device=mask_embed.device)
-    rc = lib.hipie_mask_einsum(_chk(mask_embed, "mask_embed", torch.float32),
-                               _chk(mask_features, "mask_features", torch.float32), out.data_ptr(),
-                               B, Q, C, Hh * Ww, int(precision), _DT[out_dtype], _stream())
+    e, f = _chk(mask_embed, "mask_embed", torch.float32), _chk(mask_features, "mask_features", torch.float32)
+    if int(precision) == 0 or not workspace:
+        if row_bias is not None:
+            raise RuntimeError("mask_einsum: row_bias needs precision 1 | 2 and the workspace form")
+        rc = lib.hipie_mask_einsum(e, f, out.data_ptr(), B, Q, C, Hh * Ww, int(precision), _DT[out_dtype], _stream())
+    else:
+        rb = None
+        if row_bias is not None:
+            rbt = row_bias.float().contiguous()
+            if tuple(rbt.shape) != (B, Q):
+                raise ValueError("mask_einsum: row_bias must be (B, Q) = (%d, %d), got %s" % (B, Q, tuple(rbt.shape)))
+            rb = _chk(rbt, "row_bias", torch.float32)
+        need = int(lib.hipie_mask_einsum_workspace(B, Q, C))
+        key = str(mask_embed.device)
+        ws = _ME_WS.get(key)
+        if ws is None or ws.numel() < need:
+            ws = _ME_WS[key] = torch.empty(need, dtype=torch.uint8, device=mask_embed.device)
+        rc = lib.hipie_mask_einsum_ws(e, f, rb, out.data_ptr(), ws.data_ptr(), need, B, Q, C, Hh * Ww, int(precision), _DT[out_dtype], _stream())
     _lib.check(rc, "hipie_mask_einsum")
     return out
 

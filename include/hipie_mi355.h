@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPIE_ABI_VERSION 9
+#define HIPIE_ABI_VERSION 10
 
 /* element types of activations */
 #define HIPIE_F32 0
@@ -173,10 +173,24 @@ int hipie_bi_xattn_ws(const void* q, const void* k, const void* vv, const void* 
  *           (models/maskdino/transformer_decoder/maskdino_decoder.py:520-529).
  *   embed (B,Q,C) f32, feats (B,C,HW) f32, out (B,Q,HW) `out_dtype` (f32 | f16 | bf16).
  *   precision 0: exact fp32 (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain); 1: bf16x3 split (3 bf16 MFMAs per
- *   product, ~2^-16 relative); 2: single bf16 MFMA.   C % 32 == 0.
+ *   product, ~2^-16 relative); 2: single bf16 MFMA.   C % 16 == 0.
  */
 int hipie_mask_einsum(const float* embed, const float* feats, void* out, int B, int Q, int C, int HW,
                       int precision, int out_dtype, void* stream);
+
+/*
+ * The same contraction with a caller-provided workspace, plus a per-row constant:
+ *   out[b,q,p] = row_bias[b,q] + sum_c embed[b,q,c] * feats[b,c,p],   row_bias (B,Q) f32 or NULL, precision 1 or 2.
+ * The embedding is split ONCE per call into the workspace (bf16 hi + lo parts in the layout of the kernel's LDS tile) and staged
+ * by LDS-DMA, instead of being split by every workgroup (hipie_mask_einsum): the faster form.  hipie_mask_einsum_workspace
+ * returns the bytes needed; the workspace is scratch (nothing is kept between calls), 16-byte aligned.
+ * With embed' = embed . W and row_bias = embed . b the last 1x1 convolution of the pixel decoder's mask_features head
+ * (Conv2d(256,256,1), maskdino_encoder.py:283-300) folds into the contraction of maskdino_decoder.py:527: the (B,256,H/4,W/4)
+ * map is neither convolved nor written a second time.
+ */
+int64_t hipie_mask_einsum_workspace(int B, int Q, int C);
+int hipie_mask_einsum_ws(const float* embed, const float* feats, const float* row_bias, void* out, void* workspace,
+                         int64_t workspace_bytes, int B, int Q, int C, int HW, int precision, int out_dtype, void* stream);
 
 /*
  * The same contraction on 16-bit features (the activation dtype of the 16-bit policies): out[b,q,p] = sum_c embed[b,q,c] *

@@ -121,7 +121,7 @@ def test_msda_generic_head_dim():
 
 
 @pytest.mark.parametrize("prec,tol", [(0, 2e-6), (1, 3e-5), (2, 1e-2)])
-@pytest.mark.parametrize("shape", [(2, 300, 256, 64, 64), (1, 37, 64, 24, 40), (1, 330, 32, 8, 8)])
+@pytest.mark.parametrize("shape", [(2, 300, 256, 64, 64), (1, 37, 64, 24, 40), (1, 330, 32, 8, 8), (1, 5, 16, 3, 50), (2, 300, 80, 20, 13)])
 def test_mask_einsum(prec, tol, shape):
     from hipie_amd import ops
     B, Q, C, H, W = shape
@@ -134,6 +134,15 @@ def test_mask_einsum(prec, tol, shape):
     if prec == 1:
         got16 = ops.mask_einsum(e.to(DEV), f.to(DEV), precision=1, out_dtype=torch.bfloat16).float().cpu()
         assert rel_err(got16, want) < 8e-3
+    if prec in (1, 2):          # the workspace-free entry point; then a constant per query row (the folded 1x1 convolution's emb . b)
+        plain = ops.mask_einsum(e.to(DEV), f.to(DEV), precision=prec, workspace=False).cpu()
+        assert rel_err(plain, want) < tol
+        rb = torch.randn(B, Q, generator=gen) * 3
+        gotb = ops.mask_einsum(e.to(DEV), f.to(DEV), precision=prec, row_bias=rb.to(DEV)).cpu()
+        assert rel_err(gotb, want + rb[:, :, None, None]) < tol
+    else:
+        with pytest.raises(RuntimeError):
+            ops.mask_einsum(e.to(DEV), f.to(DEV), precision=0, row_bias=torch.zeros(B, Q, device=DEV))
 
 
 @pytest.mark.parametrize("dt,split,tol", [(torch.float16, True, 6e-4), (torch.float16, False, 1e-3), (torch.bfloat16, True, 4e-3)])

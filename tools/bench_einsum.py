@@ -28,11 +28,11 @@ def main():
     B, Q, C, H = 8, 300, 256, 256
     emb = torch.randn(B, Q, C, generator=g).to(dev)
     feat = torch.randn(B, C, H, H, generator=g).to(dev)
-    for prec, od in ((1, torch.float32), (1, torch.bfloat16), (2, torch.bfloat16)):
-        t = bench(lambda: ops.mask_einsum(emb, feat, precision=prec, out_dtype=od))
+    for prec, od, wsp in ((1, torch.float32, True), (1, torch.float32, False), (1, torch.bfloat16, True), (2, torch.bfloat16, True)):
+        t = bench(lambda: ops.mask_einsum(emb, feat, precision=prec, out_dtype=od, workspace=wsp))
         by = feat.numel() * 4 + emb.numel() * 4 + B * Q * H * H * (4 if od == torch.float32 else 2)
-        print("mask_einsum precision %d out %s: %.3f ms  %.2f TB/s algorithmic  %.0f TFLOP/s" % (
-            prec, str(od).split(".")[-1], t, by / t / 1e9, 2.0 * B * Q * C * H * H / t / 1e9))
+        print("mask_einsum precision %d out %s %s: %.3f ms  %.2f TB/s algorithmic  %.0f TFLOP/s" % (
+            prec, str(od).split(".")[-1], "workspace (LDS-DMA)" if wsp else "no workspace", t, by / t / 1e9, 2.0 * B * Q * C * H * H / t / 1e9))
     for dt in (torch.float16, torch.bfloat16):
         f16 = feat.to(dt)
         for split in (True, False):

@@ -40,6 +40,17 @@ def main():
     alg = B * (S * M * D * 2 * 2 + S * M * L * P * 3 * 2 + S * L * 2 * 4)         # value in + out, offsets + logits, refs
     t = bench(lambda: ops.msda_fused(value, ss, ls, ref, off, lg))
     print("msda_fused: %.3f ms  %.2f TB/s algorithmic" % (t, alg / t / 1e9))
+    # the split3 policy's call: fp32 value / offsets / logits, every group -> workgroup map of the kernel (HIPIE_MSDA_MAP)
+    v32, o32, l32 = value.float(), off.float().contiguous(), lg.float().contiguous()
+    alg32 = B * (S * M * D * 4 * 2 + S * M * L * P * 3 * 4 + S * L * 2 * 4)
+    outs = {}
+    for mp in ("0", "1", "2"):
+        os.environ["HIPIE_MSDA_MAP"] = mp
+        t = bench(lambda: ops.msda_fused(v32, ss, ls, ref, o32, l32))
+        outs[mp] = ops.msda_fused(v32, ss, ls, ref, o32, l32)
+        print("msda_fused f32 map %s: %.3f ms  %.2f TB/s algorithmic  (sigma %s)" % (mp, t, alg32 / t / 1e9, os.environ.get("SIGMA", "1.5")))
+    os.environ.pop("HIPIE_MSDA_MAP")
+    print("maps bit-identical:", torch.equal(outs["0"], outs["1"]) and torch.equal(outs["0"], outs["2"]))
 
 
 def backward():
