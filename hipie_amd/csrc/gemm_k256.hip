@@ -5,14 +5,21 @@
 // Why a second kernel: with K = 256 the 256 x 256 tile of gemm_kernel is eight k-steps between a 256 KB load and a 256 KB store, one
 // workgroup per CU, and the three phases of a round do not overlap (0.109 ms per N = 256 launch where the k loop alone is ~0.05 and the
 // HBM time 0.065).  Here the structure of ffn_fused.hip's first product: a wave keeps the X fragments of its 32 tokens in registers for
-// its whole life (K = 256 as fp16 pairs: 128 registers, read from HBM exactly once, straight into MFMA B operands -- no LDS, no barrier on
-// that side), and walks the N / 32 chunks of 32 output features:  y^T = W[chunk] . X^T  = 16 k-steps x 3 products into two interleaved
-// accumulators.  The weight chunk tiles (32 rows x 1 KB) go L2 -> LDS by LDS-DMA, double buffered, one barrier per chunk, the DMA
-// instructions riding in the k-steps; the 16-byte units of a row are stored at c ^ (row & 15): conflict-free ds_read_b128.  The C tile is
-// (feature rows x token columns): a lane owns 16 features of ITS token and writes them as four 16-byte pieces of its output row; the
-// stores of chunk c are issued behind the barrier of chunk c + 1, so the wait for the DMA (vmcnt counts stores too) does not wait for
-// stores that have just been issued.  4 waves = 128 tokens per workgroup, two workgroups per CU: one loads X while the other multiplies.
+// its whole life (K = 256 as fp16 pairs: 128 registers, read from HBM exactly once -- no barrier on that side), and walks the N / 32
+// chunks of 32 output features:  y^T = W[chunk] . X^T  = 16 k-steps x 3 products into two interleaved accumulators.  The weight chunk
+// tiles (32 rows x 1 KB) go L2 -> LDS by LDS-DMA, double buffered, one barrier per chunk, the DMA instructions riding in the k-steps;
+// the 16-byte units of a row are stored at c ^ (row & 15): conflict-free ds_read_b128.  The C tile is (feature rows x token columns): a
+// lane owns 16 features of ITS token and writes them as four 16-byte pieces of its output row; the stores of chunk c are issued behind
+// the barrier of chunk c + 1, so the wait for the DMA (vmcnt counts stores too) does not wait for stores that have just been issued.
+// 4 waves = 128 tokens per workgroup, two workgroups per CU: one loads X while the other multiplies.
 // X rows may be HL8 (as add_layernorm_dec writes them) or plain fp32 (the residual stream itself: split here, once per wave).
+//
+// How X gets into the registers (second version).  "lane = token" means a lane needs its WHOLE 1 KB row: read straight from global that is
+// sixty-four 16-byte pieces per lane, 1 KB apart across lanes -- 32 cache lines per load instruction and a 32 KB L1 working set per
+// wave; the first version did that and was no faster than the tile kernel (tools/bench_gemm_k256.py: 0.128 against 0.123 ms at N = 256).
+// Now every wave brings ITS 32 rows in by LDS-DMA, two half rows (2 x 512 B, contiguous per instruction) at a time into a private 16 KB
+// slice of the weight buffers, and reads the fragments back with conflict-free ds_read_b128 (units swizzled by row & 15 on the DMA's
+// source side) -- coalesced 512-byte requests, no block barrier (a wave reads only what it fetched itself), twice for the two K halves.
 #include <stdlib.h>
 
 #include "common.h"
@@ -63,33 +70,55 @@ __global__ __launch_bounds__(256, 2) void gemm_k256_kernel(const TKParams p) {
     const int i = wave + 4 * q;
     tk_dma16(p.W + (long)c * TK_C * p.ldw_b, dv[q], __builtin_amdgcn_readfirstlane(lds0 + (unsigned int)(buf * TK_TILE + 1024 * i)));
   };
-#pragma unroll
-  for (int q = 0; q < 8; ++q) dma_chunk(0, 0, q);
 
   // ---- X fragments (B operand): lane (token li, half hi) holds k group 2 ks + hi of its row, both halves.  HL8 rows: 16 bytes of
-  //      hi parts + 16 bytes of lo parts per group of 8; fp32 rows: the same 32 bytes are the 8 values themselves ----
+  //      hi parts + 16 bytes of lo parts per group of 8; fp32 rows: the same 32 bytes are the 8 values themselves.
+  //      Per K half: DMA instruction j (0 .. 15) of this wave moves the half rows 2 j, 2 j + 1 of its 32 tokens (lane l: half row
+  //      l >> 5, LDS unit l & 31 <- logical unit (l & 31) ^ (row & 15)) into its 16 KB slice; then 8 k-steps x 2 fragment reads ----
   frag xh[KS], xl[KS];
   {
-    const char* xr = p.X + (long)mc * p.ldx_b + 32 * hi;
+    const int m0w = blockIdx.x * 128 + wave * 32;
+    const unsigned int xslice = lds0 + (unsigned int)(wave * 16384);
+    const char* xs = smem + wave * 16384 + li * 512;
+    unsigned int xv[16];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (XF32) {
-        const float4 a = *reinterpret_cast<const float4*>(xr + 64 * ks);
-        const float4 b = *reinterpret_cast<const float4*>(xr + 64 * ks + 16);
-        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    for (int j = 0; j < 16; ++j) {
+      const int r = 2 * j + (lane >> 5);
+      xv[j] = (unsigned int)((long)min(m0w + r, p.M - 1) * p.ldx_b + 16 * ((lane & 31) ^ (r & 15)));
+    }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          T h, l;
-          hl_split(v[j], h, l);
-          xh[ks][j] = h;
-          xl[ks][j] = l;
+    for (int half = 0; half < 2; ++half) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0): the fragment reads of the first half are done before it is overwritten
+#pragma unroll
+      for (int j = 0; j < 16; ++j) tk_dma16(p.X + 512 * half, xv[j], __builtin_amdgcn_readfirstlane(xslice + 1024 * j));
+      __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): landed (only this wave reads this slice)
+#pragma unroll
+      for (int ksl = 0; ksl < KS / 2; ++ksl) {
+        const int ks = half * (KS / 2) + ksl;
+        const int u = 2 * (2 * ksl + hi);
+        const frag a = *reinterpret_cast<const frag*>(xs + 16 * (u ^ (li & 15)));
+        const frag b = *reinterpret_cast<const frag*>(xs + 16 * ((u + 1) ^ (li & 15)));
+        if (XF32) {
+          const f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+          const float v[8] = {fa[0], fa[1], fa[2], fa[3], fb[0], fb[1], fb[2], fb[3]};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            T h, l;
+            hl_split(v[e], h, l);
+            xh[ks][e] = h;
+            xl[ks][e] = l;
+          }
+        } else {
+          xh[ks] = a;
+          xl[ks] = b;
         }
-      } else {
-        xh[ks] = *reinterpret_cast<const frag*>(xr + 64 * ks);
-        xl[ks] = *reinterpret_cast<const frag*>(xr + 64 * ks + 16);
       }
     }
+    __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
+    __syncthreads();                              // every wave has its fragments: the slices become the weight buffers
   }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) dma_chunk(0, 0, q);
 
   const int wrow = li * 1024, wsw = li & 15;                   // tile row li, unit u at byte 16 * (u ^ wsw)
   float* orow = p.out + (long)mc * p.ldo + 4 * hi;
