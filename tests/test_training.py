@@ -1,0 +1,221 @@
+"""Training-side host logic (matching costs + assignment, the set-prediction losses of both heads, contrastive de-noising
+queries) against the reference's OWN classes, run on the CPU of the build container by tests/golden/gen_train_golden.py
+(HungarianMatcherVL, MaskDINO's HungarianMatcher, SetCriterion / DINOCriterion, MaskDINO's SetCriterion, prepare_for_cdn).  The fixtures
+hold the inputs, every random tensor the reference drew (replayed here in the same order) and its outputs.  Device-agnostic: the same
+checks run on the GPU under -m gpu."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hipie_amd.training import (DetCriterion, HungarianMatcher, MaskCriterion, MatchWeights, cdn_queries, dn_match_indices, dn_split_outputs,
+                                generalized_box_iou, paired_giou_loss, paired_iou, box_cxcywh_to_xyxy)
+from hipie_amd.training.criterion import uncertain_points
+from hipie_amd.training.matcher import class_cost, mask_costs
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEVICES = [pytest.param("cpu", id="cpu"), pytest.param("cuda", id="cuda", marks=pytest.mark.gpu)]
+
+
+class Fixture:
+    def __init__(self, name, device):
+        self.z = np.load(os.path.join(GOLD, name + ".npz"))
+        self.dev = device
+
+    def __getitem__(self, k):
+        return torch.from_numpy(self.z[k]).to(self.dev)
+
+    def __contains__(self, k):
+        return k in self.z.files
+
+    def targets(self, prefix, n):
+        keys = ("labels", "boxes", "positive_map", "is_thing", "masks")
+        return [{k: self["%s%d_%s" % (prefix, i, k)] for k in keys if "%s%d_%s" % (prefix, i, k) in self} for i in range(n)]
+
+    def pairs(self, prefix, n):
+        return [(self["%s%d_q" % (prefix, i)].cpu(), self["%s%d_t" % (prefix, i)].cpu()) for i in range(n)]
+
+    def rands(self, prefix="rand"):
+        out, i = [], 0
+        while "%s%d" % (prefix, i) in self:
+            out.append(self["%s%d" % (prefix, i)])
+            i += 1
+        return out
+
+
+class Replay:
+    """a `draw` that hands out the reference's recorded random tensors in call order and insists on the shapes"""
+
+    def __init__(self, tensors):
+        self.t, self.i = list(tensors), 0
+
+    def __call__(self, shape, device):
+        r = self.t[self.i]
+        self.i += 1
+        assert tuple(r.shape) == tuple(shape), "draw %d: reference drew %s, the build asks for %s" % (self.i - 1, tuple(r.shape), tuple(shape))
+        return r.to(device)
+
+    def done(self):
+        return self.i == len(self.t)
+
+
+def same_pairs(got, want):
+    return len(got) == len(want) and all(torch.equal(g[0].cpu(), w[0]) and torch.equal(g[1].cpu(), w[1]) for g, w in zip(got, want))
+
+
+def close(a, b, tol=2e-5):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+def test_matchers_give_the_reference_assignments(dev):
+    f = Fixture("train_matcher", dev)
+    targets = f.targets("t", 3)
+    w = MatchWeights(*[float(x) for x in f.z["weights"]])
+    draw = Replay(f.rands())
+    m = HungarianMatcher(w, num_points=112 * 112, stuff_takes_mean=True, draw=draw, class_mode="map")
+    assert same_pairs(m(f["logits"], f["boxes"], targets), f.pairs("box", 3))                       # box + class costs; image 2 holds stuff only
+    assert same_pairs(m(f["logits"], f["boxes"], targets, masks=f["pmasks"]), f.pairs("mask", 3))    # + point-sampled mask costs
+    assert draw.done()
+    ones = [dict(t, positive_map=torch.ones(len(t["boxes"]), 1, dtype=torch.bool, device=dev)) for t in targets]
+    assert same_pairs(m.forward_boxes_only(f["logits"][..., :1], f["boxes"], ones), f.pairs("enc", 3))
+    # the cost terms themselves
+    assert close(class_cost(f["logits"][0].sigmoid(), targets[0], "map"), f["cls0"], 1e-6)
+    ce, dice = mask_costs(f["pmasks"][0], targets[0]["masks"], f["rand0"][0])
+    assert close(ce, f["ce0"], 1e-5) and close(dice, f["dice0"], 1e-5)
+    assert close(generalized_box_iou(box_cxcywh_to_xyxy(f["boxes"][0]), box_cxcywh_to_xyxy(targets[0]["boxes"])), f["giou0"], 1e-6)
+    # MaskDINO's matcher: class ids, then positive maps
+    draw = Replay(f.rands("md_rand"))
+    wm = MatchWeights(*[float(x) for x in f.z["md_weights"]])
+    md = HungarianMatcher(wm, num_points=300, stuff_takes_mean=True, draw=draw, class_mode="ids")
+    assert same_pairs(md(f["md_logits"], f["boxes"], targets, masks=f["md_masks"]), f.pairs("md", 3))
+    md.class_mode = "map"
+    assert same_pairs(md(f["logits"], f["boxes"], targets, masks=f["md_masks"]), f.pairs("mdvl", 3))
+    assert draw.done()
+    with pytest.raises(ValueError):
+        HungarianMatcher(MatchWeights(0, 0, 0, 0, 1))
+    with pytest.raises(ValueError):
+        generalized_box_iou(torch.tensor([[0.5, 0.5, 0.4, 0.6]]), torch.tensor([[0.1, 0.1, 0.2, 0.2]]))
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+@pytest.mark.parametrize("tag", ["dyn", "ids", "one"])
+def test_cdn_queries_match_prepare_for_cdn(dev, tag):
+    f = Fixture("train_dn", dev)
+    n_img = {"dyn": 3, "ids": 2, "one": 1}[tag]
+    targets = f.targets(tag + "_t", n_img)
+    dn_number, ratio, scale, nq, ncls = [float(x) for x in f.z[tag + "_args"]]
+    r = f.rands(tag + "_rand")
+    emb = f[tag + "_emb"]
+    if tag == "ids":                                        # class-id embeddings with label noise: p, new labels, then the box noise
+        noise = {"p": r[0], "new_label": r[1], "sign": r[2] * 2 - 1, "part": r[3]}
+        label_embed = lambda ids: emb[ids]                  # noqa: E731
+    else:
+        noise = {"sign": r[0] * 2 - 1, "part": r[1]}
+        label_embed = emb
+    ql, qb, mask, meta = cdn_queries(targets, int(dn_number), scale, int(nq), label_embed, noise, ratio, int(ncls))
+    assert [meta["single_padding"], meta["dn_num"], meta["dp_num"]] == [int(x) for x in f.z[tag + "_meta"]]
+    assert torch.equal(mask.cpu(), f[tag + "_mask"].cpu())
+    assert close(ql, f[tag + "_label"], 1e-7) and close(qb, f[tag + "_box"], 1e-6)
+    assert same_pairs(dn_match_indices(targets, meta), f.pairs(tag + "_idx", n_img))
+    # the de-noising / matching split of the decoder outputs
+    pad = meta["single_padding"] * meta["dn_num"]
+    x = torch.arange(2 * n_img * (pad + int(nq)) * 3, device=dev).reshape(2, n_img, pad + int(nq), 3)
+    known, match = dn_split_outputs(x, meta)
+    assert known.shape[2] == pad and match.shape[2] == int(nq) and torch.equal(torch.cat((known, match), 2), x)
+    assert dn_split_outputs(x, None)[0] is None
+
+
+def test_cdn_queries_without_targets_or_groups():
+    empty = [{"labels": torch.zeros(0, dtype=torch.long), "boxes": torch.zeros(0, 4)}]
+    assert cdn_queries(empty, 10, 0.4, 5, torch.zeros(1, 4)) == (None, None, None, None)
+    one = [{"labels": torch.zeros(2, dtype=torch.long), "boxes": torch.tensor([[0.5, 0.5, 0.2, 0.2], [0.3, 0.3, 0.1, 0.1]])}]
+    assert cdn_queries(one, 0, 0.4, 5, torch.zeros(1, 4))[0] is None
+    ql, qb, mask, meta = cdn_queries(one, 1, 0.4, 5, torch.ones(1, 4))       # fewer requested queries than targets: still one group
+    assert meta == {"single_padding": 4, "dn_num": 1, "dp_num": 0} and ql.shape == (1, 4, 4) and mask.shape == (9, 9)
+    assert bool(mask[4:, :4].all()) and not bool(mask[:4, :4].any()) and not bool(mask[:, 4:].any())
+    b = torch.sigmoid(qb[0])                                                  # positives stay within half a box of their target, negatives leave it
+    assert float((b[:2, :2] - one[0]["boxes"][:, :2]).abs().max()) <= 0.4 * 0.1 + 1e-6
+
+
+def _det_outputs(f, layers):
+    outs = []
+    for i in range(layers):
+        outs.append({"pred_logits": f["l%d_logits" % i], "pred_boxes": f["l%d_boxes" % i], "pred_boxious": f["l%d_boxious" % i], "text_masks": f["text_masks"],
+                     "pred_masks": [f["l%d_pred_masks%d" % (i, b)] for b in range(2)]})
+    return outs
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+def test_detection_criterion_matches_dino_criterion(dev):
+    f = Fixture("train_criterion", dev)
+    SP, G, layers = [int(x) for x in f.z["meta"]]
+    targets = f.targets("t", 2)
+    outs = _det_outputs(f, layers)
+    indices = [f.pairs("l%d_idx" % i, 2) for i in range(layers)]
+    indices = [[(a.to(dev), b.to(dev)) for a, b in layer] for layer in indices]
+    outputs = dict(outs[-1])
+    outputs["aux_outputs"] = outs[:-1]
+    outputs["enc_outputs"] = {"pred_logits": f["enc_logits"], "pred_boxes": f["enc_boxes"], "text_masks": f["text_masks"]}
+    known = {"pred_logits": f["known_logits"], "pred_boxes": f["known_boxes"], "text_masks": f["text_masks"],
+             "aux_outputs": [{"pred_logits": f["known_aux%d_logits" % i], "pred_boxes": f["known_aux%d_boxes" % i], "text_masks": f["text_masks"]}
+                             for i in range(layers - 1)]}
+    dn_meta = {"single_padding": SP, "dn_num": G, "dp_num": 0, "output_known_lbs_bboxes": known}
+    draw = Replay(f.rands())
+    matcher = HungarianMatcher(MatchWeights(2.0, 5.0, 2.0, 5.0, 5.0), class_mode="map")
+    crit = DetCriterion(matcher, ["labelsVL", "boxes", "masks"], still_cls_for_encoder=True, num_points=500, draw=draw)
+    got = crit(outputs, targets, indices, dn_meta)
+    want = {k[5:]: float(f.z[k]) for k in f.z.files if k.startswith("loss_")}
+    assert set(got) == set(want), (sorted(set(got) ^ set(want)))
+    bad = {k: (float(got[k]), want[k]) for k in want if abs(float(got[k]) - want[k]) > 2e-5 * max(1.0, abs(want[k]))}
+    assert not bad, bad
+    assert draw.done()
+    assert len(want) == 6 * layers + 3 + 3 * layers       # per layer ce / bbox / giou / boxiou / mask / dice; encoder and de-noising (no IoU head): 3 each
+    # full-resolution (not point-sampled) mask losses, the zero entries without de-noising queries, the third-party box formulas
+    dense = DetCriterion(matcher, ["masks"], point_sample_masks=False).loss_masks(outs[-1], targets, indices[-1], 7.0)
+    assert abs(float(dense["loss_mask"]) - float(f.z["dense_loss_mask"])) < 1e-5 and abs(float(dense["loss_dice"]) - float(f.z["dense_loss_dice"])) < 1e-5
+    nodn = crit.dn_losses(None, targets, layers - 1, 7.0, dev)
+    assert set(nodn) == {k[5:] for k in f.z.files if k.startswith("nodn_")} and all(float(v) == 0 for v in nodn.values())
+    assert close(paired_giou_loss(f["giou_a"], f["giou_b"]), 1 - f["giou_pairwise_diag"], 1e-6)
+    assert close(paired_iou(f["giou_a"], f["giou_b"]), f["iou_diag"], 1e-6)
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+def test_maskdino_criterion_matches_the_reference(dev):
+    f = Fixture("train_maskdino", dev)
+    groups, single, NC = [int(x) for x in f.z["meta"]]
+    targets = f.targets("t", 2)
+
+    def out(prefix):
+        return {k: f[prefix + k] for k in ("pred_logits", "pred_boxes", "pred_masks")}
+    outputs = out("main_")
+    outputs["aux_outputs"] = [out("aux0_"), out("aux1_")]
+    outputs["interm_outputs"] = out("interm_")
+    known = out("known_")
+    known["aux_outputs"] = [out("known_aux0_"), out("known_aux1_")]
+    mask_dict = {"output_known_lbs_bboxes": known, "scalar": groups, "pad_size": groups * single}
+
+    def build(draw):
+        matcher = HungarianMatcher(MatchWeights(4.0, 5.0, 2.0, 5.0, 5.0), num_points=200, stuff_takes_mean=True, draw=draw, class_mode="ids")
+        return MaskCriterion(NC, matcher, ["labels", "masks", "boxes"], vl_loss=False, num_points=200, dn="seg", dn_losses=["labels", "masks", "boxes"],
+                             panoptic_on=True, draw=draw)
+    for prefix, rprefix, outs, md in (("loss_", "rand", outputs, mask_dict), ("nodn_", "nodn_rand", {k: v for k, v in outputs.items() if k != "interm_outputs"}, None)):
+        draw = Replay(f.rands(rprefix))
+        got = build(draw)(outs, targets, md)
+        want = {k[len(prefix):]: float(f.z[k]) for k in f.z.files if k.startswith(prefix) and not k.startswith("nodn_rand")}
+        assert set(got) == set(want), sorted(set(got) ^ set(want))
+        bad = {k: (float(got[k]), want[k]) for k in want if abs(float(got[k]) - want[k]) > 2e-5 * max(1.0, abs(want[k]))}
+        assert not bad, bad
+        assert draw.done()
+    with pytest.raises(ValueError):
+        build(Replay(f.rands()))(outputs, targets, dict(mask_dict, pad_size=5))
+
+
+def test_uncertain_points_prefer_the_decision_boundary():
+    g = torch.Generator().manual_seed(0)
+    logits = torch.linspace(-8, 8, 64).repeat(64, 1)[None, None]            # the boundary (logit 0) is the vertical centre line
+    pts = uncertain_points(logits, 200, 3.0, 0.75, lambda shape, device: torch.rand(shape, generator=g))
+    assert pts.shape == (1, 200, 2)
+    assert float((pts[0, :150, 0] - 0.5).abs().mean()) < 0.1 < float((pts[0, 150:, 0] - 0.5).abs().mean())
