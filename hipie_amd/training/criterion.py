@@ -7,7 +7,8 @@
                      positive-map focal loss, sigmoid-CE + dice on importance-sampled points, de-noising and intermediate outputs).
 
 What is NOT restated: the BoxInst projection / pairwise-colour terms (`loss_masks_boxinst`, :526-596, behind MODEL.BOXINST.ENABLED, off
-in every shipped config), the tracking `loss_reid` (:598-634, video models: SURVEY section 8 "out") and the OTA dynamic-k matching.
+in every shipped config) and the tracking `loss_reid` (:598-634, video models: SURVEY section 8 "out").  With OTA matching (matcher.forward_ota)
+the reference normalises by the number of matched pairs instead of targets (`num_boxes = len(idx[0]) if self.ota`): pass ota=True.
 The cross-rank mean of the target count (`all_reduce(num_boxes) / world_size`) is applied when torch.distributed is initialised, as
 in the reference.  Random point coordinates come from ``draw(shape, device)`` (default torch.rand), in the reference's order."""
 import copy
@@ -114,8 +115,9 @@ class DetCriterion(nn.Module):
     passed as `indices_per_layer` (last entry = last layer)."""
 
     def __init__(self, matcher, losses, focal_alpha=0.25, mask_out_stride=4, point_sample_masks=True, panoptic_box_loss=True,
-                 still_cls_for_encoder=False, num_points=112 * 112, oversample_ratio=3.0, importance_sample_ratio=0.75, draw=None):
+                 still_cls_for_encoder=False, num_points=112 * 112, oversample_ratio=3.0, importance_sample_ratio=0.75, draw=None, ota=False):
         super().__init__()
+        self.ota = ota                                     # one-to-many assignments: every loss is per MATCHED PAIR (deformable_detr.py:362, 430, 481)
         self.matcher, self.losses = matcher, tuple(losses)
         self.focal_alpha, self.mask_out_stride = focal_alpha, mask_out_stride
         self.point_sample_masks, self.panoptic_box_loss = point_sample_masks, panoptic_box_loss
@@ -127,6 +129,8 @@ class DetCriterion(nn.Module):
     def loss_labels(self, out, targets, indices, count):
         """deformable_detr.py:353-381"""
         logits = out["pred_logits"]
+        if self.ota:
+            count = sum(len(p[0]) for p in indices)
         if count == 0:
             return {"loss_ce": logits.sum() * 0.0}
         onehot = _positive_onehot(logits, targets, indices)
@@ -143,6 +147,8 @@ class DetCriterion(nn.Module):
         if len(tgt) == 0 or thing.sum() == 0:
             return {"loss_bbox": src.sum() * 0.0, "loss_giou": src.sum() * 0.0}
         reweight = thing.shape[0] / (thing.sum() + 1e-6)
+        if self.ota:
+            count = src.shape[0]
         sx, tx = box_cxcywh_to_xyxy(src), box_cxcywh_to_xyxy(tgt)
         res = {"loss_bbox": (F.l1_loss(src, tgt, reduction="none") * thing * reweight).sum() / count,
                "loss_giou": (paired_giou_loss(sx, tx) * thing[:, 0] * reweight).sum() / count}
@@ -175,6 +181,8 @@ class DetCriterion(nn.Module):
         frames = src.shape[1]
         tm = self.target_masks(targets, src)
         tm = tm.reshape(len(targets), -1, frames, tm.shape[-2], tm.shape[-1])[_perm(indices, 1)]
+        if self.ota:
+            count = src.shape[0]
         if len(tm) == 0:
             return {"loss_mask": src.sum() * 0.0, "loss_dice": src.sum() * 0.0}
         if self.point_sample_masks:

@@ -3,7 +3,7 @@
 * the detection branch's ``HungarianMatcherVL`` (hipie/models/deformable_detr/matcher.py:317-729): token-level focal class cost against
   the target's positive map, L1 + GIoU box costs, optionally the point-sampled mask costs, "stuff" targets (no box) take the mean box
   cost of the "thing" targets; a second entry point (``force_box_loss``, :624-729) used for the encoder proposals: class + box costs
-  only, no stuff handling;
+  only, no stuff handling; and the one-to-many SimOTA matching the shipped configs train with (``forward_ota``, :347-509);
 * MaskDINO's ``HungarianMatcher`` (hipie/models/maskdino/matcher.py:76-259): the same costs with class ids or positive maps.
 
 One cost routine serves all of them.  The cost matrix is built on the tensors' device (one image at a time, like the reference); the
@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .boxes import box_cxcywh_to_xyxy, generalized_box_iou
+from .boxes import _pairwise_inter_union, box_cxcywh_to_xyxy, generalized_box_iou
 
 
 @dataclass
@@ -94,6 +94,56 @@ def assign(C):
     return torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)
 
 
+def ota_cost(prob, boxes, target, center_radius=2.5, stride=32):
+    """SimOTA cost of one image for a DETR-style query set (matcher.py:374-403, 405-446): class cost + 3 x (-GIoU), +100 where the query
+    centre is not BOTH inside the target box and within `center_radius / stride` (normalised units) of its centre, +10000 on queries
+    that are candidates of no target at all -> (cost (Q, T), pairwise IoU (Q, T))."""
+    tb = target["boxes"]
+    txy = box_cxcywh_to_xyxy(tb)
+    qxy = box_cxcywh_to_xyxy(boxes)
+    cx, cy = boxes[:, 0:1], boxes[:, 1:2]
+    inside = (cx > txy[None, :, 0]) & (cx < txy[None, :, 2]) & (cy > txy[None, :, 1]) & (cy < txy[None, :, 3])
+    r = center_radius / stride
+    near = (cx > tb[None, :, 0] - r) & (cx < tb[None, :, 0] + r) & (cy > tb[None, :, 1] - r) & (cy < tb[None, :, 1] + r)
+    candidate = inside.any(1) | near.any(1)
+    inter, union = _pairwise_inter_union(qxy, txy)
+    cost = class_cost(prob, target, "map") - 3.0 * generalized_box_iou(qxy, txy) + 100.0 * (~(inside & near)).to(prob.dtype)
+    cost[~candidate] += 10000.0
+    return cost, inter / union
+
+
+def dynamic_k_assign(cost, iou):
+    """SimOTA's dynamic-k assignment (matcher.py:448-509): target t takes its k_t cheapest queries, k_t = the (truncated, >= 1) sum of its 10
+    largest IoUs; a query claimed by several targets keeps the cheapest; targets left empty then take their cheapest still-free query.
+    `cost` is modified in place, as in the reference.  The reference evaluates "claimed by several targets" ONCE, before the repair loop, and
+    re-uses that mask inside it -- kept, so that assignments agree case by case.
+    -> ((query idx, target idx of each), the best query of every target)"""
+    Q, T = cost.shape
+    k = torch.clamp(iou.topk(min(Q, 10), dim=0)[0].sum(0).int(), min=1)
+    match = torch.zeros_like(cost)
+    for t in range(T):
+        match[cost[:, t].topk(int(k[t]), largest=False)[1], t] = 1.0
+    contested = match.sum(1) > 1
+
+    def keep_cheapest():
+        best = cost[contested].min(1)[1]
+        match[contested] = 0
+        match[contested, best] = 1
+
+    if contested.any():
+        keep_cheapest()
+    while bool((match.sum(0) == 0).any()):
+        cost[match.sum(1) > 0] += 100000.0
+        for t in torch.nonzero(match.sum(0) == 0).flatten():
+            match[cost[:, t].argmin(), t] = 1.0
+        if bool((match.sum(1) > 1).any()):
+            keep_cheapest()
+    chosen = match.sum(1) > 0
+    tgt = match[chosen].max(1)[1]
+    cost[match == 0] = cost[match == 0] + float("inf")
+    return (torch.nonzero(chosen).flatten(), tgt), cost.min(0)[1]
+
+
 class HungarianMatcher(nn.Module):
     """weights: MatchWeights.  num_points: points of the mask costs (12544 = 112^2 in both heads).  stuff_takes_mean: the panoptic
     box handling (`panoptic_box_loss` / `panoptic_on`).  draw(shape, device) supplies uniform [0, 1) numbers (default torch.rand): the
@@ -119,6 +169,23 @@ class HungarianMatcher(nn.Module):
             C = cost_matrix(logits[b], boxes[b], tgt, self.w, m, coords, self.stuff_takes_mean, "box" in costs, self.class_mode)
             out.append(assign(C.reshape(logits.shape[1], -1)))
         return out
+
+    @torch.no_grad()
+    def forward_ota(self, logits, boxes, targets):
+        """`forward_ota` (matcher.py:347-372; MODEL.DDETRS.OTA, on in the shipped configs): one-to-many SimOTA matching of the decoder
+        queries -> ([(query idx, target idx)] per image, [best query of every target] per image; images without targets: empty / [])."""
+        pairs, best = [], []
+        prob = logits.sigmoid()
+        for b, t in enumerate(targets):
+            if len(t["boxes"]) == 0:
+                e = torch.zeros(0, dtype=torch.int64, device=logits.device)
+                pairs.append((e, e.clone()))
+                best.append([])
+                continue
+            p, q = dynamic_k_assign(*ota_cost(prob[b], boxes[b], t))
+            pairs.append(p)
+            best.append(q)
+        return pairs, best
 
     @torch.no_grad()
     def forward_boxes_only(self, logits, boxes, targets):

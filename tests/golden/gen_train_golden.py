@@ -175,6 +175,31 @@ def gen_matcher():
     arrays.update(pairs("md", i_md)); arrays.update(pairs("mdvl", i_md_vl))
     for i, r in enumerate(rec2):
         arrays["md_rand%d" % i] = r
+    # SimOTA (the shipped configs train with MODEL.DDETRS.OTA on).  torchvision.ops.box_iou is a placeholder in the shim: the reference's own
+    # pairwise IoU (util/box_ops.py:34-46) stands in for it -- the same published formula
+    M_DET.ops.box_iou = lambda a, b: BOX.box_iou(a, b)[0]
+    ota_boxes = boxes.clone()
+    for b_, t in enumerate(targets):                      # put a few queries on the targets so that IoUs (and dynamic k) are not all tiny
+        for j in range(len(t["boxes"])):
+            ota_boxes[b_, 3 * j:3 * j + 3] = t["boxes"][j] + 0.02 * torch.randn(3, 4, generator=g)
+    ota_boxes[..., 2:] = ota_boxes[..., 2:].clamp(min=0.02)
+    empty = {"labels": torch.zeros(0, dtype=torch.long), "boxes": torch.zeros(0, 4), "positive_map": torch.zeros(0, L, dtype=torch.bool),
+             "is_thing": torch.zeros(0, dtype=torch.bool), "masks": torch.zeros(0, 32, 40)}
+    with cpu_as_cuda([]):
+        i_ota, best = m.forward_ota({"pred_logits": logits, "pred_boxes": ota_boxes}, targets[:2] + [empty])
+    arrays["ota_boxes"] = ota_boxes
+    # a contended case: three targets of which two coincide, four queries -- the repair loop of dynamic_k_matching has to run
+    tb = torch.tensor([[0.5, 0.5, 0.3, 0.3], [0.5, 0.5, 0.3, 0.3], [0.2, 0.2, 0.1, 0.1]])
+    tie_t = [{"labels": torch.zeros(3, dtype=torch.long), "boxes": tb, "positive_map": targets[0]["positive_map"][:3], "is_thing": torch.ones(3, dtype=torch.bool)}]
+    tie_q = torch.tensor([[[0.5, 0.5, 0.3, 0.3], [0.52, 0.5, 0.3, 0.28], [0.8, 0.8, 0.1, 0.1], [0.21, 0.2, 0.1, 0.1]]])
+    tie_l = torch.randn(1, 4, L, generator=g)
+    with cpu_as_cuda([]):
+        i_tie, best_tie = m.forward_ota({"pred_logits": tie_l, "pred_boxes": tie_q}, tie_t)
+    arrays.update(tie_boxes=tb, tie_queries=tie_q, tie_logits=tie_l, tie_best=best_tie[0])
+    arrays.update(pairs("tie", i_tie))
+    arrays.update(pairs("ota", i_ota))
+    for i, q in enumerate(best):
+        arrays["ota_best%d" % i] = q if torch.is_tensor(q) else torch.zeros(0, dtype=torch.long)
     save("train_matcher", **arrays)
 
 
@@ -245,6 +270,19 @@ def gen_criterion():
         crit.point_sample = False
         dense = crit.loss_masks(outputs, targets, indices[-1], 7.0)
         nodn = crit.compute_dn_loss(None, targets, layers - 1, 7.0)
+    # OTA: one-to-many pairs, every loss per matched pair
+    M_DET.ops.box_iou = lambda a, b: BOX.box_iou(a, b)[0]
+    ota_out = {"pred_logits": outs[-1]["pred_logits"], "pred_boxes": outs[-1]["pred_boxes"].clone(), "pred_boxious": outs[-1]["pred_boxious"], "text_masks": text_masks}
+    for b_, t in enumerate(targets):
+        for j in range(len(t["boxes"])):
+            ota_out["pred_boxes"][b_, 2 * j:2 * j + 2] = (t["boxes"][j] + 0.02 * torch.randn(2, 4, generator=g)).clamp(min=0.02)
+    rec3 = []
+    with cpu_as_cuda(rec3):
+        ota_idx, _ = matcher.forward_ota(ota_out, targets)
+        ota_out["pred_masks"] = [torch.randn(1, len(ota_idx[b_][0]), 1, 16, 24, generator=g) * 2 for b_ in range(B)]
+        crit_ota = C_DET.DINOCriterion(matcher, {}, ["labelsVL", "boxes", "masks"], focal_alpha=0.25, mask_out_stride=4, ota=True, point_sample=True)
+        crit_ota.num_points = 300
+        ota_losses = C_DET.SetCriterion.forward(crit_ota, ota_out, targets, [ota_idx])
     arrays = dict(text_masks=text_masks, enc_logits=outputs["enc_outputs"]["pred_logits"], enc_boxes=outputs["enc_outputs"]["pred_boxes"],
                   meta=np.array([SP, G, layers]), known_logits=known["pred_logits"], known_boxes=known["pred_boxes"], giou_pairs_ref=torch.zeros(1))
     for i, o in enumerate(outs):
@@ -259,6 +297,10 @@ def gen_criterion():
     arrays.update(_scalars("loss_", losses)); arrays.update(_scalars("dense_", dense)); arrays.update(_scalars("nodn_", nodn))
     for i, r in enumerate(rec2):
         arrays["rand%d" % i] = r
+    arrays.update(ota_boxes=ota_out["pred_boxes"], ota_masks0=ota_out["pred_masks"][0], ota_masks1=ota_out["pred_masks"][1])
+    arrays.update(pairs("ota_idx", ota_idx)); arrays.update(_scalars("otaloss_", ota_losses))
+    for i, r in enumerate(rec3):
+        arrays["ota_rand%d" % i] = r
     # the per-pair GIoU loss against the reference's own pairwise GIoU (the only third-party formula of the criterion)
     a, b = BOX.box_cxcywh_to_xyxy(rand_boxes(g, 40)), BOX.box_cxcywh_to_xyxy(rand_boxes(g, 40))
     arrays.update(giou_a=a, giou_b=b, giou_pairwise_diag=torch.diag(BOX.generalized_box_iou(a, b)), iou_diag=C_DET.compute_box_iou(a, b))

@@ -94,6 +94,14 @@ def test_matchers_give_the_reference_assignments(dev):
     md.class_mode = "map"
     assert same_pairs(md(f["logits"], f["boxes"], targets, masks=f["md_masks"]), f.pairs("mdvl", 3))
     assert draw.done()
+    # SimOTA: one-to-many pairs and the best query of every target; the third image has no target
+    empty = {k: v[:0] for k, v in targets[2].items()}
+    got, best = m.forward_ota(f["logits"], f["ota_boxes"], targets[:2] + [empty])
+    assert same_pairs(got, f.pairs("ota", 3)) and len(got[0][0]) > len(targets[0]["boxes"])          # more queries than targets: one-to-many
+    assert all(torch.equal(torch.as_tensor(best[i]).cpu().long(), f["ota_best%d" % i].cpu()) for i in range(3))
+    tie_t = [{"labels": torch.zeros(3, dtype=torch.long, device=dev), "boxes": f["tie_boxes"], "positive_map": targets[0]["positive_map"][:3]}]
+    got, best = m.forward_ota(f["tie_logits"], f["tie_queries"], tie_t)                  # two coinciding targets: the repair loop runs
+    assert same_pairs(got, f.pairs("tie", 1)) and torch.equal(best[0].cpu(), f["tie_best"].cpu())
     with pytest.raises(ValueError):
         HungarianMatcher(MatchWeights(0, 0, 0, 0, 1))
     with pytest.raises(ValueError):
@@ -173,6 +181,16 @@ def test_detection_criterion_matches_dino_criterion(dev):
     assert not bad, bad
     assert draw.done()
     assert len(want) == 6 * layers + 3 + 3 * layers       # per layer ce / bbox / giou / boxiou / mask / dice; encoder and de-noising (no IoU head): 3 each
+    # OTA: one-to-many pairs from forward_ota, every loss normalised by the number of matched pairs
+    ota_out = dict(outs[-1], pred_boxes=f["ota_boxes"], pred_masks=[f["ota_masks0"], f["ota_masks1"]])
+    ota_idx, _ = matcher.forward_ota(ota_out["pred_logits"], ota_out["pred_boxes"], targets)
+    assert same_pairs(ota_idx, f.pairs("ota_idx", 2))
+    draw = Replay(f.rands("ota_rand"))
+    got = DetCriterion(matcher, ["labelsVL", "boxes", "masks"], num_points=300, draw=draw, ota=True)(ota_out, targets, [ota_idx])
+    want = {k[8:]: float(f.z[k]) for k in f.z.files if k.startswith("otaloss_")}
+    got = {k: v for k, v in got.items() if "_dn" not in k}               # SetCriterion.forward (no de-noising part) is what the fixture ran
+    assert set(got) == set(want) and not {k: (float(got[k]), want[k]) for k in want if abs(float(got[k]) - want[k]) > 2e-5 * max(1.0, abs(want[k]))}
+    assert draw.done()
     # full-resolution (not point-sampled) mask losses, the zero entries without de-noising queries, the third-party box formulas
     dense = DetCriterion(matcher, ["masks"], point_sample_masks=False).loss_masks(outs[-1], targets, indices[-1], 7.0)
     assert abs(float(dense["loss_mask"]) - float(f.z["dense_loss_mask"])) < 1e-5 and abs(float(dense["loss_dice"]) - float(f.z["dense_loss_dice"])) < 1e-5
