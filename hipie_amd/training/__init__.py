@@ -7,3 +7,4 @@ from .boxes import box_cxcywh_to_xyxy, generalized_box_iou, paired_giou_loss, pa
 from .matcher import HungarianMatcher, MatchWeights                                            # noqa: F401
 from .dn import cdn_queries, dn_split_outputs, dn_match_indices                                # noqa: F401
 from .criterion import DetCriterion, MaskCriterion                                             # noqa: F401
+from .weights import maskdino_loss_plan, weighted_merge                                        # noqa: F401

@@ -348,7 +348,25 @@ def gen_maskdino():
     save("train_maskdino", **arrays)
 
 
+def gen_weights():
+    import json
+    import types
+    out = {}
+    for tag, kw in (("seg", dict(TWO_STAGE=True, DN="seg", DEEP_SUPERVISION=True, BOX_LOSS=True)), ("std", dict(TWO_STAGE=False, DN="standard", DEEP_SUPERVISION=True, BOX_LOSS=False)),
+                    ("no", dict(TWO_STAGE=True, DN="no", DEEP_SUPERVISION=False, BOX_LOSS=True))):
+        md = types.SimpleNamespace(CLASS_WEIGHT=4.0, COST_CLASS_WEIGHT=4.0, COST_DICE_WEIGHT=5.0, DICE_WEIGHT=5.0, COST_MASK_WEIGHT=5.0, NO_OBJECT_WEIGHT=0.1,
+                                   MASK_WEIGHT=5.0, COST_BOX_WEIGHT=5.0, BOX_WEIGHT=5.0, COST_GIOU_WEIGHT=2.0, GIOU_WEIGHT=2.0, DEC_LAYERS=3, TRAIN_NUM_POINTS=12544, **kw)
+        cfg = types.SimpleNamespace(MODEL=types.SimpleNamespace(MaskDINO=md))
+        w, dn_losses, matcher, losses = DN.get_weight_dict(cfg, True)
+        out[tag] = {"weights": w, "dn_losses": dn_losses, "losses": losses, "args": kw,
+                    "matcher": [matcher.cost_class, matcher.cost_box, matcher.cost_giou, matcher.cost_mask, matcher.cost_dice, matcher.num_points, bool(matcher.vl_loss),
+                                bool(matcher.panoptic_on)]}
+    with open(os.path.join(HERE, "train_weights.json"), "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    print("train_weights.json: %d plans" % len(out))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["matcher", "dn", "criterion", "maskdino"]
+    which = sys.argv[1:] or ["matcher", "dn", "criterion", "maskdino", "weights"]
     for w in which:
         globals()["gen_" + w]()

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from hipie_amd.training import (DetCriterion, HungarianMatcher, MaskCriterion, MatchWeights, cdn_queries, dn_match_indices, dn_split_outputs,
+from hipie_amd.training import (maskdino_loss_plan, weighted_merge, DetCriterion, HungarianMatcher, MaskCriterion, MatchWeights, cdn_queries, dn_match_indices, dn_split_outputs,
                                 generalized_box_iou, paired_giou_loss, paired_iou, box_cxcywh_to_xyxy)
 from hipie_amd.training.criterion import uncertain_points
 from hipie_amd.training.matcher import class_cost, mask_costs
@@ -237,3 +237,17 @@ def test_uncertain_points_prefer_the_decision_boundary():
     pts = uncertain_points(logits, 200, 3.0, 0.75, lambda shape, device: torch.rand(shape, generator=g))
     assert pts.shape == (1, 200, 2)
     assert float((pts[0, :150, 0] - 0.5).abs().mean()) < 0.1 < float((pts[0, 150:, 0] - 0.5).abs().mean())
+
+
+def test_maskdino_loss_plan_and_merge():
+    import json
+    plans = json.load(open(os.path.join(GOLD, "train_weights.json")))
+    for tag, p in plans.items():
+        a = p["args"]
+        w, dn_losses, matcher, losses = maskdino_loss_plan(4.0, 5.0, 5.0, 5.0, 2.0, a["TWO_STAGE"], a["DN"], a["DEEP_SUPERVISION"], 3, a["BOX_LOSS"],
+                                                           4.0, 5.0, 5.0, 5.0, 2.0, 12544, True)
+        assert w == p["weights"] and dn_losses == p["dn_losses"] and losses == p["losses"], tag
+        mw = matcher.w
+        assert [mw.cls, mw.l1, mw.giou, mw.mask, mw.dice, matcher.num_points, matcher.class_mode == "map", matcher.stuff_takes_mean] == p["matcher"]
+    merged = weighted_merge([{"a": torch.tensor(1.0), "b": torch.tensor(2.0)}, {"a": torch.tensor(3.0)}], [2.0, 0.5])
+    assert float(merged["a"]) == 3.5 and float(merged["b"]) == 4.0
