@@ -666,7 +666,6 @@ namespace hipie {       // gemm_k256.hip
 int launch_gemm_k256(const void* X, long ldx_b, int x_f32, const void* W, long ldw_b, const float* bias, float* out, long ldo, int M, int N,
                      hipStream_t st);
 }
-constexpr int K256_DEFAULT = 0;      // opt-in until measured in the step
 
 static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* resid, int64_t ldr,
                      void* out, int64_t ldo, const int32_t* out_row, const int32_t* a_row, int64_t a_rows, int M, int N, int K, int in_fmt,
@@ -700,9 +699,11 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, con
   p.conv_kpt = 0; p.conv_wp = 0; p.softmax = 0; p.sm_L = 0; p.sm_clamp = 0.f; p.sm_mask = nullptr;
   hipStream_t st = (hipStream_t)stream;
   // K = 256 linears over many rows with a plain fp32 result: the thin-K kernel (gemm_k256.hip: X rows live in registers, the weight
-  // streams through LDS in 32-feature chunks).  HIPIE_GEMM_K256=0: never (A/B timing)
+  // streams through LDS in 32-feature chunks) where it is faster than the 256-column tiles -- N >= 384 (tools/bench_gemm_k256.py: -20 % at
+  // N = 384, -7 % at 1024, -9 % at 2304; level at N = 256).  HIPIE_GEMM_K256=0: never, =1: every eligible shape (A/B timing)
   const char* k256_env = getenv("HIPIE_GEMM_K256");
-  const int k256_on = k256_env ? atoi(k256_env) : K256_DEFAULT;
+  const int k256_mode = k256_env ? atoi(k256_env) : 2;
+  const bool k256_on = k256_mode == 1 || (k256_mode == 2 && N >= 384);
   if (k256_on && split && K == 256 && out_fmt == HIPIE_F32 && act == 0 && resid == nullptr && out_row == nullptr && a_row == nullptr &&
       alpha == 1.f && oscale == 1.f && N % 32 == 0 && M >= 8192 && ldw * 2 == 1024)
     return launch_gemm_k256(A, p.lda_b, a_f32 ? 1 : 0, W, p.ldw_b, bias, (float*)out, ldo, M, N, st);
