@@ -251,3 +251,30 @@ def test_maskdino_loss_plan_and_merge():
         assert [mw.cls, mw.l1, mw.giou, mw.mask, mw.dice, matcher.num_points, matcher.class_mode == "map", matcher.stuff_takes_mean] == p["matcher"]
     merged = weighted_merge([{"a": torch.tensor(1.0), "b": torch.tensor(2.0)}, {"a": torch.tensor(3.0)}], [2.0, 0.5])
     assert float(merged["a"]) == 3.5 and float(merged["b"]) == 4.0
+
+
+def test_empty_targets_flow_through_matcher_and_criteria():
+    """an image without annotations: empty assignment, zero box / mask losses that still depend on the predictions (a graph for autograd),
+    label loss over the remaining image's queries, count clamped at 1"""
+    g = torch.Generator().manual_seed(3)
+    B, Q, L = 2, 6, 5
+    pm = torch.zeros(2, L, dtype=torch.bool)
+    pm[0, 1] = pm[1, 3] = True
+    full = {"labels": torch.tensor([0, 1]), "boxes": torch.tensor([[0.5, 0.5, 0.2, 0.2], [0.3, 0.6, 0.1, 0.3]]), "positive_map": pm,
+            "is_thing": torch.tensor([True, True]), "masks": (torch.rand(2, 32, 32, generator=g) > 0.5).float()}
+    none = {"labels": torch.zeros(0, dtype=torch.long), "boxes": torch.zeros(0, 4), "positive_map": torch.zeros(0, L, dtype=torch.bool),
+            "is_thing": torch.zeros(0, dtype=torch.bool), "masks": torch.zeros(0, 32, 32)}
+    logits = torch.randn(B, Q, L, generator=g, requires_grad=True)
+    boxes = torch.rand(B, Q, 4, generator=g) * 0.4 + 0.2
+    m = HungarianMatcher(MatchWeights(2, 5, 2, 5, 5), num_points=50, class_mode="map")
+    idx = m(logits.detach(), boxes, [full, none])
+    assert len(idx[0][0]) == 2 and len(idx[1][0]) == 0
+    outputs = {"pred_logits": logits, "pred_boxes": boxes, "text_masks": torch.ones(B, L, dtype=torch.long),
+               "pred_masks": [torch.randn(1, 2, 1, 8, 8, generator=g), torch.zeros(1, 0, 1, 8, 8)]}
+    losses = DetCriterion(m, ["labelsVL", "boxes", "masks"], num_points=40)(outputs, [full, none], [idx])
+    assert all(torch.isfinite(v).all() for v in losses.values()) and float(losses["loss_ce"].detach()) > 0
+    losses["loss_ce"].backward()
+    assert float(logits.grad[1].abs().sum()) > 0                               # the empty image's queries are all negatives: they get gradient
+    both_empty = DetCriterion(m, ["labelsVL", "boxes", "masks"], num_points=40)(
+        dict(outputs, pred_masks=[torch.zeros(1, 0, 1, 8, 8)] * 2), [none, none], [m(logits.detach(), boxes, [none, none])])
+    assert float(both_empty["loss_bbox"]) == 0 and float(both_empty["loss_mask"]) == 0 and torch.isfinite(both_empty["loss_ce"])
