@@ -271,9 +271,10 @@ def test_empty_targets_flow_through_matcher_and_criteria():
     assert len(idx[0][0]) == 2 and len(idx[1][0]) == 0
     outputs = {"pred_logits": logits, "pred_boxes": boxes, "text_masks": torch.ones(B, L, dtype=torch.long),
                "pred_masks": [torch.randn(1, 2, 1, 8, 8, generator=g), torch.zeros(1, 0, 1, 8, 8)]}
-    losses = DetCriterion(m, ["labelsVL", "boxes", "masks"], num_points=40)(outputs, [full, none], [idx])
-    assert all(torch.isfinite(v).all() for v in losses.values()) and float(losses["loss_ce"].detach()) > 0
-    losses["loss_ce"].backward()
+    with torch.enable_grad():                                                  # other test modules switch autograd off process-wide
+        losses = DetCriterion(m, ["labelsVL", "boxes", "masks"], num_points=40)(outputs, [full, none], [idx])
+        assert all(torch.isfinite(v).all() for v in losses.values()) and float(losses["loss_ce"].detach()) > 0
+        losses["loss_ce"].backward()
     assert float(logits.grad[1].abs().sum()) > 0                               # the empty image's queries are all negatives: they get gradient
     both_empty = DetCriterion(m, ["labelsVL", "boxes", "masks"], num_points=40)(
         dict(outputs, pred_masks=[torch.zeros(1, 0, 1, 8, 8)] * 2), [none, none], [m(logits.detach(), boxes, [none, none])])
