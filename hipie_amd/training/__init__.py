@@ -5,6 +5,6 @@ yet, so nothing here is on a timed path.  Every function t
 argument (or from a ``draw`` callable) so that results can be compared with the reference bit for bit."""
 from .boxes import box_cxcywh_to_xyxy, generalized_box_iou, paired_giou_loss, paired_iou      # noqa: F401
 from .matcher import HungarianMatcher, MatchWeights                                            # noqa: F401
-from .dn import cdn_queries, dn_split_outputs, dn_match_indices                                # noqa: F401
+from .dn import cdn_queries, dn_split_outputs, dn_match_indices, maskdino_dn_queries           # noqa: F401
 from .criterion import DetCriterion, MaskCriterion                                             # noqa: F401
 from .weights import maskdino_loss_plan, weighted_merge                                        # noqa: F401

@@ -93,3 +93,58 @@ def dn_match_indices(targets, meta, device=None):
         qry = (torch.arange(G, device=dev) * stride).repeat_interleave(k) + tgt
         out.append((qry, tgt))
     return out
+
+
+def maskdino_dn_queries(targets, dn_num, noise_scale, num_queries, label_embed, tgt=None, refpoint=None, noise=None, num_classes=None):
+    """MaskDINO's own de-noising queries (DN-DETR style; maskdino/transformer_decoder/maskdino_decoder.py:202-327, training branch):
+    G = dn_num // (largest target count) groups of ONE noised copy per target -- centre moved by up to half the size, size changed by up to
+    the size, both times noise_scale -- padded to P slots per image in the order [group 0 | group 1 | ..]; the label side is the image's text
+    embedding (label_embed a (B, C) tensor) or an embedding of the class id, flipped to a random class with probability noise_scale / 2
+    (label_embed a callable).  tgt (Q, C) / refpoint (Q, 4): the matching queries, appended behind the de-noising part when given.
+    noise: {"box": (G n, 4) in [0, 1)} and, with class ids, {"p": (G n,), "new_label": ids}; None: drawn here in the reference's order (p,
+    new_label, box).
+    -> (query_label (B, G P [+ Q], C), query_box (B, G P [+ Q], 4) logits, attn_mask (G P + num_queries)^2 with True = blocked,
+        {"pad_size": G P, "scalar": G, "single_pad": P}), or four Nones when there are no targets / dn_num is too small for one group."""
+    counts = [int(t["labels"].numel()) for t in targets]
+    P = max(counts) if counts else 0
+    G = dn_num // P if P > 0 else 0
+    if G == 0:
+        return None, None, None, None
+    B, n = len(targets), sum(counts)
+    labels = torch.cat([t["labels"] for t in targets])
+    boxes = torch.cat([t["boxes"] for t in targets])
+    dev = boxes.device
+    image_of = torch.cat([torch.full((c,), i, dtype=torch.long, device=dev) for i, c in enumerate(counts)])
+    slot_in_image = torch.cat([torch.arange(c, device=dev) for c in counts])
+    rep_labels, rep_boxes, rep_image = labels.repeat(G), boxes.repeat(G, 1), image_of.repeat(G)
+    noise = dict(noise or {})
+    dynamic = torch.is_tensor(label_embed)
+    if noise_scale > 0:
+        # the reference draws p and the replacement labels whatever the label mode (and uses them only with class-id embeddings)
+        p = noise["p"] if "p" in noise else torch.rand(rep_labels.shape, device=dev)
+        flip = torch.nonzero(p < noise_scale * 0.5).flatten()
+        if "new_label" in noise:
+            new = noise["new_label"]
+        else:
+            new = torch.randint(0, num_classes, flip.shape, device=dev)
+        rep_labels = rep_labels.clone()
+        rep_labels[flip] = new[:flip.numel()].to(rep_labels.dtype)
+        u = noise["box"] if "box" in noise else torch.rand(rep_boxes.shape, device=dev)
+        reach = torch.cat((rep_boxes[:, 2:] / 2, rep_boxes[:, 2:]), 1)
+        rep_boxes = (rep_boxes + (u * 2 - 1.0) * reach * noise_scale).clamp(0.0, 1.0)
+    emb = label_embed[rep_image] if dynamic else label_embed(rep_labels.long())
+    pad = G * P
+    q_label = emb.new_zeros(B, pad, emb.shape[-1])
+    q_box = rep_boxes.new_zeros(B, pad, 4)
+    slot = torch.arange(G, device=dev).repeat_interleave(n) * P + slot_in_image.repeat(G)
+    q_label[rep_image, slot] = emb
+    q_box[rep_image, slot] = _inverse_sigmoid(rep_boxes)
+    if refpoint is not None:
+        q_label = torch.cat((q_label, tgt[None].expand(B, -1, -1)), 1)
+        q_box = torch.cat((q_box, refpoint[None].expand(B, -1, -1)), 1)
+    size = pad + num_queries
+    group = torch.arange(pad, device=dev) // P
+    mask = torch.zeros(size, size, dtype=torch.bool, device=dev)
+    mask[:pad, :pad] = group[:, None] != group[None, :]
+    mask[pad:, :pad] = True
+    return q_label, q_box, mask, {"pad_size": pad, "scalar": G, "single_pad": P}

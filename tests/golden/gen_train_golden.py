@@ -226,6 +226,26 @@ def gen_dn():
         arrays.update(flat(tag + "_t", targets)); arrays.update(pairs(tag + "_idx", idx))
         for i, r in enumerate(rec):
             arrays["%s_rand%d" % (tag, i)] = r
+    # MaskDINO's own (DN-DETR style) de-noising queries: maskdino_decoder.py:202-327
+    MDD = ref_shim.ref("models.maskdino.transformer_decoder.maskdino_decoder")
+    for tag, dynamic, counts, dn_num in (("md_dyn", True, (3, 2), 7), ("md_ids", False, (2, 4, 0), 9)):
+        targets = [{"labels": torch.randint(0, 6, (n,), generator=g), "boxes": rand_boxes(g, n)} for n in counts]
+        C, Qn = 8, 5
+        me = _Self()
+        me.training, me.dn_num, me.noise_scale, me.num_classes, me.hidden_dim, me.num_queries, me.dynamic_label_enc = True, dn_num, 0.4, 6, C, Qn, dynamic
+        table = torch.randn(6, C, generator=g)
+        pooled = torch.randn(len(counts), C, generator=g)
+        me.resizer = lambda x: x
+        me.label_enc = lambda ids: table[ids]
+        tgt, refp = torch.randn(Qn, C, generator=g), torch.randn(Qn, 4, generator=g)
+        rec = []
+        with cpu_as_cuda(rec):
+            ql, qb, mask, md = MDD.MaskDINODecoder.prepare_for_dn(me, targets, tgt, refp, len(counts), pooled if dynamic else None)
+        arrays.update({tag + "_label": ql, tag + "_box": qb, tag + "_mask": mask, tag + "_meta": np.array([md["pad_size"], md["scalar"]]),
+                       tag + "_emb": pooled if dynamic else table, tag + "_args": np.array([dn_num, 0.4, Qn, 6]), tag + "_tgt": tgt, tag + "_refp": refp})
+        arrays.update(flat(tag + "_t", targets))
+        for i, r in enumerate(rec):
+            arrays["%s_rand%d" % (tag, i)] = r
     save("train_dn", **arrays)
 
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from hipie_amd.training import (maskdino_loss_plan, weighted_merge, DetCriterion, HungarianMatcher, MaskCriterion, MatchWeights, cdn_queries, dn_match_indices, dn_split_outputs,
+from hipie_amd.training import (maskdino_dn_queries, maskdino_loss_plan, weighted_merge, DetCriterion, HungarianMatcher, MaskCriterion, MatchWeights, cdn_queries, dn_match_indices, dn_split_outputs,
                                 generalized_box_iou, paired_giou_loss, paired_iou, box_cxcywh_to_xyxy)
 from hipie_amd.training.criterion import uncertain_points
 from hipie_amd.training.matcher import class_cost, mask_costs
@@ -279,3 +279,19 @@ def test_empty_targets_flow_through_matcher_and_criteria():
     both_empty = DetCriterion(m, ["labelsVL", "boxes", "masks"], num_points=40)(
         dict(outputs, pred_masks=[torch.zeros(1, 0, 1, 8, 8)] * 2), [none, none], [m(logits.detach(), boxes, [none, none])])
     assert float(both_empty["loss_bbox"]) == 0 and float(both_empty["loss_mask"]) == 0 and torch.isfinite(both_empty["loss_ce"])
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+@pytest.mark.parametrize("tag,n_img", [("md_dyn", 2), ("md_ids", 3)])
+def test_maskdino_dn_queries_match_prepare_for_dn(dev, tag, n_img):
+    f = Fixture("train_dn", dev)
+    targets = f.targets(tag + "_t", n_img)
+    dn_num, scale, nq, ncls = [float(x) for x in f.z[tag + "_args"]]
+    r = f.rands(tag + "_rand")
+    emb = f[tag + "_emb"]
+    label_embed = emb if tag == "md_dyn" else (lambda ids: emb[ids])
+    ql, qb, mask, md = maskdino_dn_queries(targets, int(dn_num), scale, int(nq), label_embed, f[tag + "_tgt"], f[tag + "_refp"],
+                                           {"p": r[0], "new_label": r[1], "box": r[2]}, int(ncls))
+    assert [md["pad_size"], md["scalar"]] == [int(x) for x in f.z[tag + "_meta"]]
+    assert torch.equal(mask.cpu(), f[tag + "_mask"].cpu()) and close(ql, f[tag + "_label"], 1e-7) and close(qb, f[tag + "_box"], 1e-6)
+    assert maskdino_dn_queries(targets, 1, scale, int(nq), label_embed)[0] is None          # fewer requested copies than targets: no group
