@@ -8,3 +8,4 @@ from .matcher import HungarianMatcher, MatchWeights                             
 from .dn import cdn_queries, dn_split_outputs, dn_match_indices, maskdino_dn_queries           # noqa: F401
 from .criterion import DetCriterion, MaskCriterion                                             # noqa: F401
 from .weights import maskdino_loss_plan, weighted_merge                                        # noqa: F401
+from .targets import prepare_targets, split_things_stuff                                       # noqa: F401

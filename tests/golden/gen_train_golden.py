@@ -16,6 +16,7 @@ import contextlib
 import importlib.util
 import os
 import sys
+import types
 
 import numpy as np
 import torch
@@ -368,9 +369,35 @@ def gen_maskdino():
     save("train_maskdino", **arrays)
 
 
+def gen_targets():
+    hipie_img_mod = ref_shim.ref_hipie_img()          # hipie_img.py with detectron2's vendored (dependency-free) Boxes / Instances
+    st = {"instances": types.SimpleNamespace(Instances=hipie_img_mod.Instances), "boxes": types.SimpleNamespace(Boxes=hipie_img_mod.Boxes)}
+    g = torch.Generator().manual_seed(15)
+    arrays = {}
+    insts = []
+    for i, (n, hw) in enumerate(((3, (48, 64)), (0, (32, 32)), (2, (40, 24)))):
+        inst = st["instances"].Instances(hw)
+        xy0 = torch.rand(n, 2, generator=g) * torch.tensor([hw[1], hw[0]]) * 0.5
+        wh = torch.rand(n, 2, generator=g) * torch.tensor([hw[1], hw[0]]) * 0.4 + 1
+        inst.gt_boxes = st["boxes"].Boxes(torch.cat((xy0, xy0 + wh), 1))
+        inst.gt_classes = torch.randint(0, 9, (n,), generator=g)
+        inst.positive_map = torch.rand(n, 6, generator=g) > 0.6
+        inst.is_thing = torch.rand(n, generator=g) > 0.4
+        inst.gt_masks = (torch.rand(n, hw[0], hw[1], generator=g) > 0.5)
+        insts.append(inst)
+        arrays.update({"in%d_boxes" % i: inst.gt_boxes.tensor, "in%d_classes" % i: inst.gt_classes, "in%d_pm" % i: inst.positive_map,
+                       "in%d_thing" % i: inst.is_thing, "in%d_masks" % i: inst.gt_masks, "in%d_hw" % i: np.array(hw)})
+    me = _Self()
+    me.device, me.use_amp, me.use_lsj = torch.device("cpu"), False, True
+    out = hipie_img_mod.HIPIE_IMG.prepare_targets(me, insts)
+    for i, t in enumerate(out):
+        for k, v in t.items():
+            arrays["out%d_%s" % (i, k)] = v
+    save("train_targets", **arrays)
+
+
 def gen_weights():
     import json
-    import types
     out = {}
     for tag, kw in (("seg", dict(TWO_STAGE=True, DN="seg", DEEP_SUPERVISION=True, BOX_LOSS=True)), ("std", dict(TWO_STAGE=False, DN="standard", DEEP_SUPERVISION=True, BOX_LOSS=False)),
                     ("no", dict(TWO_STAGE=True, DN="no", DEEP_SUPERVISION=False, BOX_LOSS=True))):
@@ -387,6 +414,6 @@ def gen_weights():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["matcher", "dn", "criterion", "maskdino", "weights"]
+    which = sys.argv[1:] or ["matcher", "dn", "criterion", "maskdino", "weights", "targets"]
     for w in which:
         globals()["gen_" + w]()

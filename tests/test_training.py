@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from hipie_amd.training import (maskdino_dn_queries, maskdino_loss_plan, weighted_merge, DetCriterion, HungarianMatcher, MaskCriterion, MatchWeights, cdn_queries, dn_match_indices, dn_split_outputs,
+from hipie_amd.training import (prepare_targets, split_things_stuff, maskdino_dn_queries, maskdino_loss_plan, weighted_merge, DetCriterion, HungarianMatcher, MaskCriterion, MatchWeights, cdn_queries, dn_match_indices, dn_split_outputs,
                                 generalized_box_iou, paired_giou_loss, paired_iou, box_cxcywh_to_xyxy)
 from hipie_amd.training.criterion import uncertain_points
 from hipie_amd.training.matcher import class_cost, mask_costs
@@ -66,6 +66,10 @@ def same_pairs(got, want):
 
 def close(a, b, tol=2e-5):
     a, b = a.double().cpu(), b.double().cpu()
+    if a.shape != b.shape:
+        return False
+    if a.numel() == 0:
+        return True
     return float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
 
 
@@ -295,3 +299,29 @@ def test_maskdino_dn_queries_match_prepare_for_dn(dev, tag, n_img):
     assert [md["pad_size"], md["scalar"]] == [int(x) for x in f.z[tag + "_meta"]]
     assert torch.equal(mask.cpu(), f[tag + "_mask"].cpu()) and close(ql, f[tag + "_label"], 1e-7) and close(qb, f[tag + "_box"], 1e-6)
     assert maskdino_dn_queries(targets, 1, scale, int(nq), label_embed)[0] is None          # fewer requested copies than targets: no group
+
+
+def test_prepare_targets_and_the_thing_stuff_split():
+    from hipie_amd.structures import Boxes, Instances
+    z = np.load(os.path.join(GOLD, "train_targets.npz"))
+    insts = []
+    for i in range(3):
+        inst = Instances(tuple(int(v) for v in z["in%d_hw" % i]))
+        inst.gt_boxes = Boxes(torch.from_numpy(z["in%d_boxes" % i]))
+        inst.gt_classes = torch.from_numpy(z["in%d_classes" % i])
+        inst.positive_map = torch.from_numpy(z["in%d_pm" % i])
+        inst.is_thing = torch.from_numpy(z["in%d_thing" % i])
+        inst.gt_masks = torch.from_numpy(z["in%d_masks" % i])
+        insts.append(inst)
+    got = prepare_targets(insts)
+    for i, t in enumerate(got):
+        assert set(t) == {k[5:] for k in z.files if k.startswith("out%d_" % i)}
+        for k, v in t.items():
+            w = torch.from_numpy(z["out%d_%s" % (i, k)])
+            assert v.dtype == w.dtype and (torch.equal(v, w) if v.dtype != torch.float32 else close(v, w, 1e-7)), (i, k)
+    fg, bg = split_things_stuff(got)
+    for t, f_, b_ in zip(got, fg, bg):
+        n_thing = int(t["is_thing"].sum())
+        assert len(f_["labels"]) == n_thing and len(b_["labels"]) == len(t["labels"]) - n_thing and bool(f_["is_thing"].all()) and not bool(b_["is_thing"].any())
+        assert torch.equal(f_["boxes"], t["boxes"][t["is_thing"]]) and torch.equal(b_["masks"], t["masks"][~t["is_thing"]]) and f_["image_size"] is t["image_size"]
+    assert prepare_targets(insts, half=True)[0]["boxes"].dtype == torch.float16
