@@ -39,16 +39,19 @@ def synth_image(index, size, device, seed=0):
     return torch.randint(0, 256, (3, size, size), generator=gi).float().to(device)
 
 
-def synth_batch(cfg, batch, size, n_classes, L, device, seed=0, task="detection", indices=None):
-    """`batch` inputs; images are those of the global indices `indices` (default 0 .. batch-1), the prompt is shared."""
+def synth_batch(cfg, batch, size, n_classes, L, device, seed=0, task="detection", indices=None, ids_device="cpu"):
+    """`batch` inputs; images are those of the global indices `indices` (default 0 .. batch-1), the prompt is shared.  Images are
+    placed on `device`; token ids / masks stay on the HOST, where the reference's tokenizer produces them (hipie_img.py:904-909) -- the
+    text encoder copies them over inside the step (ids_device: put them elsewhere, e.g. on the GPU for a hipGraph capture)."""
     g = torch.Generator().manual_seed(seed)
+    idev = ids_device
     indices = list(range(batch)) if indices is None else list(indices)
     if task == "grounding":                     # one referring expression of ~10 tokens (BASELINE configs[2], second call)
         n = 10
         ids = torch.tensor([101] + torch.randint(1996, 29000, (n,), generator=g).tolist() + [102])
         mask = torch.ones_like(ids)
         return [{"image": synth_image(i, size, device, seed), "task": "grounding",
-                 "input_ids": ids.to(device), "attention_mask": mask.to(device)} for i in indices]
+                 "input_ids": ids.to(idev), "attention_mask": mask.to(idev)} for i in indices]
     ids = torch.zeros(L, dtype=torch.long)
     mask = torch.zeros(L, dtype=torch.long)
     row, pmap = [101], {}
@@ -68,7 +71,7 @@ def synth_batch(cfg, batch, size, n_classes, L, device, seed=0, task="detection"
     out = []
     for i in indices:
         img = synth_image(i, size, device, seed)                                          # resident in HBM before timing
-        out.append({"image": img, "task": "detection", "input_ids": ids.to(device), "attention_mask": mask.to(device),
+        out.append({"image": img, "task": "detection", "input_ids": ids.to(idev), "attention_mask": mask.to(idev),
                     "positive_map_label_to_token": pmap, "is_thing": {c: (c <= 60) for c in pmap}})
     return out
 
@@ -220,10 +223,26 @@ def parity_error(policy, device, full_size=True):
         fixtures.insert(0, "e2e_full_refinit")      # the headline configuration with weights from the reference's OWN initialisation
     if full_size and os.path.exists(os.path.join(ROOT, "tests", "golden", "e2e_full.npz")):
         fixtures.insert(0, "e2e_full")              # ... and from the (harder) default synthetic distribution: the gate
-    for fixture in fixtures:
+    if full_size and os.path.exists(os.path.join(ROOT, "tests", "golden", "e2e_full_c80.npz")):
+        fixtures.insert(0, "e2e_full_c80")          # ... and on the TIMED inputs themselves: image 0 of synth_batch, the 80-class caption (L = 194)
+    for fixture in fixtures:                        #     and the grounding call (same gate weights as e2e_full)
         g = Golden(fixture)
         model = HIPIE_IMG(HipieConfig.from_dict(g.meta["cfg"]), policy, device=device)
         model.load_state_dict(_synth.synth_full_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}, dist=g.meta.get("dist")), strict=True)
+        if "bench_inputs" in g.meta:
+            bi, per_task = g.meta["bench_inputs"], {}
+            for task in ("detection", "grounding"):
+                b = synth_batch(None, 1, bi["size"], bi["n_classes"], bi["L"], device, seed=bi["seed"], task=task)
+                model.pin_topk(g[task + "_topk_fg"], g[task + "_topk_md"])
+                out = model.forward_raw(b)
+                per_task[task] = {k: rel_err(g.like(task + "_" + k, out[k].float().cpu()), g[task + "_" + k]) for k in keys}
+            errs = {k: max(per_task[t][k] for t in per_task) for k in keys}
+            res[fixture] = {"max": float("%.2e" % max(errs.values())), "per_output": {k: float("%.1e" % v) for k, v in errs.items()},
+                            "per_task_max": {t: float("%.2e" % max(v.values())) for t, v in per_task.items()}}
+            worst = max(worst, max(errs.values()))
+            del model
+            torch.cuda.empty_cache()
+            continue
         imgs = _synth.synth_images([tuple(s) for s in g.meta["sizes"]], seed=73)
         ids, mask, pmap = _synth.synth_token_ids(2, g.meta["detection"]["n_classes"], 64, seed=74)
         model.pin_topk(g["detection_topk_fg"], g["detection_topk_md"])
@@ -238,7 +257,9 @@ def parity_error(policy, device, full_size=True):
             "within_tolerance_on": [f for f in fixtures if res[f]["max"] <= 1e-3], "fixtures": res,
             "against": "tests/golden/{%s}.npz: the reference's own coco_inference on the CPU, pinned top-k (e2e_full = full ViT-H at "
                        "1024x1024 with the default synthetic weights -- the gate; e2e_full_refinit = the same with weights drawn from the "
-                       "reference's own initialisation, tests/golden/refinit_stats.json; e2e_deep = the shipped depths on a narrow ViT)"
+                       "reference's own initialisation, tests/golden/refinit_stats.json; e2e_deep = the shipped depths on a narrow ViT; "
+                       "e2e_full_c80 = the gate weights on the TIMED inputs: image 0 of this script's batch, the 80-class caption of 194 tokens, "
+                       "and the grounding call)"
                        % ",".join(fixtures)}
 
 
@@ -347,7 +368,8 @@ def main():
     # ONE global batch of batch * world images (image i seeded by i), cut like detectron2's InferenceSampler: rank r owns a contiguous
     # index range (BASELINE configs[3] at --gpus 8: 64 images, 8 per rank)
     shard = parallel.shard_range(args.batch * world, rank, world)
-    batch = synth_batch(cfg, len(shard), args.size, n_classes, L, dev, seed=0, task=args.task, indices=shard)
+    batch = synth_batch(cfg, len(shard), args.size, n_classes, L, dev, seed=0, task=args.task, indices=shard,
+                        ids_device=dev if args.graph else "cpu")
 
     def local_step():
         out = model.forward_raw(batch)
@@ -418,6 +440,32 @@ def main():
     kern_ms, kern_n = ops.PROFILE.mean_ms("vit_attn_global")
     gemm = {t: ops.PROFILE.mean_ms(t) for t in gemm_tags}
     ops.PROFILE.disable()
+
+    # the shipped eval setting: MODEL.LANGUAGE_BACKBONE.PAD_MAX with MAX_QUERY_LEN 4096 -- the same batch, the caption padded to
+    # 4096 tokens; same step definition, same policy.  The padding rows are zero behind the reference's > 512 text branch, so the
+    # product computes the real tokens plus one padding row and repeats its class-logit column (tests/test_gpu_e2e.py::test_e2e_pad_max_4096_is_trimmed)
+    pad_max = None
+    if rank == 0 and world == 1 and n_classes == 80 and L < 4096 and args.task == "detection" and graph is None and not args.no_parity_leg:
+        pbatch = synth_batch(cfg, len(shard), args.size, n_classes, 4096, dev, seed=0, task=args.task, indices=shard)
+        for b_, p_ in zip(batch, pbatch):
+            p_["image"] = b_["image"]                  # the same resident images
+
+        def padstep():
+            return inference_compact(model, model.forward_raw(pbatch), pbatch, topk=100)
+        for _ in range(2):
+            padstep()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            padstep()
+        torch.cuda.synchronize()
+        pdt_ = (time.perf_counter() - t1) / args.steps
+        pad_max = {"text_len": 4096, "attended_tokens": int(pbatch[0]["attention_mask"].sum()), "ms_per_step": round(pdt_ * 1e3, 2),
+                   "value": round(args.batch / pdt_, 3), "unit": "images/sec", "steps": args.steps,
+                   "pred_logits_shape": None, "vs_unpadded_step": round(pdt_ / (dt / args.steps), 4)}
+        po = model.forward_raw(pbatch)
+        pad_max["pred_logits_shape"] = list(po["pred_logits"].shape)
+        del po, pbatch
 
     # the full post-processing of the reference's eval branch (instance masks at 1024^2, semantic + panoptic maps),
     # timed on its own: it is the row after the a22 metric surface
@@ -551,7 +599,9 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"split": "f16x3 (split-fp16 operands, fp32 accumulate: fp32-class)", "fast": "f16", "parity": "f32+f16attn", "bf16": "bf16",
                       "default": "bf16+f32head"}[args.precision],
-            "data": "synthetic (uint8-valued random images resident in HBM, synthetic BERT token ids, random-init weights)",
+            "data": "synthetic (uint8-valued random images resident in HBM BEFORE the timed region -- the 12.6 MB / image host-to-device copy that the "
+                    "reference's timer includes (detectron2/evaluation/evaluator.py:157-161) is outside the step; synthetic BERT token ids handed over "
+                    "as host tensors like a tokenizer's output; random-init weights)",
             "config": {"workload": "BASELINE.json configs[%s]: %s, %dx%d, batch %d per GPU, %d %s (L=%d), %s"
                                    % (str(args.config) if args.config is not None else
                                       {80: "1" if args.model == "r50" else ("2" if world == 1 else "2 per GPU (weak scaling of the metric's workload: "
@@ -568,9 +618,26 @@ def main():
             "roofline_attention": roof_attn,
             "postprocess_full_ms": None if post_ms is None else round(post_ms, 2),
             "parity_err": parity_err,
+            "pad_max_4096": pad_max,
             "fast_policy": other,
             "mixed_policy": mixed,
         }
+        # SURVEY 8d names the measurement weights: default module init with the zero tensors redrawn = tests/golden/e2e_full_refinit.  `value`
+        # stays the policy that ALSO passes the (much harder) default synthetic gate; value_8d says what the contract's own distribution allows:
+        # the fastest policy measured here whose error on e2e_full_refinit is <= 5e-4, with its error on the gate fixture beside it
+        cands = [("split", line["value"], line["ms_per_step"], parity_err)] if parity_err else []
+        if mixed:
+            cands.append(("mixed", mixed["value"], mixed["ms_per_step"], mixed["parity_err"]))
+        if other and "e2e_full_refinit" in (other.get("parity_err") or {}).get("fixtures", {}):
+            cands.append(("fast", other["value"], other["ms_per_step"], other["parity_err"]))
+        ok = [c for c in cands if c[3] and c[3]["fixtures"].get("e2e_full_refinit", {}).get("max", 1.0) <= 5e-4]
+        if ok:
+            best = max(ok, key=lambda c: c[1])
+            line["value_8d"] = {"value": best[1], "unit": "images/sec", "ms_per_step": best[2], "precision_policy": best[0],
+                                "err_on_e2e_full_refinit": best[3]["fixtures"]["e2e_full_refinit"]["max"],
+                                "err_on_gate_e2e_full": best[3]["fixtures"].get("e2e_full", {}).get("max"),
+                                "note": "fastest measured policy within 5e-4 on the weights SURVEY 8d names (reference init, zero tensors redrawn); "
+                                        "NOT the headline -- `value` is the policy that also passes the harder synthetic gate"}
         if not args.no_cpu_baseline and world == 1 and args.model != "r50" and args.classes == 80:   # rank 0 at N = 1 only (bounded ~20 s CPU sample)
             import subprocess
             try:                        # separate process, hard time bound: the baseline must never break the measured line

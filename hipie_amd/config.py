@@ -204,7 +204,13 @@ class HipieConfig:
                     ("MODEL.DDETRS.LOOK_FORWARD_TWICE", m.DDETRS.LOOK_FORWARD_TWICE, True),
                     ("MODEL.DDETRS.BG_QUERY_FROM_LANG", m.DDETRS.BG_QUERY_FROM_LANG, False),
                     ("MODEL.DDETRS.NEW_MASK_HEAD", m.DDETRS.NEW_MASK_HEAD, False), ("MODEL.DDETRS.USE_RAFT", m.DDETRS.USE_RAFT, False),
-                    ("MODEL.DDETRS.USE_REL_COORD", m.DDETRS.USE_REL_COORD, True), ("MODEL.CLIP.ENABLED_TRAIN", m.CLIP.ENABLED_TRAIN, False)]
+                    ("MODEL.DDETRS.USE_REL_COORD", m.DDETRS.USE_REL_COORD, True), ("MODEL.CLIP.ENABLED_TRAIN", m.CLIP.ENABLED_TRAIN, False),
+                    # the decoupled MaskDINO branch with its own class heads (ddetrs_dn.py:172-215) and the mask outputs (hipie_img.py:59)
+                    ("MODEL.MASK_ON", m.MASK_ON, True), ("MODEL.MASKDINO.ENABLED", m.MASKDINO.ENABLED, True),
+                    ("MODEL.MASKDINO.SHARE_CLS_HEAD", m.MASKDINO.SHARE_CLS_HEAD, False),
+                    ("MODEL.MASKDINO.FIXED_LINEAR_HEAD", m.MASKDINO.FIXED_LINEAR_HEAD, False)]
+        if m.BACKBONE.NAME != "D2ViT":           # the R50 of the shipped yamls: depth 50, stride in the 3x3 (resnet.py of this package)
+            required += [("MODEL.RESNETS.STRIDE_IN_1X1", m.RESNETS.STRIDE_IN_1X1, False), ("MODEL.RESNETS.DEPTH == 50", m.RESNETS.DEPTH == 50, True)]
         bad = ["%s=%r (supported: %r)" % (k, v, want) for k, v, want in required if bool(v) != want]
         if bad:
             raise NotImplementedError("hipie_amd builds the shipped eval configuration only; unsupported: " + "; ".join(bad))

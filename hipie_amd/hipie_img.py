@@ -145,18 +145,20 @@ class HIPIE_IMG(nn.Module):
     # ---- hipie_img.py:900-922 -------------------------------------------------------------------------------
     def forward_text(self, batched_inputs, device=None):
         if "input_ids" in batched_inputs[0]:               # synthetic / pre-tokenised path (no vocab on the GPU box)
-            ids = torch.stack([x["input_ids"] for x in batched_inputs]).to(self.device)
-            mask = torch.stack([x["attention_mask"] for x in batched_inputs]).to(self.device)
+            # ids / masks stay where the caller keeps them: host tensors (what a tokenizer produces) let the text encoder trim the
+            # masked tail without a device round trip (BertEncoder.forward)
+            ids = torch.stack([x["input_ids"] for x in batched_inputs])
+            mask = torch.stack([x["attention_mask"] for x in batched_inputs])
             sep = 1012
         else:
             if self.tokenizer is None:
                 raise RuntimeError("no tokenizer assets (projects/HIPIE/bert-base-uncased): pass input_ids/attention_mask")
             captions = [x["expressions"] for x in batched_inputs]
             tok = self.tokenizer(captions, max_length=self.cfg.max_query_len, padding="max_length" if self.cfg.pad_max else "longest",
-                                 return_special_tokens_mask=True, return_tensors="pt", truncation=True).to(self.device)   # hipie_img.py:904-909
+                                 return_special_tokens_mask=True, return_tensors="pt", truncation=True)   # hipie_img.py:904-909
             ids, mask = tok.input_ids, tok.attention_mask
             sep = int(self.tokenizer(".").input_ids[0, 1])                                           # bert_model.py:68-73
-        return self.text_encoder[0]({"input_ids": ids, "attention_mask": mask}, sep=sep)
+        return self.text_encoder[0]({"input_ids": ids, "attention_mask": mask}, sep=sep, compact=True)
 
     @torch.no_grad()
     def forward_raw(self, batched_inputs):

@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from .maskdino import MaskDINOHead
-from .transformer import (MLP, FeatureResizer, NestedTensor, PConv2d, _get_clones, agg_lang_feat, geo_cached, inverse_sigmoid,
+from .transformer import (MLP, FeatureResizer, NestedTensor, PConv2d, _get_clones, agg_lang_feat, expand_tokens, geo_cached, inverse_sigmoid,
                           nested_tensor_from_images)
 
 
@@ -94,11 +94,13 @@ class DDETRSegmUniDN(nn.Module):
         lang = lang_feat_pool if task in ("grounding", "sot") else language_dict_features["hidden"]
         outputs_maskdino, _ = self.mask_dino(features_maskdino)
         outputs_maskdino = self.post_process_maskdino(outputs_maskdino, lang)
+        full_len = None if task in ("grounding", "sot") else language_dict_features.get("full_len")     # PAD_MAX columns dropped by the text encoder
+        outputs_maskdino["pred_logits"] = expand_tokens(outputs_maskdino["pred_logits"], full_len)
 
         outputs = {}
         lvl = hs.shape[0] - 1
         reference = inverse_sigmoid(init_reference if lvl == 0 else inter_references[lvl - 1])
-        outputs["pred_logits"] = self.detr.class_embed[lvl](hs[lvl], lang)
+        outputs["pred_logits"] = expand_tokens(self.detr.class_embed[lvl](hs[lvl], lang), full_len)
         outputs["pred_boxes"] = (self.detr.bbox_embed[lvl](hs[lvl]) + reference).sigmoid()
         outputs["pred_boxious"] = self.detr.iou_head[lvl](hs[lvl])
         outputs["reference_points"] = inter_references[-2, :, :, :2]

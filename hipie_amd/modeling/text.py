@@ -214,15 +214,34 @@ class BertEncoder(nn.Module):
         self.model = BertModel(cfg)
         self.language_dim = cfg.bert_hidden
 
-    def forward(self, x, task=None, sep=1012):
+    def forward(self, x, task=None, sep=1012, compact=False):
+        """x["input_ids"], x["attention_mask"] (B, L) on the host (as a tokenizer hands them over) or on the device ->
+        {"masks", "hidden", "n_keys"[, "full_len"]}.  "n_keys" (when the mask is known on the host -- no device sync is spent on it):
+        the number of leading token columns that hold every attended token, rounded up to 32; the masked keys behind it have
+        probability exactly 0 in the image -> text softmax (fuse_helper.py:96-109: -9e15) and are not computed.
+        compact=True, prompts longer than 512 tokens only: the > 512 branch of the reference leaves the hidden states behind the last
+        chunk ZERO (bert_model.py:118-127), so with PAD_MAX (hipie_img.py:904-909; MAX_QUERY_LEN 4096 in the shipped eval yamls) every padding
+        row of the language stream is the same row all the way to the class logits.  The returned "hidden" / "masks" then hold the
+        first `live` rows only -- every real token plus at least one padding row, `live` a multiple of 32 -- and "full_len" = L: the
+        consumers (fusion, VL_Align) compute `live` columns and repeat the last one (transformer.expand_tokens)."""
         ids, mask = x["input_ids"], x["attention_mask"]
+        dev = self.model.embeddings.word_embeddings.weight.device
         B, L = ids.shape
+        mask_h = None if mask.is_cuda else mask
         if L <= 512:
-            return {"masks": mask, "hidden": self.model(ids, mask)}
+            ids, mask = ids.to(dev), mask.to(dev)
+            out = {"masks": mask, "hidden": self.model(ids, mask)}
+            if mask_h is not None:
+                out["n_keys"] = _n_keys(mask_h)
+            return out
         CLS, EOS = 101, 102
-        chunks = []
-        for b in range(B):       # host-side string-like processing of the token row (bert_model.py:74-110)
-            inp = ids[b].clone()
+        # host-side string-like processing of the token rows (bert_model.py:74-110): on host copies, so that the loop costs no device
+        # round trips (a device-resident prompt pays ONE copy here)
+        ids_h = ids.cpu() if ids.is_cuda else ids
+        mask_h = mask.cpu() if mask_h is None else mask_h
+        chunks, covered = [], 0
+        for b in range(B):
+            inp = ids_h[b].clone()
             begin, start_src = 0, 0
             while True:
                 seps = torch.where((inp == sep) | (inp == EOS))[0]
@@ -232,24 +251,44 @@ class BertEncoder(nn.Module):
                 last = int(seps[-1])
                 first = inp[:last + 1].clone()
                 first[-1] = EOS
-                on = torch.where(mask[b][:last + 1] == 1)[0]
+                on = torch.where(mask_h[b][:last + 1] == 1)[0]         # the reference never advances the mask row (bert_model.py:87)
                 n = len(first)
-                out_mask = torch.zeros(512, dtype=ids.dtype, device=ids.device)
+                out_mask = torch.zeros(512, dtype=ids_h.dtype)
                 if start_src == 0:
-                    row = torch.cat([first, torch.zeros(512 - n, dtype=ids.dtype, device=ids.device)])
+                    row = torch.cat([first, torch.zeros(512 - n, dtype=ids_h.dtype)])
                     out_mask[on] = 1
                 else:
-                    pad = torch.zeros(512 - n - 1, dtype=ids.dtype, device=ids.device)
+                    pad = torch.zeros(512 - n - 1, dtype=ids_h.dtype)
                     pad[0] = sep
-                    row = torch.cat([torch.tensor([CLS], dtype=ids.dtype, device=ids.device), first, pad])
+                    row = torch.cat([torch.tensor([CLS], dtype=ids_h.dtype), first, pad])
                     out_mask[on + 1] = 1
                     out_mask[0] = 1
                 chunks.append((b, row, out_mask, (start_src, start_src + n, begin, begin + n)))
                 start_src = 1
                 inp = inp[n:]
                 begin += n
-        hid = self.model(torch.stack([c[1] for c in chunks]), torch.stack([c[2] for c in chunks]))
-        out = torch.zeros(B, L, hid.shape[-1], dtype=torch.float32, device=ids.device)
+                covered = max(covered, begin)
+        hid = self.model(torch.stack([c[1] for c in chunks]).to(dev), torch.stack([c[2] for c in chunks]).to(dev))
+        attended = _n_attended(mask_h)
+        live = L
+        if compact:
+            # rows >= max(covered, attended) have zero hidden states AND a zero mask: all alike.  Keep one of them.
+            live = min(L, (max(covered, attended) + 1 + 31) // 32 * 32)
+        out = torch.zeros(B, live, hid.shape[-1], dtype=torch.float32, device=dev)
         for i, (b, _, _, (s0, s1, t0, t1)) in enumerate(chunks):
             out[b, t0:t1] = hid[i, s0:s1]
-        return {"masks": mask, "hidden": out}
+        res = {"masks": mask_h[:, :live].to(dev), "hidden": out, "n_keys": min(live, (max(attended, 1) + 31) // 32 * 32)}
+        if live < L:
+            res["full_len"] = L
+        return res
+
+
+def _n_attended(mask_h):
+    """index of the last attended token + 1 over the batch (host tensor)"""
+    nz = torch.nonzero(mask_h.reshape(mask_h.shape[0], -1) != 0)
+    return int(nz[:, 1].max()) + 1 if nz.numel() else 0
+
+
+def _n_keys(mask_h):
+    L = mask_h.shape[1]
+    return min(L, (max(_n_attended(mask_h), 1) + 31) // 32 * 32)

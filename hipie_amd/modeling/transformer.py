@@ -366,13 +366,15 @@ class BiMultiHeadAttention(nn.Module):
         self.out_v_proj, self.out_l_proj = PLinear(embed_dim, v_dim), PLinear(embed_dim, l_dim)
         self.attn_dtype = attn_dtype
 
-    def forward(self, v, l, attention_mask_l=None, gamma_v=None):
+    def forward(self, v, l, attention_mask_l=None, gamma_v=None, n_keys=None):
+        """n_keys: host-known number of leading text columns that hold every attended token (BertEncoder.forward): the image -> text
+        direction of the split policy runs over those keys only -- masked keys have probability exactly 0 (fuse_helper.py:96-109)."""
         B, Nv, _ = v.shape
         L = l.shape[1]
         H, hd, dt = self.num_heads, self.head_dim, self.attn_dtype
         wq, bq = self._scaled_q()                              # v_proj with the 1/sqrt(head_dim) folded in: no (B, Nv, 2048) multiply pass
         if getattr(self, "split", False) and v.is_cuda and self.v_proj.weight.dtype == torch.float32 and hd % 32 == 0 and ops.split_ok(v.shape[-1]):
-            return self._forward_split(v, l, attention_mask_l, gamma_v, wq, bq)
+            return self._forward_split(v, l, attention_mask_l, gamma_v, wq, bq, n_keys)
         # the GEMM epilogue rounds to the attention operand dtype itself (bit-identical to fp32 out + .to(fp16), minus
         # a 178M-element cast pass per visual projection)
         of = ops.F16 if (getattr(self, "split", False) and dt == torch.float16) else ops.F32
@@ -388,7 +390,7 @@ class BiMultiHeadAttention(nn.Module):
         wo, bo = self._scaled_out(gamma_v)
         return _lin(self, "out_scaled", ov, wo, bo).to(self.out_v_proj.out_dtype), self.out_l_proj(ol)
 
-    def _forward_split(self, v, l, attention_mask_l, gamma_v, wq, bq):
+    def _forward_split(self, v, l, attention_mask_l, gamma_v, wq, bq, n_keys=None):
         """Precision.split3.  image -> text (the update of the 21760-token visual stream, whose error the decoder amplifies): fp32-class
         -- S = Q.K^T per (image, head) as one batched split GEMM from the HL8 projection, masked softmax -> HL8, P.V_text as the second
         batched GEMM (ops.bi_i2t_split).  text -> image (the language stream; its softmax averages over all visual tokens): the fp16
@@ -408,7 +410,7 @@ class BiMultiHeadAttention(nn.Module):
         vv16 = self.values_v_proj(vh, x_hl8=True, out_fmt=ops.F16).view(B, Nv, H, hd)
         k32 = self.l_proj(l)
         vl32 = self.values_l_proj(l)
-        ov = ops.bi_i2t_split(q_hl8.view(B, Nv, -1), k32.view(B, L, -1), vl32.view(B, L, -1), keep, H, clamp=50000.0)
+        ov = ops.bi_i2t_split(q_hl8.view(B, Nv, -1), k32.view(B, L, -1), vl32.view(B, L, -1), keep, H, clamp=50000.0, n_keys=n_keys)
         # text -> image: queries = text tokens, keys / values = visual tokens, no mask on that side (fuse_helper.py:85-95)
         ol = ops.flash_attn(k32.half().view(B, L, H, hd), q16, vv16, 1.0, clamp=50000.0, out_f32=True)
         if gamma_v is None:
@@ -444,9 +446,9 @@ class BiAttentionBlockForCheckpoint(nn.Module):
         self.gamma_v = nn.Parameter(init_values * torch.ones(v_dim))
         self.gamma_l = nn.Parameter(init_values * torch.ones(l_dim))
 
-    def forward(self, v, l, attention_mask_l=None, task=None):
+    def forward(self, v, l, attention_mask_l=None, task=None, n_keys=None):
         v, l = self.layer_norm_v(v), self.layer_norm_l(l)
-        dv, dl = self.attn(v, l, attention_mask_l=attention_mask_l, gamma_v=self.gamma_v)
+        dv, dl = self.attn(v, l, attention_mask_l=attention_mask_l, gamma_v=self.gamma_v, n_keys=n_keys)
         # gamma_v is folded into the visual output projection (weights only), so the 21760-token stream stays in its own
         # dtype: `v + gamma_v * dv` would promote it to fp32 and every later encoder GEMM would cast it back
         return v + dv.to(v.dtype), l + self.gamma_l * dl
@@ -462,7 +464,7 @@ class VLFuse(nn.Module):
 
     def forward(self, x, task=None):
         lang = x["lang"]
-        fv, fl = self.b_attn(x["visual"], lang["hidden"], lang["masks"], task)
+        fv, fl = self.b_attn(x["visual"], lang["hidden"], lang["masks"], task, n_keys=lang.get("n_keys"))
         lang["hidden"] = fl
         return {"visual": fv, "lang": lang}
 
@@ -782,6 +784,18 @@ def get_valid_ratio(mask):
     vh = torch.sum(~mask[:, :, 0], 1).float() / H
     vw = torch.sum(~mask[:, 0, :], 1).float() / W
     return torch.stack([vw, vh], -1)
+
+
+def expand_tokens(logits, full_len):
+    """(..., live) per-token logits -> (..., full_len): BertEncoder(compact=True) dropped the padding rows behind `live` because they
+    are all the same row (zero hidden state, zero mask: bert_model.py:118-127); their class logits are the last computed column."""
+    n = logits.shape[-1]
+    if full_len is None or n >= full_len:
+        return logits
+    out = logits.new_empty(*logits.shape[:-1], full_len)
+    out[..., :n] = logits
+    out[..., n:] = logits[..., -1:]
+    return out
 
 
 def agg_lang_feat(features, mask):

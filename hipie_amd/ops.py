@@ -212,17 +212,21 @@ def flash_attn(q, k, v, scale, bias_h=None, bias_w=None, key_mask=None, clamp=0.
 
 
 @_timed("bi_i2t_split")
-def bi_i2t_split(q_hl8, k, vl, text_mask, heads, clamp=50000.0):
+def bi_i2t_split(q_hl8, k, vl, text_mask, heads, clamp=50000.0, n_keys=None):
     """image -> text direction of the vision-language fusion at fp32-class accuracy (fuse_helper.py:77-121):
         out_v[b, i, h] = softmax_j( clamp(q[b,i,h] . k[b,j,h]) over the text tokens kept by text_mask ) . vl[b, j, h]
     q_hl8 (B, Nv, 2*E) HL8 (E = heads * hd; the scaled v_proj output straight from the GEMM epilogue), k, vl (B, L, E) fp32,
     text_mask (B, L) -> (B, Nv, E) fp32.  Texts of up to 256 tokens: TWO launches -- the batched logits GEMM with the masked row softmax in
     its epilogue (P as HL8; S never exists) and P_h.V_h as the second batched GEMM; longer texts: S = Q_h.K_h^T, hipie_softmax_hl8, P_h.V_h; the text-side operands (L x E) are padded to a
-    multiple of 32 tokens and split on the way."""
+    multiple of 32 tokens and split on the way.  n_keys (host int, optional): every attended token sits in the first n_keys columns --
+    the masked keys behind them have probability exactly 0 (-9e15 before the softmax) and are left out, so a PAD_MAX prompt (4096
+    columns, 194 of them attended) costs what its real tokens cost and nothing of size Nv x L is allocated."""
     lib = _lib.load()
     B, Nv, E2 = q_hl8.shape
     E = E2 // 2
     hd = E // heads
+    if n_keys is not None and 0 < n_keys < k.shape[1]:
+        k, vl, text_mask = k[:, :n_keys], vl[:, :n_keys], text_mask[:, :n_keys]
     L = k.shape[1]
     Lp = (L + 31) // 32 * 32
     if q_hl8.dtype != torch.float16 or not q_hl8.is_contiguous() or k.dtype != torch.float32 or vl.dtype != torch.float32 or hd % 32:

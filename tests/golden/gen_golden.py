@@ -428,7 +428,10 @@ def gen_e2e_full_refinit():
     print("e2e_full_refinit: %.0f s" % (time.time() - t0))
 
 
-def gen_e2e(c=None, name="e2e_tiny", tasks=(("detection", 9), ("grounding", 1)), sizes=((200, 256), (256, 224)), dist=None):
+def gen_e2e(c=None, name="e2e_tiny", tasks=(("detection", 9), ("grounding", 1)), sizes=((200, 256), (256, 224)), dist=None,
+            imgs=None, prompts=None, extra_meta=None):
+    """imgs / prompts: explicit inputs instead of the _synth ones -- prompts = {task: (ids (B, L), mask (B, L), pmap)} (gen_e2e_full_c80: the
+    inputs bench.py times)."""
     c = c or TINY
     model = build_ref_model(c)
     bert = build_ref_bert(c)
@@ -437,7 +440,7 @@ def gen_e2e(c=None, name="e2e_tiny", tasks=(("detection", 9), ("grounding", 1)),
     full_man = {"detr." + k: v for k, v in man.items()}
     full_man.update({"text_encoder.body." + k: v for k, v in man_b.items()})
     sizes = [tuple(s_) for s_ in sizes]
-    imgs = _synth.synth_images(sizes, seed=73)
+    imgs = _synth.synth_images(sizes, seed=73) if imgs is None else imgs
     mean = torch.tensor(c["pixel_mean"]).view(3, 1, 1)
     std = torch.tensor(c["pixel_std"]).view(3, 1, 1)
     # HIPIE_IMG.preprocess_image (hipie_img.py:880-898): normalise, ImageList.from_tensors (pad to max HxW)
@@ -450,6 +453,7 @@ def gen_e2e(c=None, name="e2e_tiny", tasks=(("detection", 9), ("grounding", 1)),
     arrays, meta = {}, dict(cfg=c, manifest=man_json(full_man), sizes=sizes)
     if dist is not None:
         meta["dist"] = "refinit"
+    meta.update(extra_meta or {})
     topk_log = []
     real_topk = torch.topk
 
@@ -460,7 +464,10 @@ def gen_e2e(c=None, name="e2e_tiny", tasks=(("detection", 9), ("grounding", 1)),
     for spec in tasks:
         task, ncls = spec[0], spec[1]
         max_len, pad_to = (spec[2], spec[3]) if len(spec) > 2 else (64, None)
-        ids, mask, pmap = _synth.synth_token_ids(2, ncls, max_len, seed=74, pad_to=pad_to)
+        if prompts is not None:
+            ids, mask, pmap = prompts[task]
+        else:
+            ids, mask, pmap = _synth.synth_token_ids(2, ncls, max_len, seed=74, pad_to=pad_to)
         ids, mask = ids[:len(sizes)], mask[:len(sizes)]          # one prompt row per image (rows are generated independently)
         lang = bert({"input_ids": ids, "attention_mask": mask}, sep=1012)
         arrays[task + "_lang_hidden"] = lang["hidden"].clone()
@@ -517,6 +524,33 @@ def gen_e2e_full():
     print("e2e_full: %.0f s" % (time.time() - t0))
 
 
+def gen_e2e_full_c80():
+    """The workload bench.py TIMES, literally (BASELINE configs[2]): the full ViT-H and the shipped head sizes on image 0 of
+    bench.synth_batch (1024 x 1024) with the 80-class caption (L = 194 tokens), plus the separate grounding call of the same configuration
+    (one referring expression, L = 12: tasks cannot mix, hipie_img.py:285), both through the reference's own coco_inference on the CPU.
+    The test side rebuilds the inputs with bench.synth_batch (meta["bench_inputs"])."""
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import bench
+    t0 = time.time()
+    size, ncls, L = 1024, 80, 194
+    det = bench.synth_batch(None, 1, size, ncls, L, "cpu", seed=0, task="detection")
+    gnd = bench.synth_batch(None, 1, size, ncls, L, "cpu", seed=0, task="grounding")
+    assert torch.equal(det[0]["image"], gnd[0]["image"])
+    prompts = {"detection": (det[0]["input_ids"][None], det[0]["attention_mask"][None], det[0]["positive_map_label_to_token"]),
+               "grounding": (gnd[0]["input_ids"][None], gnd[0]["attention_mask"][None], {1: list(range(1, 11))})}
+    gen_e2e(FULL, "e2e_full_c80", (("detection", ncls), ("grounding", 1)), sizes=((size, size),), imgs=[det[0]["image"]], prompts=prompts,
+            extra_meta={"bench_inputs": dict(size=size, n_classes=ncls, L=L, seed=0, batch=1)})
+    print("e2e_full_c80: %.0f s" % (time.time() - t0))
+
+
+def gen_e2e_padmax():
+    """MODEL.LANGUAGE_BACKBONE.PAD_MAX with MAX_QUERY_LEN 4096, the shipped eval setting (configs/eval/image_joint_vit_huge_32g_pan_maskdino_ade_test.yaml:10-11,
+    hipie_img.py:904-909): the e2e_tiny inputs with the 9-class caption padded to 4096 tokens.  BertEncoder's > 512 branch then leaves the
+    hidden states of the padding zero (bert_model.py:118-127) and the fusion / class-logit stages run over 4096 mostly-masked columns."""
+    gen_e2e(TINY, "e2e_padmax_tiny", (("detection", 9, 64, 4096),))
+
+
 # ------------------------------------------------------------------------------ sub-module goldens from the e2e model
 def gen_stages(c=None, name="stages_tiny", sizes=((200, 256), (256, 224))):
     """Intermediate tensors of the same tiny model (detection task), for stage-by-stage checks:
@@ -527,7 +561,7 @@ def gen_stages(c=None, name="stages_tiny", sizes=((200, 256), (256, 224))):
     _synth.load_synth(model, seed=71)
     _synth.load_synth(bert, seed=72)
     sizes = [tuple(s_) for s_ in sizes]
-    imgs = _synth.synth_images(sizes, seed=73)
+    imgs = _synth.synth_images(sizes, seed=73) if imgs is None else imgs
     mean = torch.tensor(c["pixel_mean"]).view(3, 1, 1)
     std = torch.tensor(c["pixel_std"]).view(3, 1, 1)
     batched = torch.zeros(len(sizes), 3, max(s_[0] for s_ in sizes), max(s_[1] for s_ in sizes))
@@ -766,7 +800,8 @@ def gen_manifest_full():
 
 
 ALL = dict(manifest_full=gen_manifest_full, prompts=gen_prompts, post=gen_post, resnet50=gen_resnet50, msda=gen_msda, msda_bwd=gen_msda_bwd, vit_attn=gen_vit_attn, vit_backbone=gen_vit_backbone, bi_attn=gen_bi_attn, bert=gen_bert,
-           dynamic_mask=gen_dynamic_mask, e2e=gen_e2e, stages=gen_stages, stages_full=gen_stages_full, e2e_r50=gen_e2e_r50, e2e_long=gen_e2e_long, e2e_deep=gen_e2e_deep, e2e_full=gen_e2e_full, maskclip=gen_maskclip, refinit_stats=gen_refinit_stats, e2e_full_refinit=gen_e2e_full_refinit)
+           dynamic_mask=gen_dynamic_mask, e2e=gen_e2e, stages=gen_stages, stages_full=gen_stages_full, e2e_r50=gen_e2e_r50, e2e_long=gen_e2e_long, e2e_deep=gen_e2e_deep, e2e_full=gen_e2e_full, maskclip=gen_maskclip, refinit_stats=gen_refinit_stats, e2e_full_refinit=gen_e2e_full_refinit, e2e_full_c80=gen_e2e_full_c80,
+           e2e_padmax=gen_e2e_padmax)
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)

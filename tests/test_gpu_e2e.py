@@ -120,6 +120,64 @@ def test_e2e_long_prompt(policy, tol):
         assert errs[k] < tol, (k, errs[k])
 
 
+def test_e2e_pad_max_4096_is_trimmed():
+    """The shipped eval setting (MODEL.LANGUAGE_BACKBONE.PAD_MAX, MAX_QUERY_LEN 4096: configs/eval/image_joint_vit_huge_32g_pan_maskdino_ade_test.yaml:10-11,
+    hipie_img.py:904-909) in the TIMED policy against the reference's own coco_inference on the same 4096-column inputs
+    (tests/golden/e2e_padmax_tiny.npz): every a22 output -- the 4096-column class logits included -- within 1e-3, AND the padding is free:
+    the text encoder hands the fusion the real tokens plus one padding row (their hidden states are zero in the reference,
+    bert_model.py:118-127, so all padding rows / columns are alike), the image -> text softmax runs over the attended keys only
+    (masked keys have probability exactly 0, fuse_helper.py:96-109), and nothing of size Nv x 4096 is allocated."""
+    from hipie_amd.config import Precision
+    g, model = build(Precision.split3(), "e2e_padmax_tiny")
+    model.pin_topk(g["detection_topk_fg"], g["detection_topk_md"])
+    batch = inputs(g, "detection")
+    assert batch[0]["input_ids"].shape[0] == 4096 and int(batch[0]["attention_mask"].sum()) < 64
+    short = [dict(b, input_ids=b["input_ids"][:64], attention_mask=b["attention_mask"][:64]) for b in batch]
+    model.forward_raw(short)                       # same weights, same images, the caption unpadded: the memory yard-stick
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    model.forward_raw(short)
+    torch.cuda.synchronize()
+    peak_short = torch.cuda.max_memory_allocated()
+    torch.cuda.reset_peak_memory_stats()
+    out = model.forward_raw(batch)
+    torch.cuda.synchronize()
+    peak_pad = torch.cuda.max_memory_allocated()
+    errs = {k: rel_err(g.like("detection_" + k, out[k].float().cpu()), g["detection_" + k]) for k in KEYS}
+    print("PAD_MAX 4096, split policy: " + " ".join("%s=%.1e" % kv for kv in errs.items()))
+    assert out["pred_logits"].shape[-1] == 4096 and out["pred_logits_maskdino"].shape[-1] == 4096
+    for k in KEYS:
+        assert errs[k] < 1e-3, (k, errs[k])
+    B = len(batch)
+    Nv = sum((256 // s) ** 2 for s in (8, 16, 32, 64))
+    one_score_tensor = B * 8 * Nv * 4096 * 4             # S (fp32) = P (HL8) bytes of the untrimmed image -> text direction
+    print("peak memory: unpadded %.1f MB, PAD_MAX %.1f MB (an Nv x 4096 score tensor would be %.1f MB)"
+          % (peak_short / 2 ** 20, peak_pad / 2 ** 20, one_score_tensor / 2 ** 20))
+    assert peak_pad - peak_short < one_score_tensor // 8
+
+
+@pytest.mark.parametrize("task", ["detection", "grounding"])
+def test_e2e_full_size_bench_inputs(task):
+    """the workload bench.py TIMES, literally (BASELINE configs[2]): full ViT-H, shipped head sizes, image 0 of bench.synth_batch at
+    1024 x 1024, the 80-class caption (L = 194) -- and the separate grounding call (one referring expression) -- in the timed policy
+    against tests/golden/e2e_full_c80.npz = the reference's own coco_inference on those inputs."""
+    import os
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "e2e_full_c80.npz")):
+        pytest.skip("tests/golden/e2e_full_c80.npz not generated")
+    import bench
+    from hipie_amd.config import Precision
+    g, model = build(Precision.split3(), "e2e_full_c80")
+    bi = g.meta["bench_inputs"]
+    batch = bench.synth_batch(None, 1, bi["size"], bi["n_classes"], bi["L"], "cpu", seed=bi["seed"], task=task)
+    assert batch[0]["input_ids"].shape[0] == g.meta[task]["L"]
+    model.pin_topk(g[task + "_topk_fg"], g[task + "_topk_md"])
+    out = model.forward_raw(batch)
+    errs = {k: rel_err(g.like(task + "_" + k, out[k].float().cpu()), g[task + "_" + k]) for k in KEYS}
+    print("split3, FULL SIZE, bench inputs (%s, L = %d): " % (task, g.meta[task]["L"]) + " ".join("%s=%.1e" % kv for kv in errs.items()))
+    for k in KEYS:
+        assert errs[k] < 1e-3, (k, errs[k])
+
+
 @pytest.mark.parametrize("policy", ["split3", "parity"])          # split3 = the registry default / the timed policy
 def test_e2e_tiny_free_topk_overlap(policy):
     """un-pinned selection: the product's own two-stage top-k (hipie_topk) picks >= 90 % of the reference's queries"""

@@ -315,7 +315,8 @@ def _eval_cfg(**over):
                     LOOK_FORWARD_TWICE=True, BG_QUERY_FROM_LANG=False, NEW_MASK_HEAD=False, USE_RAFT=False, USE_REL_COORD=True),
         LANGUAGE_BACKBONE=dict(LANG_DIM=768, MAX_QUERY_LEN=8192, PAD_MAX=True), DYHEAD=dict(LOG_SCALE=0.0, PRIOR_PROB=0.01),
         CLIP=dict(ENABLED=False, ENABLED_TRAIN=False, NAME="ViT-B-32", ALPHA=0.35, BETA=0.7, FG_IOU_A=0.3, FG_IOU_B=1.7, AGG_MODE="MUL"),
-        PANO_TEMPERATURE_CLIP_FG=0.06, MASKDINO=dict(CONFIG_PATH="unused"))
+        PANO_TEMPERATURE_CLIP_FG=0.06, MASKDINO=dict(CONFIG_PATH="unused", ENABLED=True, SHARE_CLS_HEAD=False, FIXED_LINEAR_HEAD=False),
+        MASK_ON=True, RESNETS=dict(DEPTH=50, STRIDE_IN_1X1=False))
     cfg = dict(MODEL=model, TEST=dict(USE_BG_FOR_PANO_ON=True, BG_CLS_AGNOSTIC=False, MAX_POOL=False))
     for path, v in over.items():
         node = cfg

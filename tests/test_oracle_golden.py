@@ -165,6 +165,49 @@ def test_e2e_long_prompt():
         assert rel_err(g.like("detection_" + k, out[k]), g["detection_" + k]) < 2e-4, k
 
 
+def test_e2e_pad_max_4096():
+    """MODEL.LANGUAGE_BACKBONE.PAD_MAX at MAX_QUERY_LEN 4096 (the shipped eval yamls; hipie_img.py:904-909): a 9-class caption padded to 4096
+    tokens through the > 512 branch of BertEncoder -- the hidden states of the padding stay ZERO (bert_model.py:118-127), fusion and class
+    logits run over 4096 mostly-masked columns.  Also pins what the product's trimming relies on: every padding row of the reference's
+    language stream and every padding column of its class logits is the same row / column."""
+    g = Golden("e2e_padmax_tiny")
+    cfg, sd, imgs, ids, mask = e2e_inputs(g, "detection")
+    assert ids.shape[1] == 4096 and int(mask.sum(1).max()) < 64
+    lang = om.bert_encoder(ids, mask, sd, "text_encoder.body.model.", cfg)
+    n_real = int(mask.sum(1).max())
+    assert float(lang["hidden"][:, n_real:].abs().max()) == 0.0
+    assert rel_err(g.like("detection_lang_hidden", lang["hidden"]), g["detection_lang_hidden"]) < 5e-5
+    out = om.coco_inference(imgs, lang, sd, cfg, task="detection", topk_fg=g["detection_topk_fg"], topk_md=g["detection_topk_md"])
+    for k in E2E_KEYS:
+        assert rel_err(g.like("detection_" + k, out[k]), g["detection_" + k]) < 2e-4, k
+    for k in ("pred_logits", "pred_logits_maskdino"):
+        pad = out[k][..., n_real:]
+        assert float((pad - pad[..., :1]).abs().max()) <= 1e-5 * float(out[k].abs().max()), k
+
+
+def test_e2e_full_c80_bench_inputs():
+    """the workload bench.py times (BASELINE configs[2]: ViT-H, 1024 x 1024, image 0 of bench.synth_batch, 80-class caption of 194 tokens,
+    and the separate grounding call): the oracle against the reference's own coco_inference on those inputs (~2 min of CPU per task: the
+    grounding half only with HIPIE_SLOW_TESTS=1, to keep the CPU suite short)."""
+    import os
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "e2e_full_c80.npz")):
+        pytest.skip("tests/golden/e2e_full_c80.npz not generated")
+    import bench
+    g = Golden("e2e_full_c80")
+    bi = g.meta["bench_inputs"]
+    cfg = g.meta["cfg"]
+    sd = _synth.synth_full_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}, dist=g.meta.get("dist"))
+    for task in ("detection", "grounding") if os.environ.get("HIPIE_SLOW_TESTS") == "1" else ("detection",):
+        b = bench.synth_batch(None, 1, bi["size"], bi["n_classes"], bi["L"], "cpu", seed=bi["seed"], task=task)[0]
+        ids, mask = b["input_ids"][None], b["attention_mask"][None]
+        assert ids.shape[1] == g.meta[task]["L"]
+        lang = om.bert_encoder(ids, mask, sd, "text_encoder.body.model.", cfg)
+        assert rel_err(g.like(task + "_lang_hidden", lang["hidden"]), g[task + "_lang_hidden"]) < 5e-5
+        out = om.coco_inference([b["image"]], lang, sd, cfg, task=task, topk_fg=g[task + "_topk_fg"], topk_md=g[task + "_topk_md"])
+        for k in E2E_KEYS:
+            assert rel_err(g.like(task + "_" + k, out[k]), g[task + "_" + k]) < 2e-4, (task, k)
+
+
 @pytest.mark.parametrize("task", ["detection", "grounding"])
 def test_e2e_r50_tiny(task):
     """BASELINE configs[0] (R50, one text prompt: grounding) / [1] (R50, class prompts): a22 against the reference run behind its own
