@@ -338,7 +338,9 @@ def main():
     from hipie_amd.hipie_img import HIPIE_IMG
     from hipie_amd.postprocess import inference, inference_compact
 
-    rank, world, local = parallel.init_from_env()
+    # N = 1 opens a ONE-rank "nccl" process group, so the step's all-gather and the timing all-reduce run through RCCL exactly as at
+    # N > 1 (dp.backend says which backend really ran; null = the group could not be created and the collectives are identities)
+    rank, world, local = parallel.init_from_env(single_rank_group=True)
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or "
                          "run `python bench.py --gpus %d` without a WORLD_SIZE in the environment)" % (args.gpus, world, args.gpus, args.gpus))
@@ -429,6 +431,7 @@ def main():
     if args.timed_only:
         if rank == 0:
             print(json.dumps({"ms_per_step": round(dt / args.steps * 1e3, 2), "images_per_sec": round(args.batch * world * args.steps / dt, 3)}))
+        parallel.shutdown()
         return
 
     # dominant hand-written kernel, timed live with HIP events on the launch stream: the same 24 launches per step of the
@@ -661,6 +664,7 @@ def main():
                 line["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
         print(json.dumps(line))
     parallel.barrier()
+    parallel.shutdown()
 
 
 if __name__ == "__main__":

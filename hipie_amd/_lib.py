@@ -61,6 +61,7 @@ SIGNATURES = {
     "hipie_conv3x3_split": [c_p, c_l, c_p, c_p, c_p, c_l, c_l] + [c_i] * 6 + [c_p],
     "hipie_ffn_fused": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p],
     "hipie_topk": [c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p],
+    "hipie_fill_rows": [c_p, c_l, c_p, c_l, c_p, c_l, c_p],
     "hipie_to_hl8": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_f, c_p],
     "hipie_selftest": [c_i, c_p, c_p, c_p, c_p],
 }

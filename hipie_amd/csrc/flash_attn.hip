@@ -584,12 +584,14 @@ static int flash_attn_impl(FAParams p, int hd, int dtype, void* stream) {
   HIPIE_REQUIRE((((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v | (uintptr_t)p.out) & 15) == 0, "flash_attn: pointers must be 16-byte aligned");
   p.swz = ((p.B * p.H) % 8 == 0) ? 1 : 0;
   p.defer = ((dtype & ~HIPIE_OUT_F32) == HIPIE_F16) ? 0.f : kDefer;      // fp16 = parity policy: classic running max
-  { const char* d = getenv("HIPIE_FA_DEFER"); if (d) p.defer = (float)atof(d); }
+  // diagnostic switches: read from the environment once per process
+  { static const float defer_env = [] { const char* d = getenv("HIPIE_FA_DEFER"); return d ? (float)atof(d) : -1.f; }();
+    if (defer_env >= 0.f) p.defer = defer_env; }
   { static int prio = -1; if (prio < 0) { const char* e = getenv("HIPIE_FA_PRIO"); prio = e ? atoi(e) : 1; } p.prio = prio; }   // +1.5 % (tools/bench_attn.py)
   // 8 waves (256 queries) per workgroup halve the K/V traffic per query but keep all waves of a CU in lockstep
   bool wide = false;       // measured: two independent 4-wave workgroups per CU (1.09 ms) beat one 8-wave workgroup (1.16 ms)
-  const char* e = getenv("HIPIE_FA_WAVES");
-  if (e && (e[0] == '4' || e[0] == '8')) wide = (e[0] == '8');
+  static const int waves_env = [] { const char* e = getenv("HIPIE_FA_WAVES"); return (e && (e[0] == '4' || e[0] == '8')) ? e[0] - '0' : 0; }();
+  if (waves_env) wide = (waves_env == 8);
   hipStream_t st = (hipStream_t)stream;
   p.out_f32 = (dtype & HIPIE_OUT_F32) ? 1 : 0;
   dtype &= ~HIPIE_OUT_F32;

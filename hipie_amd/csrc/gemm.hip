@@ -615,7 +615,7 @@ static int launch_gemm_small(GemmParams& p, hipStream_t st) {
 }
 
 #ifdef HIPIE_GEMM_VARIANTS
-#include "gemm_overlap_study.h"
+#include "../../tools/ubench/gemm_overlap_study.h"     // round-4 timing study: not part of the product, lives with the micro-benchmarks
 #endif
 
 template <int BN, bool SPLIT, int VAR = 0>
@@ -701,16 +701,16 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, con
   // K = 256 linears over many rows with a plain fp32 result: the thin-K kernel (gemm_k256.hip: X rows live in registers, the weight
   // streams through LDS in 32-feature chunks) where it is faster than the 256-column tiles -- N >= 384 (tools/bench_gemm_k256.py: -20 % at
   // N = 384, -7 % at 1024, -9 % at 2304; level at N = 256).  HIPIE_GEMM_K256=0: never, =1: every eligible shape (A/B timing)
-  const char* k256_env = getenv("HIPIE_GEMM_K256");
-  const int k256_mode = k256_env ? atoi(k256_env) : 2;
+  // (diagnostic switches are read from the environment ONCE per process, not per launch)
+  static const int k256_mode = [] { const char* e = getenv("HIPIE_GEMM_K256"); return e ? atoi(e) : 2; }();
   const bool k256_on = k256_mode == 1 || (k256_mode == 2 && N >= 384);
+  // the thin-K kernel addresses X rows with 32-bit offsets from the base of the whole matrix: M rows must stay below 4 GiB
   if (k256_on && split && K == 256 && out_fmt == HIPIE_F32 && act == 0 && resid == nullptr && out_row == nullptr && a_row == nullptr &&
-      alpha == 1.f && oscale == 1.f && N % 32 == 0 && M >= 8192 && ldw * 2 == 1024)
+      alpha == 1.f && oscale == 1.f && N % 32 == 0 && M >= 8192 && ldw * 2 == 1024 && (long)M * p.lda_b < (1L << 32))
     return launch_gemm_k256(A, p.lda_b, a_f32 ? 1 : 0, W, p.ldw_b, bias, (float*)out, ldo, M, N, st);
   const bool wide = (N % 320 == 0);
   // problems that fill less than 3/8 of the CUs with 256-row tiles go to the 64 x 128 tile kernel (HIPIE_GEMM_SMALL=0: never; A/B timing)
-  static int small_on = -1;
-  if (small_on < 0) { const char* e = getenv("HIPIE_GEMM_SMALL"); small_on = e ? atoi(e) : 1; }
+  static const int small_on = [] { const char* e = getenv("HIPIE_GEMM_SMALL"); return e ? atoi(e) : 1; }();
   const bool small_ok = small_on && (long)((M + 255) / 256) * ((N + (wide ? 319 : 255)) / (wide ? 320 : 256)) < 96;
 #ifdef HIPIE_GEMM_VARIANTS
   { const char* e = getenv("HIPIE_GEMM_VARIANT"); const int v = e ? atoi(e) : 0;

@@ -36,7 +36,32 @@ __global__ __launch_bounds__(256) void box_refine_kernel(const Td* __restrict__ 
   out[i] = 1.f / (1.f + expf(-v));
 }
 
+// dst row rows[i] <- the ONE source row (row_bytes a multiple of 16): e.g. the HL8 bias row into the padding rows of a window-layout qkv
+// buffer.  One workgroup per destination row, 16-byte stores.
+__global__ __launch_bounds__(256) void fill_rows_kernel(char* __restrict__ dst, long ld_bytes, const int* __restrict__ rows,
+                                                        const char* __restrict__ src, int row_bytes) {
+  const long r = rows[blockIdx.x];
+  if (r < 0) return;
+  char* d = dst + r * ld_bytes;
+  for (int o = threadIdx.x * 16; o < row_bytes; o += 256 * 16)
+    *reinterpret_cast<uint4*>(d + o) = *reinterpret_cast<const uint4*>(src + o);
+}
+
 }  // namespace hipie
+
+extern "C" int hipie_fill_rows(void* dst, int64_t ld_bytes, const int32_t* rows, int64_t n_rows, const void* src_row, int64_t row_bytes,
+                               void* stream) {
+  using namespace hipie;
+  HIPIE_REQUIRE(n_rows >= 0 && n_rows < (1L << 31), "fill_rows: n_rows=%ld", (long)n_rows);
+  if (n_rows == 0) return HIPIE_OK;
+  HIPIE_REQUIRE(dst && rows && src_row, "fill_rows: null pointer");
+  HIPIE_REQUIRE(row_bytes > 0 && row_bytes % 16 == 0 && row_bytes < (1L << 30) && ld_bytes >= row_bytes && ld_bytes % 16 == 0 &&
+                ((uintptr_t)dst % 16) == 0 && ((uintptr_t)src_row % 16) == 0, "fill_rows: rows of %ld bytes, stride %ld (16-byte units)",
+                (long)row_bytes, (long)ld_bytes);
+  hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, (char*)dst, (long)ld_bytes, rows,
+                     (const char*)src_row, (int)row_bytes);
+  return check_launch("fill_rows");
+}
 
 extern "C" int hipie_sine_embed(const float* ref, const float* dim_t, void* out, int64_t n, int n_coord, int num_pos_feats,
                                 int ref_stride, float scale, int out_dtype, void* stream) {

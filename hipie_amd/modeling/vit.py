@@ -71,6 +71,78 @@ def window_unpartition(win, ws, pad_hw, hw):
 
 
 _ROW_MAPS = {}
+_PAD_ROWS = {}
+
+
+def window_pad_rows(out_src):
+    """int32 indices of the PADDING rows of the window layout (out_src < 0), cached per row map: computed once per geometry (the
+    nonzero is a host round trip), not per block."""
+    key = (out_src.data_ptr(), out_src.numel(), str(out_src.device))
+    r = _PAD_ROWS.get(key)
+    if r is None:
+        r = _PAD_ROWS[key] = torch.nonzero(out_src < 0).flatten().to(torch.int32).contiguous()
+    return r
+
+
+class _QkvBuffers(object):
+    """window-layout qkv buffers of the windowed ViT blocks (split policy).  The qkv GEMM of such a block runs over the REAL tokens only
+    and scatters into the window layout; the padding rows hold the HL8 qkv bias.  Two ways to provide them:
+
+      persistent   one buffer per (block, geometry), stored ON the block (it dies with the model) with its padding rows written once:
+                   nothing to refill per step (0.6 GB per block at ViT-H bs 8, 4.9 GB for the 8 windowed blocks) -- while the buffers of
+                   all LIVE blocks of the process fit the budget (HIPIE_QKV_CACHE_GB, default 8 GiB; least recently used buffers of OTHER
+                   geometries are dropped first, so alternating image sizes do not accumulate);
+      shared       beyond the budget (large per-GPU batches): ONE scratch buffer per geometry for all blocks, the padding rows re-written
+                   by hipie_fill_rows in front of every block's qkv GEMM (99 MB per block at bs 8) -- memory stays bounded.
+    """
+
+    def __init__(self):
+        import collections
+        import os
+        self.budget = int(float(os.environ.get("HIPIE_QKV_CACHE_GB", "8")) * (1 << 30))
+        self.entries = collections.OrderedDict()          # id(block) -> (weakref(block), geometry key, bytes); the buffer is on the block
+        self.shared = {}                                  # geometry key -> scratch buffer
+
+    def _live_bytes(self):
+        for k in [k for k, e in self.entries.items() if e[0]() is None]:
+            del self.entries[k]
+        return sum(e[2] for e in self.entries.values())
+
+    def get(self, owner, rows, width, device, pad_rows, bias_row, bias_ver):
+        import weakref
+        key = (rows, width, str(device))
+        st = owner.__dict__.get("_qkv_state")
+        if st is not None and st[0] == key:
+            if id(owner) in self.entries:
+                self.entries.move_to_end(id(owner))
+            if st[2] != bias_ver:                           # new weights: re-write the padding rows
+                ops.fill_rows(st[1], pad_rows, bias_row)
+                owner._qkv_state = (key, st[1], bias_ver)
+            return st[1]
+        owner._qkv_state = None                             # another geometry: this block's old buffer goes first
+        self.entries.pop(id(owner), None)
+        need = rows * width * 2
+        while self._live_bytes() + need > self.budget:      # then least recently used buffers of OTHER geometries
+            victim = next((k for k, e in self.entries.items() if e[1] != key), None)
+            if victim is None:
+                break
+            blk = self.entries.pop(victim)[0]()
+            if blk is not None:
+                blk._qkv_state = None
+        if self._live_bytes() + need <= self.budget:
+            buf = torch.empty(rows, width, dtype=torch.float16, device=device)
+            ops.fill_rows(buf, pad_rows, bias_row)
+            owner._qkv_state = (key, buf, bias_ver)
+            self.entries[id(owner)] = (weakref.ref(owner), key, need)
+            return buf
+        buf = self.shared.get(key)
+        if buf is None:
+            self.shared.clear()                             # one geometry at a time in the shared mode
+            buf = self.shared[key] = torch.empty(rows, width, dtype=torch.float16, device=device)
+        return ops.fill_rows(buf, pad_rows, bias_row)
+
+
+QKV_BUFFERS = _QkvBuffers()
 
 
 def window_row_maps(B, H, W, ws, device):
@@ -180,14 +252,12 @@ class Attention(nn.Module):
             # padding rows are filled with the HL8 bias row
             rows = y.shape[0]
             w_, b_, _ = ops.split_weight(self, "qkv", [self.qkv.weight, self.qkv.bias], wq, bq)
-            pk = (rows, out_row.data_ptr(), str(y.device), self._versions())
-            if getattr(self, "_pad_key", None) != pk:
-                # a per-block qkv buffer in the window layout whose padding rows hold the bias ONCE (0.6 GB per windowed block at bs 8:
-                # HBM is sized for it; refilling 99 MB of padding rows per block and step cost 1 ms per step)
-                self._qkv_buf = torch.empty(rows, 6 * C, dtype=torch.float16, device=y.device)
-                self._qkv_buf[torch.nonzero(out_row < 0).flatten()] = ops.to_hl8(b_.view(1, -1))
-                self._pad_key = pk
-            qkv = self._qkv_buf
+            ver = self._versions()
+            if getattr(self, "_bias_hl8_key", None) != ver:
+                self._bias_hl8, self._bias_hl8_key = ops.to_hl8(b_.view(1, -1)).view(-1), ver
+            # the window-layout qkv buffer with the bias in its padding rows: per block while the process-wide budget allows (padding
+            # written once), else one shared scratch buffer refilled per block (QKV_BUFFERS)
+            qkv = QKV_BUFFERS.get(self, rows, 6 * C, y.device, window_pad_rows(out_row), self._bias_hl8, ver)
             ops.split_linear(y, self, "qkv", self.qkv.weight, self.qkv.bias, out_fmt=ops.HL8, x_hl8=True, weight_fn=wq, bias_fn=bq,
                              tag="gemm_qkv", out=qkv, out_row=tok2win, a_row=tok2win)
         else:

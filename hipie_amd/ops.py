@@ -103,11 +103,21 @@ def _chk(t, name, dtype=None):
     return t.data_ptr()
 
 
+def _check_im2col_step(B, im2col_step):
+    """the reference op processes the batch in chunks of min(B, im2col_step) images and asserts that the chunk divides the batch
+    (ms_deform_attn_cuda.cu:50-52, :112-114); this kernel has no chunking (one launch over B), but a call the reference would refuse
+    is refused here too, with its message."""
+    step = min(int(B), int(im2col_step))
+    if step <= 0 or B % step != 0:
+        raise RuntimeError("batch(%d) must divide im2col_step(%d)" % (B, step))
+
+
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
     """MSDA.ms_deform_attn_forward (ops/src/vision.cpp:13-16): value (B,S,M,D), shapes (L,2) i64, level_start (L,) i64,
     sampling_loc (B,Lq,M,L,P,2), attn_weight (B,Lq,M,L,P) -> (B,Lq,M*D).  value may be f32/f16/bf16 with f32 loc/attn, or all f64."""
     lib = _lib.load()
     B, S, M, D = value.shape
+    _check_im2col_step(B, im2col_step)
     _, Lq, _, L, P, _ = sampling_loc.shape
     f64 = value.dtype == torch.float64              # the reference op's double instantiation (ops/test.py checks it)
     if value.dtype not in _DT and not f64:
@@ -128,6 +138,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     respect to value, sampling_loc and attn_weight, all f32 or all f64 -> (grad_value, grad_sampling_loc, grad_attn_weight)."""
     lib = _lib.load()
     B, S, M, D = value.shape
+    _check_im2col_step(B, im2col_step)
     _, Lq, _, L, P, _ = sampling_loc.shape
     dt = value.dtype
     if dt not in (torch.float32, torch.float64):
@@ -359,7 +370,25 @@ def vit_attn_rel(qkv, tab_h, tab_w, grid_hw, heads, fast=False):
     return out
 
 
-_XA_WS = {}
+class _Workspace(object):
+    """scratch memory of a kernel family, one buffer per (device, stream): concurrent streams never share a buffer.  A buffer that turns
+    out too small is replaced by one of at least twice the size and the old one is KEPT ALIVE (a captured hipGraph may still hold its
+    address; geometric growth bounds what is retained by the final size).  Single assumption left: launches on one stream are ordered."""
+
+    def __init__(self):
+        self.bufs, self.retired = {}, []
+
+    def get(self, nbytes, device):
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+        b = self.bufs.get(key)
+        if b is None or b.numel() < nbytes:
+            if b is not None:
+                self.retired.append(b)
+            b = self.bufs[key] = torch.empty(max(int(nbytes), 2 * (b.numel() if b is not None else 0)), dtype=torch.uint8, device=device)
+        return b
+
+
+_XA_WS = _Workspace()
 
 
 @_timed("bi_xattn")
@@ -374,12 +403,7 @@ def bi_xattn(q, k, vv, vl, text_mask, clamp=50000.0, out_f32=False):
     out_v = torch.empty(B, Nv, H * hd, dtype=odt, device=q.device)
     out_l = torch.empty(B, L, H * hd, dtype=odt, device=q.device)
     need = 0 if out_f32 else int(lib.hipie_bi_xattn_workspace(B, H, Nv, L, hd))          # split partials of the text -> image direction (0: none)
-    ws = None
-    if need > 0:
-        key = str(q.device)
-        ws = _XA_WS.get(key)
-        if ws is None or ws.numel() * 4 < need:
-            ws = _XA_WS[key] = torch.empty((need + 3) // 4, dtype=torch.float32, device=q.device)
+    ws = _XA_WS.get(need, q.device) if need > 0 else None
     rc = lib.hipie_bi_xattn_ws(_chk(q, "q"), _chk(k, "k"), _chk(vv, "vv"), _chk(vl, "vl"), _chk(text_mask, "text_mask"),
                                out_v.data_ptr(), out_l.data_ptr(), None if ws is None else ws.data_ptr(), need, B, H, Nv, L, hd,
                                float(clamp), _DT[q.dtype] | (OUT_F32 if out_f32 else 0), _stream())
@@ -387,7 +411,7 @@ def bi_xattn(q, k, vv, vl, text_mask, clamp=50000.0, out_f32=False):
     return out_v, out_l
 
 
-_ME_WS = {}
+_ME_WS = _Workspace()
 
 
 @_timed("mask_einsum")
@@ -413,10 +437,7 @@ def mask_einsum(mask_embed, mask_features, precision=1, out_dtype=torch.float32,
                 raise ValueError("mask_einsum: row_bias must be (B, Q) = (%d, %d), got %s" % (B, Q, tuple(rbt.shape)))
             rb = _chk(rbt, "row_bias", torch.float32)
         need = int(lib.hipie_mask_einsum_workspace(B, Q, C))
-        key = str(mask_embed.device)
-        ws = _ME_WS.get(key)
-        if ws is None or ws.numel() < need:
-            ws = _ME_WS[key] = torch.empty(need, dtype=torch.uint8, device=mask_embed.device)
+        ws = _ME_WS.get(need, mask_embed.device)
         rc = lib.hipie_mask_einsum_ws(e, f, rb, out.data_ptr(), ws.data_ptr(), need, B, Q, C, Hh * Ww, int(precision), _DT[out_dtype], _stream())
     _lib.check(rc, "hipie_mask_einsum")
     return out
@@ -824,6 +845,19 @@ def to_hl8(x, scale=1.0):
     return out
 
 
+@_timed("fill_rows")
+def fill_rows(dst, rows, src_row):
+    """dst[rows[i]] = src_row for every i (hipie_fill_rows): dst (R, W) contiguous device tensor, rows int32 (n,), src_row (W,) of dst's
+    dtype; row bytes a multiple of 16.  In place; returns dst."""
+    lib = _lib.load()
+    if dst.dim() != 2 or not dst.is_cuda or src_row.dtype != dst.dtype or src_row.numel() != dst.shape[1]:
+        raise RuntimeError("fill_rows: dst (R, W) on the device, src_row (W,) of the same dtype")
+    rc = lib.hipie_fill_rows(_chk(dst, "dst"), dst.stride(0) * dst.element_size(), _chk(rows, "rows", torch.int32), rows.numel(),
+                             _chk(src_row, "src_row"), dst.shape[1] * dst.element_size(), _stream())
+    _lib.check(rc, "hipie_fill_rows")
+    return dst
+
+
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 
@@ -865,6 +899,10 @@ def gemm(a, w, bias=None, resid=None, out_fmt=F32, act=ACT_NONE, alpha=1.0, osca
             raise RuntimeError("gemm: a_row must be a contiguous int32 vector (split operands only)")
         M = a_row.numel()
         lead = (M,)
+        if out is not None and out_row is None and out.numel() // out.shape[-1] < M:
+            raise RuntimeError("gemm: `out` has fewer rows (%d) than the row map (%d)" % (out.numel() // out.shape[-1], M))
+        if resid is not None and resid.numel() // N < M:
+            raise RuntimeError("gemm: `resid` has fewer rows (%d) than the row map (%d)" % (resid.numel() // N, M))
     if out_row is not None:
         if out is None:
             lead = (int(out_rows),)
@@ -951,8 +989,11 @@ def split_weight(owner, key, params, weight_fn, bias_fn=None):
 def conv3x3_split_ok(x, conv):
     """3 x 3, stride 1, padding 1, dense: the shapes hipie_conv3x3_split runs well (full 256-column tiles)"""
     return (x.is_cuda and x.dim() == 4 and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
-            and conv.groups == 1 and conv.weight.dtype == torch.float32 and conv.in_channels % 32 == 0 and conv.out_channels % 256 == 0
+            and conv.padding_mode == "zeros" and conv.groups == 1 and conv.weight.dtype == torch.float32 and conv.in_channels % 32 == 0 and conv.out_channels % 256 == 0
             and x.shape[0] * (x.shape[2] + 2) * (x.shape[3] + 2) >= 16384)
+
+
+_CONV_STAGE = {}
 
 
 @_timed("conv3x3_split")
@@ -966,7 +1007,14 @@ def conv3x3_split(x, conv, act=ACT_NONE):
     Hp, Wp = H + 2, W + 2
     guard = Wp + 1
     rows = B * Hp * Wp
-    buf = torch.zeros(rows + 2 * guard, C, dtype=torch.float32, device=x.device)
+    # the zero-padded staging grid is cached per (geometry, device, stream): its border and guard rows stay zero, only the interior is
+    # re-written per call (one full-map zero-fill pass less per convolution)
+    skey = (B, C, H, W, str(x.device), torch.cuda.current_stream(x.device).cuda_stream)
+    buf = _CONV_STAGE.get(skey)
+    if buf is None:
+        if len(_CONV_STAGE) >= 8:
+            _CONV_STAGE.pop(next(iter(_CONV_STAGE)))
+        buf = _CONV_STAGE[skey] = torch.zeros(rows + 2 * guard, C, dtype=torch.float32, device=x.device)
     buf[guard:guard + rows].view(B, Hp, Wp, C)[:, 1:-1, 1:-1].copy_(x.permute(0, 2, 3, 1))
     w, b, _ = split_weight(conv, "w3x3", [conv.weight] + ([conv.bias] if conv.bias is not None else []),
                            lambda: conv.weight.permute(0, 2, 3, 1).reshape(N, 9 * C), (lambda: conv.bias) if conv.bias is not None else None)

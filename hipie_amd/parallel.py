@@ -12,11 +12,35 @@ import torch.distributed as dist
 PRED_FIELDS = 7          # x0, y0, x1, y1, score, class, query index
 
 
-def init_from_env(backend=None):
-    """torchrun-style env (RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT).  Returns (rank, world, local_rank)."""
+def init_single_rank_group(backend=None, device_index=0):
+    """a process group of ONE rank (file:// rendezvous, no port): the N = 1 step then runs the same collectives as the N > 1 one --
+    all_gather_into_tensor / all_reduce go through RCCL when the backend is "nccl" -- instead of short-cutting them.  Returns the
+    backend name, or None when the group could not be created (the collectives then degrade to identities, as without a group)."""
+    import tempfile
+    if dist.is_initialized():
+        return dist.get_backend()
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(device_index)
+    path = os.path.join(tempfile.gettempdir(), "hipie_pg_%d_%d" % (os.getpid(), int.from_bytes(os.urandom(4), "little")))
+    try:
+        dist.init_process_group(backend=backend, init_method="file://" + path, rank=0, world_size=1)
+    except Exception as e:          # pragma: no cover - depends on the box
+        import sys
+        print("hipie_amd.parallel: single-rank %s group not available (%r); running without a process group" % (backend, e), file=sys.stderr)
+        return None
+    return dist.get_backend()
+
+
+def init_from_env(backend=None, single_rank_group=False):
+    """torchrun-style env (RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT).  Returns (rank, world, local_rank).
+    single_rank_group: with WORLD_SIZE 1 also open a one-rank process group (init_single_rank_group), so the collectives really run."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and single_rank_group and not dist.is_initialized():
+        init_single_rank_group(backend, local)
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -72,7 +96,7 @@ def compact_maps(results, hw, stride=4, device=None):
 def all_gather_predictions(block):
     """(n_local, ...) per rank (same shape on every rank: pad upstream) -> (world*n_local, ...) on every rank.  One
     all_gather_into_tensor per block: the (n, topk, 7) fp32 instance block and, when computed, the (n, 2, h, w) int16 map block."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return block
     world = dist.get_world_size()
     block = block.contiguous()
@@ -85,7 +109,7 @@ def all_gather_predictions(block):
 def live_ranks(device):
     """number of ranks that actually take part in the process group's collectives: an all-reduce (sum) of ones over the backend
     in use (RCCL for "nccl").  1 without a process group.  bench.py reports it next to the gathered block's shape."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return 1
     t = torch.ones(1, dtype=torch.float32, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -106,12 +130,20 @@ def dp_evidence(gathered, per_rank, rank, world, device):
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+    if dist.is_initialized():
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(value, device):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPIE_ABI_VERSION 10
+#define HIPIE_ABI_VERSION 11
 
 /* element types of activations */
 #define HIPIE_F32 0
@@ -434,6 +434,11 @@ int hipie_gemm_gather(const void* A, int64_t lda, int64_t a_rows, const int32_t*
  */
 int hipie_vit_attn_split(const void* qkv, const void* tab_h, const void* tab_w, void* out, int B, int gh, int gw, int heads,
                          int hd, void* stream);
+
+/* dst + rows[i] * ld_bytes <- the row_bytes bytes at src_row, for i < n_rows (negative entries are skipped): one constant row into a
+ * listed set of rows.  Used to write the HL8 qkv BIAS row into the padding rows of a window-layout qkv buffer -- the qkv of a padding token
+ * of window_partition is the bias, its LayerNorm output being zero (hipie/backbone/utils.py:29-37, vit.py:67-71).  16-byte units. */
+int hipie_fill_rows(void* dst, int64_t ld_bytes, const int32_t* rows, int64_t n_rows, const void* src_row, int64_t row_bytes, void* stream);
 
 /* rows of `x_dtype` (HIPIE_F32 | HIPIE_F16) values -> HIPIE_HL8 rows of scale * x (K a multiple of 8; ldx in elements of x, ldo in
  * fp16 elements >= 2K): the generic producer of split operands (the LayerNorm / GEMM epilogues emit HL8 directly). */

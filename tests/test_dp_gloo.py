@@ -83,3 +83,33 @@ def test_shard_range_covers_everything():
         for world in (1, 2, 8):
             allidx = [i for r in range(world) for i in shard_range(total, r, world)]
             assert allidx == list(range(total))
+
+
+def _single(q):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    from hipie_amd import parallel
+    r, w, _ = parallel.init_from_env(backend="gloo", single_rank_group=True)          # what bench.py does at N = 1 (there: "nccl")
+    block = torch.arange(2 * 3 * parallel.PRED_FIELDS, dtype=torch.float32).view(2, 3, -1)
+    out = parallel.all_gather_predictions(block)
+    maps = torch.arange(2 * 2 * 4 * 4, dtype=torch.int16).view(2, 2, 4, 4)
+    mout = parallel.all_gather_predictions(maps)
+    dp = parallel.dp_evidence(out, 2, r, w, torch.device("cpu"))
+    t = parallel.max_over_ranks(0.5, torch.device("cpu"))
+    parallel.barrier()
+    parallel.shutdown()
+    q.put((r, w, out.data_ptr() != block.data_ptr(), torch.equal(out, block), torch.equal(mout, maps), dp, t))
+
+
+def test_single_rank_group_runs_the_collectives():
+    """N = 1 with a one-rank process group (file:// rendezvous): the gathers and reductions go through the backend instead of being
+    short-cut -- the code path bench.py --gpus 1 times (backend "nccl" there: tests/test_gpu_rccl.py)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_single, args=(q,))
+    p.start()
+    r, w, fresh, same, msame, dp, t = q.get(timeout=120)
+    p.join(60)
+    assert p.exitcode == 0
+    assert (r, w) == (0, 1) and fresh and same and msame and t == 0.5
+    assert dp["backend"] == "gloo" and dp["rccl_ranks"] == 1 and dp["gathered_block_shape"] == [2, 3, 7]

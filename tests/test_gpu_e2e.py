@@ -120,6 +120,40 @@ def test_e2e_long_prompt(policy, tol):
         assert errs[k] < tol, (k, errs[k])
 
 
+def test_windowed_qkv_buffers_persistent_and_shared_modes_agree():
+    """the window-layout qkv buffers of the windowed ViT blocks (vit.QKV_BUFFERS): per block while the process-wide budget allows, one shared
+    scratch buffer refilled by hipie_fill_rows beyond it (large per-GPU batches) -- bit-identical outputs, bounded memory, and a second
+    geometry does not leave the first one's buffers behind."""
+    from hipie_amd.config import Precision
+    from hipie_amd.modeling import vit
+    g, model = build(Precision.split3())
+    model.pin_topk(g["detection_topk_fg"], g["detection_topk_md"])
+    batch = inputs(g, "detection")
+    saved = vit.QKV_BUFFERS.budget
+    try:
+        vit.QKV_BUFFERS.budget = 8 << 30
+        a = model.forward_raw(batch)
+        blocks = [m for m in model.modules() if isinstance(m, vit.Attention) and m.__dict__.get("_qkv_state") is not None]
+        assert len(blocks) == 2 and vit.QKV_BUFFERS._live_bytes() > 0          # the tiny ViT has two windowed blocks
+        one = [dict(batch[0])]                                                  # a second geometry (one image): the old buffers are replaced
+        model.pin_topk(g["detection_topk_fg"][:1], g["detection_topk_md"][:1])
+        model.forward_raw(one)
+        n_geo = len(set(e[1] for e in vit.QKV_BUFFERS.entries.values() if e[0]() is not None and e[0]() in blocks))
+        assert n_geo == 1
+        model.pin_topk(g["detection_topk_fg"], g["detection_topk_md"])
+        vit.QKV_BUFFERS.budget = 0                                              # nothing fits: the shared scratch buffer
+        for m in blocks:
+            m._qkv_state = None
+        vit.QKV_BUFFERS.entries.clear()
+        b = model.forward_raw(batch)
+        assert all(m.__dict__.get("_qkv_state") is None for m in blocks) and len(vit.QKV_BUFFERS.shared) == 1
+        for k in KEYS:
+            assert torch.equal(a[k], b[k]), k
+    finally:
+        vit.QKV_BUFFERS.budget = saved
+        vit.QKV_BUFFERS.shared.clear()
+
+
 def test_e2e_pad_max_4096_is_trimmed():
     """The shipped eval setting (MODEL.LANGUAGE_BACKBONE.PAD_MAX, MAX_QUERY_LEN 4096: configs/eval/image_joint_vit_huge_32g_pan_maskdino_ade_test.yaml:10-11,
     hipie_img.py:904-909) in the TIMED policy against the reference's own coco_inference on the same 4096-column inputs

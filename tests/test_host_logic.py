@@ -600,3 +600,20 @@ def test_effective_cores_respects_affinity_and_is_positive():
     assert 1 <= n <= (os.cpu_count() or 1)
     if hasattr(os, "sched_getaffinity"):
         assert n <= len(os.sched_getaffinity(0))
+
+
+def test_msda_im2col_step_is_validated_like_the_reference_op():
+    """ms_deform_attn_cuda.cu:50-52 / :112-114: `batch % min(batch, im2col_step) == 0` or the op refuses the call.  The kernel here does not
+    chunk the batch, but a call the reference would refuse must not silently succeed (checked before anything touches the device)."""
+    import pytest
+    import torch
+    from hipie_amd import ops
+    v = torch.zeros(6, 5, 8, 32)
+    sh, ls = torch.tensor([[1, 5]]), torch.tensor([0])
+    loc, w = torch.zeros(6, 3, 8, 1, 4, 2), torch.zeros(6, 3, 8, 1, 4)
+    with pytest.raises(RuntimeError, match=r"batch\(6\) must divide im2col_step\(4\)"):
+        ops.ms_deform_attn_forward(v, sh, ls, loc, w, 4)
+    with pytest.raises(RuntimeError, match=r"must divide im2col_step"):
+        ops.ms_deform_attn_backward(v, sh, ls, loc, w, torch.zeros(6, 3, 256), 4)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):      # a valid step (3 divides 6) gets as far as the device check
+        ops.ms_deform_attn_forward(v, sh, ls, loc, w, 3)

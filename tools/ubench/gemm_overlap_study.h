@@ -1,4 +1,4 @@
-// gemm_overlap_study.h -- round-4 timing study, compiled ONLY into `make EXTRA=-DHIPIE_GEMM_VARIANTS` builds (included by gemm.hip).
+// gemm_overlap_study.h -- round-4 timing study (moved out of hipie_amd/csrc in round 5), compiled ONLY into `make -C hipie_amd/csrc EXTRA=-DHIPIE_GEMM_VARIANTS` builds (included by gemm.hip).
 // Three attempts to run the tile epilogue of the split GEMM beside another tile's k loop: gemm2 (two free-running 4-wave workgroups per
 // CU), gemm3 (one persistent workgroup whose two 4-wave groups ping-pong) and gemm4 (gemm2 made persistent, the second workgroup of a CU
 // started half a tile late).  All produce correct results (tests/test_gpu_gemm.py passes with HIPIE_GEMM2=1|2|4) and none beats gemm_kernel on the ViT shapes; the measurements and what they established are in
