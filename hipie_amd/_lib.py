@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libhipie_mi355.so")
+# HIPIE_LIB_PATH: another build of the SAME ABI, for same-box A/B timing of a kernel change (tools/); the default is the in-tree library
+LIB_PATH = os.environ.get("HIPIE_LIB_PATH") or os.path.join(_HERE, "csrc", "libhipie_mi355.so")
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int

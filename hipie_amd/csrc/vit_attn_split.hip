@@ -23,6 +23,10 @@
 #include "common.h"
 #include "mfma.h"
 
+#ifndef HIPIE_VS_TAIL
+#define HIPIE_VS_TAIL 1        // 0: hd 80 as three 32-row blocks with a ones column (the round-4 form), for A/B timing builds only
+#endif
+
 namespace hipie {
 
 constexpr float VS_LAZY = 6.f;       // exp2(6) = 64: P <= 64, far inside fp16; a tile's P.V partial sums stay far inside fp32
@@ -53,12 +57,30 @@ __device__ __forceinline__ float vs_xhalf_max(float x) {
   return fmaxf(__builtin_bit_cast(float, (unsigned int)r[0]), __builtin_bit_cast(float, (unsigned int)r[1]));
 }
 
-// LDS-DMA of 16 bytes per lane: LDS[lds_dst + 16 * lane] <- *(sbase + voff)  (see gemm.hip / vit_attn.hip for the inline-asm form)
-__device__ __forceinline__ void vs_dma16(const char* sbase, unsigned int voff, unsigned int lds_dst) {
+// two probabilities -> one VGPR of fp16 hi halves and one of lo halves, lo = fp16(p - hi) from ONE instruction each: v_fma_mix{lo,hi}_f16
+// forms p - hi exactly (the fp16 hi enters as an fp16 source operand) and rounds once.  The C++ form `(T)(pv - (float)(T)pv)` costs a
+// v_cvt_f16_f32, a v_cvt_f32_f16 and a v_sub_f32 per VALUE on top of the two packs: 4 instead of 1.5 VALU per probability, 80 of the
+// ~230 VALU instructions a wave issues per 64-key tile of the global-attention instance.
+__device__ __forceinline__ void vs_split2(const float a, const float b, unsigned int& H, unsigned int& L) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  unsigned int keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+  unsigned int h, l;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a), "v"(b));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(a));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(b));
+  H = h;
+  L = l;
+#endif
+}
+
+// LDS-DMA of 16 bytes per lane: LDS[lds_dst + 16 * lane] <- *(sbase + voff) for the lanes of `mask` (see gemm.hip / vit_attn.hip for the
+// inline-asm form).  The lane mask (a tile's row-padding chunks are neither fetched nor written) is applied inside the statement --
+// s_and_saveexec / s_mov exec around the load, no branch -- and M0 is simply overwritten (nothing else in this kernel uses it): 5 scalar
+// instructions per DMA where the compiler's own predication + an M0 save / restore took 12.
+__device__ __forceinline__ void vs_dma16(const char* sbase, unsigned int voff, unsigned int lds_dst, unsigned long long mask) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  unsigned long long save;
+  asm volatile("s_and_saveexec_b64 %0, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"
+               : "=&s"(save) : "v"(voff), "s"(sbase), "s"(lds_dst), "s"(mask) : "memory", "m0");
 #endif
 }
 
@@ -85,7 +107,14 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
   constexpr int NT = WAVES * 64;
   // hd = 80 leaves d rows 80 .. 95 of the last O^T block unused: column 80 of the V_hi plane holds 1.0 (written once; the DMA skips the
   // padding chunks), so O^T row 80 accumulates the row sums of the (fp16) probabilities on the matrix pipe -- no VALU adds for them
-  constexpr bool ONES = DB * 32 > HD;
+  // hd = 80 = 2 x 32 + 16: the d rows 64 .. 79 of O^T are a 16-row TAIL computed with v_mfma_f32_16x16x32_f16 (16 d rows x 16 queries x 32
+  // keys) instead of a third 32-row block of which half would be padding -- 60 instead of 66 MFMA-equivalents per 64-key tile (the matrix
+  // pipe is the power-limited resource of this kernel: time follows the MFMA work issued, not the instruction count).  The tail's B operand
+  // needs a lane's 16 queries x 4 k-groups where the S^T layout has 32 queries x 2 halves: two v_permlane16_swap per VGPR re-deal the two
+  // 16-key steps of a 32-key block into the fragments of queries 0-15 (X) and 16-31 (Y); see the PV loop.
+  constexpr bool TAIL = (HD % 32 == 16) && (HIPIE_VS_TAIL != 0);
+  constexpr int DBB = TAIL ? HD / 32 : DB;     // full 32-row d blocks that run on the 32x32x16 MFMA
+  constexpr bool ONES = (DB * 32 > HD) && !TAIL;
   static_assert(R == 1 || (KW > 0 && R * KW <= KT), "R key rows of KW keys must fit the tile");
   static_assert(BHC == 0 || (R == 1 && BHC <= 31), "chunked bias_h: one key row per tile, at most 31 rows per chunk");
   static_assert(KSTR % 8 == 0 && VSTR % 8 == 0, "plane rows are whole 16-byte chunks");
@@ -221,7 +250,7 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
     return (unsigned int)(((long)row * p.krs + (isk ? 0 : C2) + 16 * col + 8 * pl) * (long)sizeof(T));
   };
   unsigned int dvoff[NDMA];
-  unsigned int dskip = 0u;            // bit r: this lane's chunk of DMA instruction r is row padding -- not fetched, not written
+  unsigned long long dmask[NDMA];     // lanes of DMA instruction r whose chunk is DATA (row-padding chunks are not fetched, not written)
 #pragma unroll
   for (int r = 0; r < NDMA; ++r) {
     dvoff[r] = dma_voff(r, nkt - 1);
@@ -229,18 +258,19 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
     const bool isk = jj < 2 * KBLK;
     const int pl = isk ? jj / KBLK : (jj - 2 * KBLK) / VBLK;
     const int c = 64 * (isk ? jj - pl * KBLK : jj - 2 * KBLK - pl * VBLK) + lane;
-    if (c % (isk ? KCH : VCH) >= CPR) dskip |= 1u << r;
+    dmask[r] = __builtin_amdgcn_ballot_w64(c % (isk ? KCH : VCH) < CPR);
   }
   const unsigned int lds0 = (unsigned int)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem_raw);
   const char* kbase0 = reinterpret_cast<const char*>(Kg);
   const long tile_bytes = (R > 1 ? (long)nkt * p.st : p.kts) * (long)sizeof(T);
+  // the NDMA * WAVES slots of a round may exceed the NBLK blocks of a tile image: a surplus slot re-fetches the LAST block (same bytes to
+  // the same place as the wave that owns it) instead of branching around the instruction
   auto dma_tile = [&](const int t, const int buf, const int r) {
-    const int j = wave + WAVES * r;
-    if (j >= NBLK) return;
+    const int j = (WAVES * r + WAVES - 1 < NBLK) ? wave + WAVES * r : min(wave + WAVES * r, NBLK - 1);
     const bool last_ragged = ragged && (t == nt - 1);
     const unsigned int vo = last_ragged ? dma_voff(r, p.N - t * nkt - 1) : dvoff[r];
     const unsigned int ldst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned int)(buf * BUF * (int)sizeof(T) + 1024 * j));
-    if (!((dskip >> r) & 1u)) vs_dma16(kbase0 + (long)t * tile_bytes, vo, ldst);
+    vs_dma16(kbase0 + (long)t * tile_bytes, vo, ldst, dmask[r]);
   };
 
   // row padding of the V planes of both buffers (the prologue's staging area overlapped them): zeros, and 1.0 in column HD of V_hi
@@ -256,12 +286,15 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
     }
   }
 
-  f32x16 O[DB];
+  f32x16 O[DBB];
+  f32x4 OT[2];                  // TAIL: d rows 32 DBB + 4 (lane >> 4) + r of queries (lane & 15) [0] and 16 + (lane & 15) [1] of this wave
   float m_run = -INFINITY, l_run = 0.f;
 #pragma unroll
-  for (int d = 0; d < DB; ++d)
+  for (int d = 0; d < DBB; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) O[d][r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { OT[0][r] = 0.f; OT[1][r] = 0.f; }
 
 #pragma unroll
   for (int r = 0; r < NDMA; ++r) dma_tile(0, 0, r);
@@ -277,7 +310,9 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
     const T* Kl = Kh + KPL;
     const T* Vh = Kh + 2 * KPL;
     const T* Vl = Vh + VPL;
-    const bool more = t + 1 < nt;
+    // the DMA of the NEXT tile is issued unconditionally: behind the last tile it re-fetches that tile into the idle buffer (1 / nt more
+    // L2 traffic) -- no `more` branches around the six DMA statements of the loop body
+    const int tn = min(t + 1, nt - 1);
     if (BHC > 0 && t % (BHC > 0 ? BHC : 1) == 0) bias_h_chunk(t);
     float bh0 = bh_all[(BHC > 0 ? t % (BHC > 0 ? BHC : 1) : R * t) * QW + wave * 32 + li], bh1 = 0.f;
     if (R > 1) bh1 = (R * t + 1 < kh) ? bh_all[(R * t + 1) * QW + wave * 32 + li] : -INFINITY;
@@ -307,17 +342,15 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
           S[blk] = Mfma32<T>::mma(kfh[ks & 1][blk], ql[ks], S[blk]);
           S[blk] = Mfma32<T>::mma(kfh[ks & 1][blk], qh[ks], S[blk]);
         }
-        if (more && ks < NDMA) dma_tile(t + 1, (t + 1) & 1, ks);
+        if (ks < NDMA) dma_tile(tn, (t + 1) & 1, ks);
       }
-      if (more) {
 #pragma unroll
-        for (int r = KS; r < NDMA; ++r) dma_tile(t + 1, (t + 1) & 1, r);
-      }
+      for (int r = KS; r < NDMA; ++r) dma_tile(tn, (t + 1) & 1, r);
     }
     // V^T fragments of the first PV product (step 0, hi plane): in flight while the softmax statistics are computed
-    hfrag va[2][DB], vb[2][DB];                 // [parity][d]: rows 0-3 / 8-11 of the 16-key step for this lane half
+    hfrag va[2][DBB], vb[2][DBB];               // [parity][d]: rows 0-3 / 8-11 of the 16-key step for this lane half
 #pragma unroll
-    for (int d = 0; d < DB; ++d) {
+    for (int d = 0; d < DBB; ++d) {
       va[0][d] = Mfma32<T>::tr_read(Vh + vlane + 32 * d);
       vb[0][d] = Mfma32<T>::tr_read(Vh + vlane + 32 * d + 8 * VSTR);
     }
@@ -329,11 +362,19 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[blk][r] += (32 * blk + crow(r, hi) < kw) ? bh0 : bh1;
     }
-    float mx = -INFINITY;
+    // four independent v_max3 chains: a single chain made hipcc put a wait state behind every link (inline-asm VALU feeding the next one)
+    float mx = -INFINITY, mxb = -INFINITY, mxc = -INFINITY, mxd = -INFINITY;
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) mx = vs_max3(mx, S[blk][r], S[blk][r + 1]);
+      for (int r = 0; r < 16; r += 8) {
+        mx = vs_max3(mx, S[blk][r], S[blk][r + 1]);
+        mxb = vs_max3(mxb, S[blk][r + 2], S[blk][r + 3]);
+        mxc = vs_max3(mxc, S[blk][r + 4], S[blk][r + 5]);
+        mxd = vs_max3(mxd, S[blk][r + 6], S[blk][r + 7]);
+      }
+    mx = vs_max3(mx, mxb, mxc);
+    mx = vs_max3(mx, mxd, mxd);
     mx = vs_xhalf_max(mx);
     mx += (R > 1 ? 0.f : bh0);
     // LAZY running maximum: the reference point only moves when some row's maximum grew by more than 2^VS_LAZY (log2 domain), so
@@ -346,22 +387,112 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
       m_run = m_new;
       if (!ONES) l_run *= alpha;
 #pragma unroll
-      for (int d = 0; d < DB; ++d)
+      for (int d = 0; d < DBB; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[d][r] *= alpha;
+      if (TAIL) {               // the tail accumulators hold query (lane & 15) / 16 + (lane & 15): their factors live in those lanes
+        const float ax = __shfl(alpha, lane & 15), ay = __shfl(alpha, 16 + (lane & 15));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { OT[0][r] *= ax; OT[1][r] *= ay; }
+      }
     }
     const float off = (R > 1 ? 0.f : bh0) - m_run;
 
     // ---- P = exp2(S + off) as an fp16 PAIR;  O^T += V_hi^T . (P_hi + P_lo)^T + V_lo^T . P_hi^T.  Product u = (step, plane): the V^T reads of product
     //      u + 1 and (before a new step) the exps / packs of the next P fragment are issued ahead of the MFMAs of product u ----
-    frag pf, pfl;                // the probabilities of a 16-key step as an fp16 pair: hi, and lo = fp16(p - hi)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    if constexpr (TAIL) {
+      // p[b][s]: the probabilities of 16-key step s of 32-key block (parity b) as packed fp16 pairs, hi and lo halves -- in the S^T layout
+      // (lane = query li, the lane half's 8 keys of the step), which IS the B operand of the 32x32x16 products
+      u32x4 p_h[2][2], p_l[2][2];
+      auto make_p = [&](const int blk, const int st, u32x4& Hh, u32x4& Ll) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float pv = __builtin_amdgcn_exp2f(S[0][j] + off);
-      if (!ONES) l_run += pv;
-      const T ph = (T)pv;
-      pf[j] = ph;
-      pfl[j] = (T)(pv - (float)ph);
+        for (int j = 0; j < 4; ++j) {
+          const float p0 = __builtin_amdgcn_exp2f(S[blk][8 * st + 2 * j] + off), p1 = __builtin_amdgcn_exp2f(S[blk][8 * st + 2 * j + 1] + off);
+          l_run += p0 + p1;                    // fp32 row sums of the unrounded probabilities (no spare O^T row for a ones column here)
+          unsigned int hh, ll;
+          vs_split2(p0, p1, hh, ll);
+          Hh[j] = hh;
+          Ll[j] = ll;
+        }
+      };
+      // tail A operand (V^T rows 32 DBB .. + 15 over the 32 keys of a block): lane group g = lane >> 4 holds the k-group the swapped P
+      // fragments give it -- keys {0-3, 8-11}, {16-19, 24-27}, {4-7, 12-15}, {20-23, 28-31} of the block for g = 0 .. 3 -- as two transposing reads
+      const int tg = lane >> 4, tj = lane & 15;
+      const int tlane = ((tg & 1) * 16 + (tg >> 1) * 4 + (tj >> 2)) * VSTR + 32 * DBB + 4 * (tj & 3);
+      hfrag ta_h[2], ta_l[2];
+      make_p(0, 0, p_h[0][0], p_l[0][0]);
+#pragma unroll
+      for (int u = 0; u < 4 * NB; ++u) {
+        const int step = u >> 1, pl = u & 1, blk = step >> 1, st = step & 1, bp = blk & 1;
+        frag vf[DBB];
+#pragma unroll
+        for (int d = 0; d < DBB; ++d)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { vf[d][j] = va[u & 1][d][j]; vf[d][4 + j] = vb[u & 1][d][j]; }
+        if (u + 1 < 4 * NB) {
+          const int nstep = (u + 1) >> 1, npl = (u + 1) & 1;
+          const T* vbp = (npl ? Vl : Vh) + (16 * nstep) * VSTR + vlane;
+#pragma unroll
+          for (int d = 0; d < DBB; ++d) {
+            va[(u + 1) & 1][d] = Mfma32<T>::tr_read(vbp + 32 * d);
+            vb[(u + 1) & 1][d] = Mfma32<T>::tr_read(vbp + 32 * d + 8 * VSTR);
+          }
+          if (npl == 0) make_p(nstep >> 1, nstep & 1, p_h[(nstep >> 1) & 1][nstep & 1], p_l[(nstep >> 1) & 1][nstep & 1]);
+        }
+        if (st == 1 && pl == 0) {           // the tail's V^T fragments of this block, requested one product ahead of their use
+          ta_h[0] = Mfma32<T>::tr_read(Vh + (32 * blk) * VSTR + tlane);
+          ta_h[1] = Mfma32<T>::tr_read(Vh + (32 * blk + 8) * VSTR + tlane);
+          ta_l[0] = Mfma32<T>::tr_read(Vl + (32 * blk) * VSTR + tlane);
+          ta_l[1] = Mfma32<T>::tr_read(Vl + (32 * blk + 8) * VSTR + tlane);
+        }
+        // plane 0 (V_hi): both halves of P;  plane 1 (V_lo): P_hi only (lo x lo is below fp32 rounding)
+        const frag pf = __builtin_bit_cast(frag, p_h[bp][st]);
+#pragma unroll
+        for (int d = 0; d < DBB; ++d) O[d] = Mfma32<T>::mma(vf[d], pf, O[d]);
+        if (pl == 0) {
+          const frag pfl = __builtin_bit_cast(frag, p_l[bp][st]);
+#pragma unroll
+          for (int d = 0; d < DBB; ++d) O[d] = Mfma32<T>::mma(vf[d], pfl, O[d]);
+        }
+        if (st == 1 && pl == 1) {
+          // ---- the 16-row tail of this 32-key block.  v_permlane16_swap exchanges lanes 16-31 / 48-63 of its first operand with lanes
+          //      0-15 / 32-47 of the second: (step 0, step 1) -> X = the four k-groups of queries 0-15, Y = those of queries 16-31 ----
+          typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+          u32x4 xh, yh, xl, yl;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const u32x2 sh = __builtin_amdgcn_permlane16_swap(p_h[bp][0][j], p_h[bp][1][j], false, false);
+            const u32x2 sl = __builtin_amdgcn_permlane16_swap(p_l[bp][0][j], p_l[bp][1][j], false, false);
+            xh[j] = sh[0]; yh[j] = sh[1]; xl[j] = sl[0]; yl[j] = sl[1];
+          }
+          frag ah, al;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { ah[j] = ta_h[0][j]; ah[4 + j] = ta_h[1][j]; al[j] = ta_l[0][j]; al[4 + j] = ta_l[1][j]; }
+          const frag fxh = __builtin_bit_cast(frag, xh), fyh = __builtin_bit_cast(frag, yh);
+          OT[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, fxh, OT[0], 0, 0, 0);
+          OT[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, fyh, OT[1], 0, 0, 0);
+          OT[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, __builtin_bit_cast(frag, xl), OT[0], 0, 0, 0);
+          OT[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, __builtin_bit_cast(frag, yl), OT[1], 0, 0, 0);
+          OT[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, fxh, OT[0], 0, 0, 0);
+          OT[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, fyh, OT[1], 0, 0, 0);
+        }
+      }
+    } else {
+    frag pf, pfl;                // the probabilities of a 16-key step as an fp16 pair: hi, and lo = fp16(p - hi)
+    {
+      u32x4 ph4, pl4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float p0 = __builtin_amdgcn_exp2f(S[0][2 * j] + off), p1 = __builtin_amdgcn_exp2f(S[0][2 * j + 1] + off);
+        if (!ONES) l_run += p0 + p1;
+        unsigned int hh, ll;
+        vs_split2(p0, p1, hh, ll);
+        ph4[j] = hh;
+        pl4[j] = ll;
+      }
+      pf = __builtin_bit_cast(frag, ph4);
+      pfl = __builtin_bit_cast(frag, pl4);
     }
 #pragma unroll
     for (int u = 0; u < 4 * NB; ++u) {
@@ -382,14 +513,18 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
         }
         if (npl == 0) {           // a new step follows: its probabilities
           const int nb_ = nstep >> 1, ns_ = nstep & 1;
+          u32x4 ph4, pl4;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float pv = __builtin_amdgcn_exp2f(S[nb_][8 * ns_ + j] + off);
-            if (!ONES) l_run += pv;
-            const T ph = (T)pv;
-            pn[j] = ph;
-            pnl[j] = (T)(pv - (float)ph);
+          for (int j = 0; j < 4; ++j) {
+            const float p0 = __builtin_amdgcn_exp2f(S[nb_][8 * ns_ + 2 * j] + off), p1 = __builtin_amdgcn_exp2f(S[nb_][8 * ns_ + 2 * j + 1] + off);
+            if (!ONES) l_run += p0 + p1;
+            unsigned int hh, ll;
+            vs_split2(p0, p1, hh, ll);
+            ph4[j] = hh;
+            pl4[j] = ll;
           }
+          pn = __builtin_bit_cast(frag, ph4);
+          pnl = __builtin_bit_cast(frag, pl4);
         }
       }
       // plane 0 (V_hi): both halves of P;  plane 1 (V_lo): P_hi only (lo x lo is below fp32 rounding)
@@ -404,6 +539,8 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
       (void)step;
     }
 
+    }
+
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's DMA writes of tile t + 1 have landed
     __syncthreads();                          // ... and everybody's; all reads of tile t are done
   }
@@ -412,12 +549,12 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
   {
     // ONES: d row HD = row HD % 32 of the last block = register 8 (crow(8, 0) = 16 = 80 - 64) of the lower lane half
     static_assert(!ONES || (HD % 32 == 16), "the ones column is read back from O^T row 16 of the last block");
-    const float l_tot = ONES ? __shfl(O[DB - 1][8], li) : l_run + __shfl_xor(l_run, 32);
+    const float l_tot = ONES ? __shfl(O[DBB - 1][8], li) : l_run + __shfl_xor(l_run, 32);
     const float inv = 1.f / l_tot;
     if (qi < p.N) {
       T* orow = Og + qm * p.o_st;
 #pragma unroll
-      for (int d = 0; d < DB; ++d)
+      for (int d = 0; d < DBB; ++d)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int d0 = 32 * d + 8 * rr + 4 * hi;
@@ -435,6 +572,32 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
             *reinterpret_cast<f16x4*>(dst + 8) = ol;
           }
         }
+    }
+    if (TAIL) {
+      // tail rows: lane holds d = 32 DBB + 4 (lane >> 4) + e of query (lane & 15) [OT[0]] and 16 + (lane & 15) [OT[1]] of this wave
+      const int d0 = 32 * DBB + 4 * (lane >> 4);
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int ql = 16 * h2 + (lane & 15);                 // query inside the wave's 32
+        const float iv = __shfl(inv, ql);
+        const int qi2 = qt * QW + wave * 32 + ql;
+        const int qc2 = min(qi2, p.N - 1);
+        const int qy2 = qc2 / kw, qx2 = qc2 - qy2 * kw;
+        const long qm2 = p.tr ? (long)qx2 * p.kwm + qy2 : (long)qc2;
+        if (qi2 < p.N) {
+          f16x4 oh, ol;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            T hh, ll;
+            hl_split(OT[h2][e] * iv, hh, ll);
+            oh[e] = hh;
+            ol[e] = ll;
+          }
+          T* dst = Og + qm2 * p.o_st + 16 * (d0 >> 3) + (d0 & 4);
+          *reinterpret_cast<f16x4*>(dst) = oh;
+          *reinterpret_cast<f16x4*>(dst + 8) = ol;
+        }
+      }
     }
   }
 }
