@@ -333,6 +333,16 @@ def main():
         emit(cpu_baseline(cfg.to_dict(), args.size, 194, 80, emit=emit))
         return
 
+    # ONE JSON line on stdout and nothing else: libraries write there too (RCCL prints a version banner through C stdio when its
+    # communicator comes up, flushed at exit, i.e. BEHIND the line).  From here on file descriptor 1 is stderr; the result lines go to
+    # the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit_line(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     from hipie_amd import ops, parallel
     from hipie_amd.config import HipieConfig, Precision
     from hipie_amd.hipie_img import HIPIE_IMG
@@ -430,7 +440,7 @@ def main():
 
     if args.timed_only:
         if rank == 0:
-            print(json.dumps({"ms_per_step": round(dt / args.steps * 1e3, 2), "images_per_sec": round(args.batch * world * args.steps / dt, 3)}))
+            emit_line({"ms_per_step": round(dt / args.steps * 1e3, 2), "images_per_sec": round(args.batch * world * args.steps / dt, 3)})
         parallel.shutdown()
         return
 
@@ -662,7 +672,7 @@ def main():
                     line["cpu_baseline_r50_512"] = json.loads(tag[-1][len("CPU_BASELINE_R50 "):])
             except Exception as e:
                 line["cpu_baseline"] = {"value": None, "error": repr(e)[:200]}
-        print(json.dumps(line))
+        emit_line(line)
     parallel.barrier()
     parallel.shutdown()
 

@@ -214,9 +214,11 @@ __global__ __launch_bounds__(256) void msda_d32_kernel(const T* __restrict__ val
   // row = one (batch, query); offsets / logits of head m inside the row (dense rows when the strides are M*L*P*2 / M*L*P)
   publish_records<A, FUSED>(rec, sub, loc_or_off + bq * off_stride + (long)m * (LP * 2), w_or_logit + bq * w_stride + (long)m * LP,
                             FUSED ? ref + bq * L * ref_dim : nullptr, ref_dim, shapes, lstart, L, P, row);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();                      // the 8 lanes of a group live in one wave: no block barrier needed
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // the 8 lanes of a group live in one wave: no block barrier is needed; the records are waited for (lgkmcnt(0)) before they are read back
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+  __builtin_amdgcn_wave_barrier();
 
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   const T* vb = value + (long)b * S * row + m * 32 + sub * 4;

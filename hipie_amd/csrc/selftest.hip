@@ -31,6 +31,84 @@ __global__ void selftest_tr_kernel(const bf16_t* __restrict__ tile, float* __res
   for (int j = 0; j < 4; ++j) out[lane * 4 + j] = (float)v[j];
 }
 
+// LDS canary (probe 2): every workgroup fills `words` dwords of DYNAMIC LDS with a pattern of its own, then re-reads them `rounds` times
+// with pauses in between and counts the words that changed (out[0] += mismatches, out[1] += workgroups run).  Run beside another kernel on a
+// second stream it tells whether that kernel writes into LDS it does not own.  a[0] = words (<= 8192), a[1] = rounds.
+__global__ __launch_bounds__(256) void selftest_lds_canary_kernel(const uint16_t* __restrict__ cfg, float* __restrict__ out) {
+  extern __shared__ unsigned int canary[];
+  const int words = cfg[0], rounds = cfg[1];
+  const unsigned int salt = 0x9E3779B9u * (blockIdx.x + 1);
+  for (int i = threadIdx.x; i < words; i += 256) canary[i] = salt ^ (unsigned int)(i * 2654435761u);
+  __syncthreads();
+  int bad = 0;
+  for (int r = 0; r < rounds; ++r) {
+    __builtin_amdgcn_s_sleep(100);
+    for (int i = threadIdx.x; i < words; i += 256) {
+      const unsigned int want = salt ^ (unsigned int)(i * 2654435761u);
+      if (canary[i] != want) { ++bad; canary[i] = want; }
+    }
+    __syncthreads();
+  }
+  if (bad) atomicAdd(out, (float)bad);
+  if (threadIdx.x == 0) atomicAdd(out + 1, 1.f);
+}
+
+// probe 3: instruction-class canaries of a 256-thread workgroup with 16.5 KB of dynamic LDS (the footprint of msda_d32_kernel), to be run
+// beside another kernel on a second stream.  out[4 + c] counts the mismatches of class c:
+//   0  global_load_dword of a known pattern through L1 (per-lane addresses, re-read many times)
+//   1  ds_write_b128 by one lane -> lgkmcnt(0) -> ds_read_b128 by ANOTHER lane of the same wave (no workgroup barrier), as msda's records
+//   2  ds_bpermute_b32 (the __shfl_xor butterflies of an 8-lane group)
+//   3  global_load_dwordx4 gathers of 128-byte segments (8 lanes x 16 B), the value fetches of msda
+__global__ __launch_bounds__(256) void selftest_class_canary_kernel(const unsigned int* __restrict__ pat, int npat, int rounds,
+                                                                   float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned int lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  unsigned int* rec = lds + (tid >> 3) * 132;                 // msda's record block of this 8-lane group
+  const int sub = tid & 7;
+  int bad0 = 0, bad1 = 0, bad2 = 0, bad3 = 0;
+  unsigned int h = 0x9E3779B9u * (blockIdx.x * 256u + tid + 1u);
+  for (int r = 0; r < rounds; ++r) {
+    h = h * 1664525u + 1013904223u;
+    // class 0
+    const unsigned int i0 = (h >> 8) % (unsigned int)npat;
+    if (pat[i0] != (i0 * 2654435761u ^ 0xA5A5A5A5u)) ++bad0;
+    // class 1: lane `sub` publishes records sub and sub + 8 of its group, then every lane reads all 16
+    for (int i = sub; i < 16; i += 8) {
+      const unsigned int base = (unsigned int)(blockIdx.x * 131 + (tid >> 3) * 17 + i) * 2246822519u + (unsigned int)r;
+      *reinterpret_cast<uint4*>(rec + i * 8) = make_uint4(base, base + 1u, base + 2u, base + 3u);
+      *reinterpret_cast<uint4*>(rec + i * 8 + 4) = make_uint4(base + 4u, base + 5u, base + 6u, base + 7u);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i < 16; ++i) {
+      const unsigned int base = (unsigned int)(blockIdx.x * 131 + (tid >> 3) * 17 + i) * 2246822519u + (unsigned int)r;
+      const uint4 a = *reinterpret_cast<const uint4*>(rec + i * 8), b = *reinterpret_cast<const uint4*>(rec + i * 8 + 4);
+      if (a.x != base || a.y != base + 1u || a.z != base + 2u || a.w != base + 3u || b.x != base + 4u || b.y != base + 5u ||
+          b.z != base + 6u || b.w != base + 7u) ++bad1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // class 2
+    const unsigned int mine = (unsigned int)(lane * 40503u + r);
+    for (int x = 1; x <= 4; x <<= 1) {
+      const unsigned int got = (unsigned int)__shfl_xor((int)mine, x);
+      if (got != (unsigned int)((lane ^ x) * 40503u + r)) ++bad2;
+    }
+    // class 3: group `tid >> 3` gathers a pseudo-random 128-byte segment, lane sub its 16 bytes
+    const unsigned int gh = (0x85EBCA6Bu * (blockIdx.x * 32u + (tid >> 3) + 1u)) + (unsigned int)r * 0xC2B2AE35u;
+    const unsigned int seg = (gh >> 7) % (unsigned int)(npat / 32);
+    const uint4 v = *reinterpret_cast<const uint4*>(pat + seg * 32 + sub * 4);
+    const unsigned int e0 = seg * 32 + sub * 4;
+    if (v.x != (e0 * 2654435761u ^ 0xA5A5A5A5u) || v.y != ((e0 + 1) * 2654435761u ^ 0xA5A5A5A5u) ||
+        v.z != ((e0 + 2) * 2654435761u ^ 0xA5A5A5A5u) || v.w != ((e0 + 3) * 2654435761u ^ 0xA5A5A5A5u)) ++bad3;
+  }
+  if (bad0) atomicAdd(out + 4, (float)bad0);
+  if (bad1) atomicAdd(out + 5, (float)bad1);
+  if (bad2) atomicAdd(out + 6, (float)bad2);
+  if (bad3) atomicAdd(out + 7, (float)bad3);
+  if (tid == 0) atomicAdd(out + 1, 1.f);
+}
+
 }  // namespace hipie
 
 extern "C" int hipie_selftest(int which, const uint16_t* a, const uint16_t* b, float* out, void* stream) {
@@ -42,6 +120,13 @@ extern "C" int hipie_selftest(int which, const uint16_t* a, const uint16_t* b, f
     hipLaunchKernelGGL(selftest_mfma_kernel, dim3(1), dim3(64), 0, st, (const bf16_t*)a, (const bf16_t*)b, out);
   } else if (which == 1) {
     hipLaunchKernelGGL(selftest_tr_kernel, dim3(1), dim3(64), 0, st, (const bf16_t*)a, out);
+  } else if (which == 2) {
+    // a = (words, rounds) as two uint16 on the HOST side of the call is not possible (device pointer): a points to a 2-element device array;
+    // b (optional) = grid size as its first element's address reinterpreted -- kept simple: 4096 workgroups of 256 threads, 16896 bytes each
+    hipLaunchKernelGGL(selftest_lds_canary_kernel, dim3(4096), dim3(256), 16896, st, a, out);
+  } else if (which == 3) {
+    // a = pattern array of 1 << 20 dwords (pat[i] = i * 2654435761 ^ 0xA5A5A5A5), device memory
+    hipLaunchKernelGGL(selftest_class_canary_kernel, dim3(4096), dim3(256), 16896, st, (const unsigned int*)a, 1 << 20, 64, out);
   } else {
     return set_err(HIPIE_EINVAL, "selftest: unknown probe %d", which);
   }

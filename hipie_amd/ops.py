@@ -590,7 +590,7 @@ def group_norm(x, groups, weight, bias, eps, relu=False, prebias=None, out_dtype
         raise RuntimeError("group_norm: x must be NCHW- or channels-last-contiguous")
     out_dtype = out_dtype or x.dtype
     out = torch.empty_like(x, dtype=out_dtype)            # preserves the memory format
-    key = (str(x.device), B * groups)
+    key = (str(x.device), B * groups, torch.cuda.current_stream(x.device).cuda_stream)      # per stream: the two branches of the head overlap
     ws = _GN_WS.get(key)
     if ws is None:
         ws = _GN_WS[key] = torch.empty(2 * B * groups * 512, dtype=torch.float32, device=x.device)

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""wall time of the main stages of one bench forward (HIP events around the modules' forward calls, eager launches):
-where the step goes after the backbone.  Output: gpurun_out/stage_times.txt"""
+"""GPU time of the main stages of one bench forward and of every hand-written kernel class.  Stage rows: the device is SYNCHRONISED in
+front of and behind each stage's forward and the host clock is read there (side streams off), so a row is that stage's own GPU time --
+the rows of nested stages add up (round 4 bracketed the stages with HIP events on a stream the host was ~1000 launches ahead of; the
+`backbone` row of profiles/r04_stage_times.txt came out as the whole forward).  The synchronisations cost the overlap between stages,
+so the sum sits slightly above the free-running forward, which is printed first.  Output: gpurun_out/stage_times.txt"""
 import os
 import sys
 
@@ -29,18 +32,21 @@ def main():
               "mask_head (CondInst convs)": d.mask_head, "whole DDETRSegmUniDN": d}
     rec = {k: [] for k in stages}
 
+    import time
+    hooks_on = [False]
+
     def pre(name):
         def f(m, a, kw=None):
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()
-            rec[name].append([e, None])
+            if hooks_on[0]:
+                torch.cuda.synchronize()
+                rec[name].append([time.perf_counter(), None])
         return f
 
     def post(name):
         def f(m, a, out):
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()
-            rec[name][-1][1] = e
+            if hooks_on[0]:
+                torch.cuda.synchronize()
+                rec[name][-1][1] = time.perf_counter()
         return f
     for k, m in stages.items():
         if isinstance(m, torch.nn.ModuleList):          # input_proj: time each member, summed
@@ -53,15 +59,20 @@ def main():
     for _ in range(3):
         model.forward_raw(batch)
     torch.cuda.synchronize()
-    for k in rec:
-        rec[k].clear()
     n = 3
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0.record()
     for _ in range(n):
-        model.forward_raw(batch)
+        model.forward_raw(batch)                      # free-running (hooks inert, side streams as configured)
     t1.record()
     torch.cuda.synchronize()
+    streams = d.use_streams
+    d.use_streams = False                             # stage rows: one stream, synchronised stage boundaries
+    hooks_on[0] = True
+    for _ in range(n):
+        model.forward_raw(batch)
+    hooks_on[0] = False
+    d.use_streams = streams
     os.makedirs("gpurun_out", exist_ok=True)
     from hipie_amd import ops
     ops.PROFILE.shapes = len(sys.argv) > 2 and sys.argv[2] == "shapes"
@@ -70,11 +81,11 @@ def main():
     prof = ops.PROFILE.summary()
     ops.PROFILE.disable()
     with open("gpurun_out/stage_times.txt", "w") as f:
-        f.write("policy %s: forward_raw %.2f ms (mean of %d, with hooks)\n" % (pol, t0.elapsed_time(t1) / n, n))
+        f.write("policy %s: forward_raw %.2f ms free-running (mean of %d; side streams %s)\n" % (pol, t0.elapsed_time(t1) / n, n, "on" if streams else "off"))
         for tag, (mean, cnt, tot) in sorted(prof.items(), key=lambda kv: -kv[1][2]):
             f.write("   kernel class %-18s n=%4d mean=%8.3f ms total=%8.2f ms\n" % (tag, cnt, mean, tot))
         for k, v in rec.items():
-            f.write("%-40s %8.2f ms  (%d calls / forward)\n" % (k, sum(a.elapsed_time(b) for a, b in v) / n, len(v) // n))
+            f.write("%-40s %8.2f ms  (%d calls / forward; synchronised boundaries)\n" % (k, sum((b - a) * 1e3 for a, b in v) / n, len(v) // n))
     print(open("gpurun_out/stage_times.txt").read())
 
 
