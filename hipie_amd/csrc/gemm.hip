@@ -81,6 +81,9 @@ __device__ __forceinline__ void gm_dma16(const char* sbase, unsigned int voff, u
 // x < -4, where 1 + erf cancels.  16 VALU instructions, two of them transcendental, no branch: ocml's erff is two polynomial branches
 // (both executed by a wavefront) around an exp -- the fc1 epilogue (160 values per lane and tile) was 0.145 ms per launch behind fc2's.
 __device__ __forceinline__ float gm_gelu(float x) {
+#ifdef HIPIE_GELU_ERFF
+  return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+#endif
   const float a = __builtin_fabsf(x);
   const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.27601078152656555f, a, 1.f));
   float q = -0.113462433218956f;
@@ -118,7 +121,7 @@ typedef _Float16 gm_h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void gm_split2(float x0, float x1, unsigned int& H, unsigned int& L) {
   x0 = __builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f);
   x1 = __builtin_amdgcn_fmed3f(x1, -65504.f, 65504.f);
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HIPIE_NO_FMA_MIX)
   // hi = fp16(x) for the pair in one v_cvt_pk_f16_f32; lo = fp16(x - hi) in ONE v_fma_mix{lo,hi}_f16 each (the fp16 hi is an fp16 source
   // operand of the fma, x - hi is exact, one rounding): the same bits as `(f16)(x - (float)(f16)x)`, which costs a convert, a convert back
   // and a subtract per value.  The asm operands are the register values themselves: nothing for the compiler to re-fold (see hl_split).
@@ -128,6 +131,12 @@ __device__ __forceinline__ void gm_split2(float x0, float x1, unsigned int& H, u
   asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(x1));
   H = h;
   L = l;
+#else
+  gm_h2 h, l;
+  h[0] = (f16_t)x0; h[1] = (f16_t)x1;
+  l[0] = (f16_t)(x0 - (float)h[0]); l[1] = (f16_t)(x1 - (float)h[1]);
+  H = __builtin_bit_cast(unsigned int, h);
+  L = __builtin_bit_cast(unsigned int, l);
 #endif
 }
 
@@ -196,6 +205,11 @@ __device__ __forceinline__ void gm_epi_vals(const float (&x)[NG][4], const int G
         unsigned int H0, L0, H1, L1;
         gm_split2(v[g][0], v[g][1], H0, L0);
         gm_split2(v[g][2], v[g][3], H1, L1);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HIPIE_NO_FMA_MIX)
+        // the split above is inline asm, which hipcc's hazard recogniser does not look into: v_permlane32_swap must not read a VGPR in the
+        // two wait states behind the VALU instruction that wrote it (see vs_settle in vit_attn_split.hip)
+        asm volatile("s_nop 1" : "+v"(H0), "+v"(L0), "+v"(H1), "+v"(L1));
+#endif
         const u32x2 s0 = __builtin_amdgcn_permlane32_swap(H0, L0, false, false);    // lower: (H0 own, H0 of upper); upper: (L0 of lower, L0 own)
         const u32x2 s1 = __builtin_amdgcn_permlane32_swap(H1, L1, false, false);
         piece[g] = (u32x4){s0[0], s1[0], s0[1], s1[1]};

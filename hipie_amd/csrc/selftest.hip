@@ -109,6 +109,30 @@ __global__ __launch_bounds__(256) void selftest_class_canary_kernel(const unsign
   if (tid == 0) atomicAdd(out + 1, 1.f);
 }
 
+// probe 4: the fp16-pair split in its two forms.  a = n float pairs (as raw 32-bit words), out[0] += pairs whose (hi, lo) words differ
+// between the C++ form ((f16)x, (f16)(x - (float)(f16)x)) and the v_cvt_pk_f16_f32 + v_fma_mix{lo,hi}_f16 form; out[2..5] = first mismatch
+__global__ void selftest_split_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = x[2 * i], b = x[2 * i + 1];
+  h2 hc, lc;
+  hc[0] = (f16_t)a; hc[1] = (f16_t)b;
+  lc[0] = (f16_t)(a - (float)hc[0]); lc[1] = (f16_t)(b - (float)hc[1]);
+  unsigned int h, l;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a), "v"(b));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(a));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(b));
+  const unsigned int hcw = __builtin_bit_cast(unsigned int, hc), lcw = __builtin_bit_cast(unsigned int, lc);
+  if (h != hcw || l != lcw) {
+    if (atomicAdd(out, 1.f) == 0.f) {
+      out[2] = a; out[3] = b;
+      out[4] = __builtin_bit_cast(float, h); out[5] = __builtin_bit_cast(float, hcw);
+      out[6] = __builtin_bit_cast(float, l); out[7] = __builtin_bit_cast(float, lcw);
+    }
+  }
+}
+
 }  // namespace hipie
 
 extern "C" int hipie_selftest(int which, const uint16_t* a, const uint16_t* b, float* out, void* stream) {
@@ -124,6 +148,8 @@ extern "C" int hipie_selftest(int which, const uint16_t* a, const uint16_t* b, f
     // a = (words, rounds) as two uint16 on the HOST side of the call is not possible (device pointer): a points to a 2-element device array;
     // b (optional) = grid size as its first element's address reinterpreted -- kept simple: 4096 workgroups of 256 threads, 16896 bytes each
     hipLaunchKernelGGL(selftest_lds_canary_kernel, dim3(4096), dim3(256), 16896, st, a, out);
+  } else if (which == 4) {
+    hipLaunchKernelGGL(selftest_split_kernel, dim3(4096), dim3(256), 0, st, (const float*)a, 4096 * 256, out);
   } else if (which == 3) {
     // a = pattern array of 1 << 20 dwords (pat[i] = i * 2654435761 ^ 0xA5A5A5A5), device memory
     hipLaunchKernelGGL(selftest_class_canary_kernel, dim3(4096), dim3(256), 16896, st, (const unsigned int*)a, 1 << 20, 64, out);

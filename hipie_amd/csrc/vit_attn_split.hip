@@ -62,13 +62,30 @@ __device__ __forceinline__ float vs_xhalf_max(float x) {
 // v_cvt_f16_f32, a v_cvt_f32_f16 and a v_sub_f32 per VALUE on top of the two packs: 4 instead of 1.5 VALU per probability, 80 of the
 // ~230 VALU instructions a wave issues per 64-key tile of the global-attention instance.
 __device__ __forceinline__ void vs_split2(const float a, const float b, unsigned int& H, unsigned int& L) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(HIPIE_NO_FMA_MIX)
+  typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+  h2v h, l;
+  h[0] = (f16_t)a; h[1] = (f16_t)b;
+  l[0] = (f16_t)(a - (float)h[0]); l[1] = (f16_t)(b - (float)h[1]);
+  H = __builtin_bit_cast(unsigned int, h);
+  L = __builtin_bit_cast(unsigned int, l);
+#elif defined(__HIP_DEVICE_COMPILE__)
   unsigned int h, l;
   asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a), "v"(b));
   asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(a));
   asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(b));
   H = h;
   L = l;
+#endif
+}
+
+// hipcc's hazard recogniser does not look inside inline asm: a VGPR written by the statements above and read by the NEXT instruction as an
+// MFMA operand or by v_permlane*_swap is read too early (gfx950 needs 2 wait states there; round 5: the a22 error of the full-depth
+// fixture went from 5e-5 to 1e-3 -- isolated stale fragments -- until this was added; tools/split_form_check.py shows the split itself
+// is bit-identical to the C++ form).  One s_nop behind a block of splits, tied to every register the block wrote.
+__device__ __forceinline__ void vs_settle(unsigned int (&h)[4], unsigned int (&l)[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_nop 1" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]));
 #endif
 }
 
@@ -363,7 +380,10 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
         for (int r = 0; r < 16; ++r) S[blk][r] += (32 * blk + crow(r, hi) < kw) ? bh0 : bh1;
     }
     // four independent v_max3 chains: a single chain made hipcc put a wait state behind every link (inline-asm VALU feeding the next one)
-    float mx = -INFINITY, mxb = -INFINITY, mxc = -INFINITY, mxd = -INFINITY;
+    // The first link of two chains is a C++ fmaxf on an element of the FIRST and of the LAST score block: a VALU read of MFMA results that
+    // hipcc can see, so it places the MFMA -> VALU wait states there (it does not look inside the v_max3 asm statements, which could
+    // otherwise read an accumulator the matrix pipe has not finished writing); everything behind reads completed registers.
+    float mx = __builtin_fmaxf(S[0][0], S[0][1]), mxb = __builtin_fmaxf(S[NB - 1][2], S[NB - 1][3]), mxc = -INFINITY, mxd = -INFINITY;
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
@@ -406,15 +426,16 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
       // (lane = query li, the lane half's 8 keys of the step), which IS the B operand of the 32x32x16 products
       u32x4 p_h[2][2], p_l[2][2];
       auto make_p = [&](const int blk, const int st, u32x4& Hh, u32x4& Ll) {
+        unsigned int hh[4], ll[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float p0 = __builtin_amdgcn_exp2f(S[blk][8 * st + 2 * j] + off), p1 = __builtin_amdgcn_exp2f(S[blk][8 * st + 2 * j + 1] + off);
           l_run += p0 + p1;                    // fp32 row sums of the unrounded probabilities (no spare O^T row for a ones column here)
-          unsigned int hh, ll;
-          vs_split2(p0, p1, hh, ll);
-          Hh[j] = hh;
-          Ll[j] = ll;
+          vs_split2(p0, p1, hh[j], ll[j]);
         }
+        vs_settle(hh, ll);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { Hh[j] = hh[j]; Ll[j] = ll[j]; }
       };
       // tail A operand (V^T rows 32 DBB .. + 15 over the 32 keys of a block): lane group g = lane >> 4 holds the k-group the swapped P
       // fragments give it -- keys {0-3, 8-11}, {16-19, 24-27}, {4-7, 12-15}, {20-23, 28-31} of the block for g = 0 .. 3 -- as two transposing reads
@@ -481,18 +502,16 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
     } else {
     frag pf, pfl;                // the probabilities of a 16-key step as an fp16 pair: hi, and lo = fp16(p - hi)
     {
-      u32x4 ph4, pl4;
+      unsigned int hh[4], ll[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float p0 = __builtin_amdgcn_exp2f(S[0][2 * j] + off), p1 = __builtin_amdgcn_exp2f(S[0][2 * j + 1] + off);
         if (!ONES) l_run += p0 + p1;
-        unsigned int hh, ll;
-        vs_split2(p0, p1, hh, ll);
-        ph4[j] = hh;
-        pl4[j] = ll;
+        vs_split2(p0, p1, hh[j], ll[j]);
       }
-      pf = __builtin_bit_cast(frag, ph4);
-      pfl = __builtin_bit_cast(frag, pl4);
+      vs_settle(hh, ll);
+      pf = __builtin_bit_cast(frag, (u32x4){hh[0], hh[1], hh[2], hh[3]});
+      pfl = __builtin_bit_cast(frag, (u32x4){ll[0], ll[1], ll[2], ll[3]});
     }
 #pragma unroll
     for (int u = 0; u < 4 * NB; ++u) {
@@ -513,18 +532,16 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
         }
         if (npl == 0) {           // a new step follows: its probabilities
           const int nb_ = nstep >> 1, ns_ = nstep & 1;
-          u32x4 ph4, pl4;
+          unsigned int hh[4], ll[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float p0 = __builtin_amdgcn_exp2f(S[nb_][8 * ns_ + 2 * j] + off), p1 = __builtin_amdgcn_exp2f(S[nb_][8 * ns_ + 2 * j + 1] + off);
             if (!ONES) l_run += p0 + p1;
-            unsigned int hh, ll;
-            vs_split2(p0, p1, hh, ll);
-            ph4[j] = hh;
-            pl4[j] = ll;
+            vs_split2(p0, p1, hh[j], ll[j]);
           }
-          pn = __builtin_bit_cast(frag, ph4);
-          pnl = __builtin_bit_cast(frag, pl4);
+          vs_settle(hh, ll);
+          pn = __builtin_bit_cast(frag, (u32x4){hh[0], hh[1], hh[2], hh[3]});
+          pnl = __builtin_bit_cast(frag, (u32x4){ll[0], ll[1], ll[2], ll[3]});
         }
       }
       // plane 0 (V_hi): both halves of P;  plane 1 (V_lo): P_hi only (lo x lo is below fp32 rounding)

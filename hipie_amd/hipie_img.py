@@ -169,22 +169,8 @@ class HIPIE_IMG(nn.Module):
         if not self._final:
             self.finalize()
         images = self.preprocess_image(batched_inputs)
-        lang_event = None
-        if self.detr.use_streams and self.device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
-            # the text encoder (a ~2 ms chain of small launches) runs on the side stream beside the backbone; coco_inference waits for it
-            # where the language features are first read
-            from .modeling.ddetrs_dn import _side_stream
-            side = _side_stream(self.device)
-            side.wait_stream(torch.cuda.current_stream())      # (also makes the side stream part of a hipGraph capture of the caller's stream)
-            with torch.cuda.stream(side):
-                lang = self.forward_text(batched_inputs)
-                lang_event = side.record_event()
-            for v in lang.values():
-                if torch.is_tensor(v):
-                    v.record_stream(torch.cuda.current_stream())
-        else:
-            lang = self.forward_text(batched_inputs)
-        outputs, _ = self.detr.coco_inference(images, None, None, train=False, language_dict_features=lang, task=task, lang_event=lang_event)
+        lang = self.forward_text(batched_inputs)
+        outputs, _ = self.detr.coco_inference(images, None, None, train=False, language_dict_features=lang, task=task)
         outputs["image_sizes"] = images.image_sizes
         return outputs
 

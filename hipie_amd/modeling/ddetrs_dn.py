@@ -13,18 +13,6 @@ from .transformer import (MLP, FeatureResizer, NestedTensor, PConv2d, _get_clone
                           nested_tensor_from_images)
 
 
-_SIDE_STREAMS = {}
-
-
-def _side_stream(device):
-    """one side stream per device for the branch / text-encoder overlap (created on first use)"""
-    key = str(device)
-    st = _SIDE_STREAMS.get(key)
-    if st is None:
-        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return st
-
-
 class MaskHeadSmallConv(nn.Module):
     """ddetrs_dn.py:1580-1689 with fpn_dims=None, use_raft=False: five 3x3 convs, nearest-upsample adds."""
 
@@ -66,31 +54,27 @@ class DDETRSegmUniDN(nn.Module):
         self.feature_keys = ["res3", "res4", "res5"]
         self.mask_dino_cls_embed = _get_clones(self.detr.class_embed[0], cfg.md_dec_layers + 2)
         self.cfg = cfg
-        import os
-        self.use_streams = os.environ.get("HIPIE_STREAMS", "1") != "0"      # the text encoder on a side stream (HIPIE_IMG.forward_raw)
 
     def post_process_maskdino(self, outputs, language_feat, idx=-1):
         outputs["pred_logits"] = self.mask_dino_cls_embed[idx](outputs["pred_logits"], language_feat)
         return outputs
 
     def coco_inference(self, samples, gt_targets=None, criterion=None, train=False, language_dict_features=None,
-                       task=None, bg_queries_lang=None, lang_event=None):
+                       task=None, bg_queries_lang=None):
         """samples: object with .image_sizes and iteration over the (unpadded) normalised images (ImageList-like).
-        lang_event: HIP event behind which language_dict_features (computed on a side stream, HIPIE_IMG.forward_raw) is complete.
 
-        Streams: only the text encoder runs beside other work (HIPIE_STREAMS=0 switches that off).  Round 5 also ran the MaskDINO head on
-        the side stream beside the deformable transformer (the two branches are independent until the MaskDINO class logits): -6 ms per
-        bs-8 step -- and a22 outputs that moved by ~1e-3 from run to run.  tools/concurrency_stress.py traced it to hipie_msda_fused, which
-        returns wrong values for isolated pairs of (query, head) groups when its workgroups share a CU with workgroups of hipie_gemm's tile
-        kernels -- never alone, never beside other kernels; mechanism not found.  Until it is, the branches stay in order."""
+        One stream, in order.  Round 5 tried two overlaps on a side stream (tools/ab_streams.py at that commit): the text encoder beside
+        the backbone -- correct, and no gain (the backbone's kernels fill the chip; 198.9 vs 198.9 ms per bs-8 step) -- and the MaskDINO head
+        beside the deformable transformer (the branches are independent until the MaskDINO class logits): -6 ms per step, but a22 outputs that
+        moved by ~1e-3 from run to run.  tools/concurrency_stress.py traced that to hipie_msda_fused, which returns wrong values for isolated
+        pairs of (query, head) groups when its workgroups share a CU with workgroups of hipie_gemm's tile kernels -- never alone, never beside
+        other kernels; the mechanism was not found, so the branches stay in order."""
         assert not train
         image_sizes = samples.image_sizes
         if not isinstance(samples, NestedTensor):
             div = getattr(self.detr.backbone[0].backbone, "size_divisibility", 32)
             samples = nested_tensor_from_images(list(samples), size_divisibility=div, stacked=getattr(samples, "tensor", None))
         features, pos = self.detr.backbone(samples)
-        if lang_event is not None:
-            torch.cuda.current_stream().wait_event(lang_event)
         if task in ("grounding", "sot"):
             lang_feat_pool = agg_lang_feat(language_dict_features["hidden"], language_dict_features["masks"]).unsqueeze(1)
         elif task != "detection":

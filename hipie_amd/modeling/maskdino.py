@@ -36,8 +36,19 @@ class FoldedMaskFeatures(object):
     """the mask_features head without its last 1x1 convolution (weight (256,256), bias (256)): `pre` (B,256,H/4,W/4) NCHW, fp32 or
     the 16-bit activation dtype."""
 
-    def __init__(self, pre, weight, bias):
-        self.pre, self.weight, self.bias = pre, weight, bias
+    def __init__(self, pre, weight, bias, owner=None):
+        self.pre, self.weight, self.bias, self.owner = pre, weight, bias, owner
+
+    def fold(self, e32):
+        """(emb . W, emb . b) for emb (B, Q, C_out): the query side of the folded convolution.  On the device with an owning module (the
+        convolution, which carries the cache of the split weight): ONE hipie_gemm whose extra output row is the bias vector."""
+        w, b = self.weight, self.bias
+        if self.owner is not None and e32.is_cuda and w.dtype == torch.float32 and ops.split_ok(w.shape[0]):
+            cin = w.shape[1]
+            y = ops.split_linear(e32.contiguous(), self.owner, "fold_aug", self.owner.weight, None,
+                                 weight_fn=lambda: torch.cat([w.float().t(), b.float()[None]], 0), params=[self.owner.weight, self.owner.bias])
+            return y[..., :cin].contiguous(), y[..., cin].contiguous()
+        return (e32 @ w.float()).contiguous(), e32 @ b.float()
 
 
 class MSDeformAttnTransformerEncoder(nn.Module):
@@ -150,7 +161,8 @@ class MaskDINOEncoder(nn.Module):
             # map disappear; x stays fp32, NCHW
             x = self._mask_features_front(z, torch.float32)
             conv = self.mask_features[3]
-            mf = FoldedMaskFeatures(x.float().contiguous(), conv.weight.reshape(conv.weight.shape[0], -1), conv.bias)
+            mf = FoldedMaskFeatures(x.float().contiguous(), conv.weight.reshape(conv.weight.shape[0], -1), conv.bias,
+                                    owner=conv if getattr(self.precision, "split", False) else None)
         else:
             mf = self.mask_features[3](self._mask_features_front(z, torch.float32))
             mf = mf.float().contiguous()  # NCHW fp32, pixel fastest: hipie_mask_einsum's operand layout, produced once for both calls
@@ -202,16 +214,15 @@ class MaskDINODecoder(nn.Module):
             emb = self.mask_embed(dec)
             if isinstance(mask_features, FoldedMaskFeatures):      # 16-bit features: 3 = single product, 4 = embedding split hi + lo; fp32: 1 | 2
                 e32 = emb.float()
-                w, b = mask_features.weight.float(), mask_features.bias.float()
                 pre = mask_features.pre
+                ew, eb = mask_features.fold(e32)
                 if pre.dtype == torch.float32:                      # fp32 features: the bf16-split contraction with a row bias
-                    masks = ops.mask_einsum((e32 @ w).contiguous(), pre, precision=self.precision.einsum, out_dtype=self.precision.act,
-                                            row_bias=e32 @ b)
+                    masks = ops.mask_einsum(ew, pre, precision=self.precision.einsum, out_dtype=self.precision.act, row_bias=eb)
                 elif e32.shape[1] <= 320 and (pre.shape[-1] * pre.shape[-2]) % 8 == 0:
-                    masks = ops.mask_einsum16(e32 @ w, pre, split=self.precision.einsum == 4, row_bias=e32 @ b)
+                    masks = ops.mask_einsum16(ew, pre, split=self.precision.einsum == 4, row_bias=eb)
                 else:       # more queries than the 16-bit kernel's tile (or an odd pixel count): the fp32-feature kernel, bias added after
-                    masks = ops.mask_einsum((e32 @ w).contiguous(), pre.float().contiguous(), precision=1, out_dtype=self.precision.act)
-                    masks = masks + (e32 @ b).to(masks.dtype)[..., None, None]
+                    masks = ops.mask_einsum(ew, pre.float().contiguous(), precision=1, out_dtype=self.precision.act)
+                    masks = masks + eb.to(masks.dtype)[..., None, None]
             else:
                 masks = ops.mask_einsum(emb.float().contiguous(), mask_features, precision=self.precision.einsum,
                                         out_dtype=self.precision.act)

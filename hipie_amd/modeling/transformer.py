@@ -899,7 +899,21 @@ class VL_Align(nn.Module):
 
     def forward(self, x, embedding):
         embedding = F.normalize(embedding, p=2, dim=-1)
-        tok = self.dot_product_projection_text(embedding / 2.0)
+        p = self.dot_product_projection_text
+        if (getattr(p, "split", False) and x.is_cuda and x.dim() == 3 and embedding.dim() == 3 and p.weight.dtype == torch.float32
+                and ops.split_ok(embedding.shape[-1]) and ops.split_ok(p.weight.shape[0])):
+            # split policy: no library GEMM here either.  The token projection and the language bias `embedding . bias_lang` are ONE
+            # hipie_gemm (the bias vector is an extra output row of the projection: the operand is embedding / 2, so the row is 2 bias_lang),
+            # the per-image logits `x . tok^T` one hipie_gemm_batched launch
+            d = p.weight.shape[0]
+            ta = ops.split_linear((embedding * 0.5).contiguous(), self, "tok_aug", p.weight, p.bias,
+                                  weight_fn=lambda: torch.cat([p.weight.float(), 2.0 * self.bias_lang.float()[None]], 0),
+                                  bias_fn=lambda: torch.cat([p.bias.float(), torch.zeros(1, device=p.bias.device)], 0),
+                                  params=[p.weight, p.bias, self.bias_lang])
+            tok, bias = ta[..., :d], ta[..., d] + self.bias0
+            logit = ops.matmul_nt_batched(x.float(), tok.contiguous()) / self.log_scale.exp() + bias.unsqueeze(1)
+            return logit.clamp(max=50000).clamp(min=-50000)
+        tok = p(embedding / 2.0)
         bias = torch.matmul(embedding, self.bias_lang) + self.bias0
         logit = torch.matmul(x, tok.transpose(-1, -2)) / self.log_scale.exp() + bias.unsqueeze(1)
         return logit.clamp(max=50000).clamp(min=-50000)

@@ -953,6 +953,29 @@ def vit_attn_split(qkv, tab_h, tab_w, grid_hw, heads):
     return out
 
 
+@_timed("gemm_batched")
+def matmul_nt_batched(a, w, alpha=1.0):
+    """out[b] = alpha * a[b] . w[b]^T at fp32-class accuracy on hipie_gemm_batched: a (B, M, K), w (B, N, K) fp32 device tensors,
+    K % 32 == 0 -> (B, M, N) fp32.  The operands are split to HL8 on the way in; N is padded to a multiple of 8 with zero rows.  For the
+    per-image products of the heads (class logits = queries . token embeddings^T, VL_Align: deformable_detr.py:55-73)."""
+    lib = _lib.load()
+    B, M, K = a.shape
+    N = w.shape[1]
+    if w.shape[0] != B or w.shape[2] != K or K % 32 or not a.is_cuda:
+        raise RuntimeError("matmul_nt_batched: a (B, M, K), w (B, N, K) device tensors with K %% 32 == 0, got %s / %s" % (tuple(a.shape), tuple(w.shape)))
+    Np = (N + 7) // 8 * 8
+    if Np != N:
+        wp = torch.zeros(B, Np, K, dtype=torch.float32, device=w.device)
+        wp[:, :N] = w
+        w = wp
+    ah, wh = to_hl8(a.float().contiguous()), to_hl8(w.float().contiguous())
+    out = torch.empty(B, M, Np, dtype=torch.float32, device=a.device)
+    rc = lib.hipie_gemm_batched(ah.data_ptr(), 2 * K, M * 2 * K, 0, wh.data_ptr(), 2 * K, Np * 2 * K, 0, out.data_ptr(), Np, M * Np, 0,
+                                B, 1, M, Np, K, F32, float(alpha), _stream())
+    _lib.check(rc, "hipie_gemm_batched")
+    return out if Np == N else out[..., :N]
+
+
 def vit_attn_split_ok(grid_hw, hd):
     """geometry hipie_vit_attn_split covers: head_dim 64 / 80, 14-wide windows, token grids up to 96 wide (64 x 64 at 1024^2, 84 x 84 at
     1344^2) and -- walked column by column -- grids wider than 96 whose height is <= 96 (64 x 128: a 1024 x 2048 image, the eval yamls'

@@ -98,7 +98,6 @@ def main():
     from hipie_amd.config import HipieConfig, Precision
     from hipie_amd.hipie_img import HIPIE_IMG
     dev = torch.device("cuda", 0)
-    os.environ["HIPIE_STREAMS"] = "0"
     if len(sys.argv) > 1 and sys.argv[1] == "tiny":
         import _synth
         from util import Golden
@@ -115,7 +114,6 @@ def main():
         bench.randomize_degenerate_inits(model)
         batch = bench.synth_batch(cfg, 8, 1024, 80, 194, dev)
     model.finalize()
-    model.detr.use_streams = False
     for it in range(2):
         model.forward_raw(batch)
         torch.cuda.synchronize()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU time of the main stages of one bench forward and of every hand-written kernel class.  Stage rows: the device is SYNCHRONISED in
-front of and behind each stage's forward and the host clock is read there (side streams off), so a row is that stage's own GPU time --
+front of and behind each stage's forward and the host clock is read there, so a row is that stage's own GPU time --
 the rows of nested stages add up (round 4 bracketed the stages with HIP events on a stream the host was ~1000 launches ahead of; the
 `backbone` row of profiles/r04_stage_times.txt came out as the whole forward).  The synchronisations cost the overlap between stages,
 so the sum sits slightly above the free-running forward, which is printed first.  Output: gpurun_out/stage_times.txt"""
@@ -63,16 +63,13 @@ def main():
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0.record()
     for _ in range(n):
-        model.forward_raw(batch)                      # free-running (hooks inert, side streams as configured)
+        model.forward_raw(batch)                      # free-running (hooks inert)
     t1.record()
     torch.cuda.synchronize()
-    streams = d.use_streams
-    d.use_streams = False                             # stage rows: one stream, synchronised stage boundaries
     hooks_on[0] = True
     for _ in range(n):
         model.forward_raw(batch)
     hooks_on[0] = False
-    d.use_streams = streams
     os.makedirs("gpurun_out", exist_ok=True)
     from hipie_amd import ops
     ops.PROFILE.shapes = len(sys.argv) > 2 and sys.argv[2] == "shapes"
@@ -81,7 +78,7 @@ def main():
     prof = ops.PROFILE.summary()
     ops.PROFILE.disable()
     with open("gpurun_out/stage_times.txt", "w") as f:
-        f.write("policy %s: forward_raw %.2f ms free-running (mean of %d; side streams %s)\n" % (pol, t0.elapsed_time(t1) / n, n, "on" if streams else "off"))
+        f.write("policy %s: forward_raw %.2f ms free-running (mean of %d)\n" % (pol, t0.elapsed_time(t1) / n, n))
         for tag, (mean, cnt, tot) in sorted(prof.items(), key=lambda kv: -kv[1][2]):
             f.write("   kernel class %-18s n=%4d mean=%8.3f ms total=%8.2f ms\n" % (tag, cnt, mean, tot))
         for k, v in rec.items():
