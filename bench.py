@@ -564,7 +564,7 @@ def main():
     if rank == 0:
         std = args.model == "vit_huge" and args.batch == 8 and args.size == 1024
         pmc = {}
-        for pmc_file in ("r03_pmc_kernels.json", "r04_pmc_kernels.json"):      # the newer round's rows (split GEMM, fused FFN) win
+        for pmc_file in ("r03_pmc_kernels.json", "r04_pmc_kernels.json", "r05_pmc_kernels.json"):      # the newest round's rows win
             pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_file)
             if os.path.exists(pmc_path) and std:
                 pmc.update(json.load(open(pmc_path)))
@@ -583,7 +583,8 @@ def main():
         g_flop = sum(2.0 * M_tok * k * n * gemm[t][1] for t, (k, n) in shapes.items() if gemm.get(t, (None, 0))[0])
         g_ach = g_flop / (g_ms * 1e-3) / 1e12 if g_ms else None
         roof_attn = {"bound": "mfma", "kernel": "%s (ViT global attention, %d launches timed)" %
-                     ("vit_attn_split_kernel<hd%d,NB2,8 waves>: split-fp16 logits (3 products), P and V as fp16 pairs (3 products)" % (E // cfg.vit_heads)
+                     ("vit_attn_split_kernel<hd%d,NB2,8 waves>: split-fp16 logits (3 products), P and V as fp16 pairs (3 products); hd 80 = two 32-row blocks + a "
+                      "16-row tail on v_mfma_f32_16x16x32_f16 (no head-dim padding)" % (E // cfg.vit_heads)
                       if split else "vit_attn_sp_kernel<%s,hd%d>" % (str(prec.attn).split(".")[-1], E // cfg.vit_heads), kern_n),
                      "achieved": None if ach is None else round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
                      "frac": None if ach is None else round(ach / 2500.0, 4), "mfma_flops_per_algorithmic_flop": 3.0 if split else 1.0,
@@ -602,7 +603,7 @@ def main():
                     "per_shape_ms": {t: round(gemm[t][0], 4) for t in shapes if gemm.get(t, (None, 0))[0]},
                     "traffic": pmc.get("gemm_qkv_split", {}).get("traffic_bytes_per_launch"),
                     "traffic_note": "bytes per launch of the qkv shape (0.81 ms; 691 MB algorithmic), rocprofv3 PMC FETCH_SIZE (x2, guide correction) + "
-                                    "WRITE_SIZE, separate passes: profiles/r04_pmc_kernels.json"}
+                                    "WRITE_SIZE, separate passes: profiles/r05_pmc_kernels.json (r04_pmc_kernels.json when absent)"}
         else:
             roof = roof_attn
         line = {
