@@ -366,15 +366,17 @@ class BiMultiHeadAttention(nn.Module):
         self.out_v_proj, self.out_l_proj = PLinear(embed_dim, v_dim), PLinear(embed_dim, l_dim)
         self.attn_dtype = attn_dtype
 
-    def forward(self, v, l, attention_mask_l=None, gamma_v=None, n_keys=None):
-        """n_keys: host-known number of leading text columns that hold every attended token (BertEncoder.forward): the image -> text
+    def forward(self, v, l, attention_mask_l=None, gamma_v=None, n_keys=None, resid_v=None):
+        """resid_v: the block's residual for the visual stream; the split path adds it in the epilogue of the output projection
+        (`self.resid_fused` tells the caller) instead of leaving a (B, Nv, 256) add pass behind.  n_keys: host-known number of leading text columns that hold every attended token (BertEncoder.forward): the image -> text
         direction of the split policy runs over those keys only -- masked keys have probability exactly 0 (fuse_helper.py:96-109)."""
         B, Nv, _ = v.shape
         L = l.shape[1]
         H, hd, dt = self.num_heads, self.head_dim, self.attn_dtype
         wq, bq = self._scaled_q()                              # v_proj with the 1/sqrt(head_dim) folded in: no (B, Nv, 2048) multiply pass
         if getattr(self, "split", False) and v.is_cuda and self.v_proj.weight.dtype == torch.float32 and hd % 32 == 0 and ops.split_ok(v.shape[-1]):
-            return self._forward_split(v, l, attention_mask_l, gamma_v, wq, bq, n_keys)
+            return self._forward_split(v, l, attention_mask_l, gamma_v, wq, bq, n_keys, resid_v)
+        self.resid_fused = False
         # the GEMM epilogue rounds to the attention operand dtype itself (bit-identical to fp32 out + .to(fp16), minus
         # a 178M-element cast pass per visual projection)
         of = ops.F16 if (getattr(self, "split", False) and dt == torch.float16) else ops.F32
@@ -390,7 +392,7 @@ class BiMultiHeadAttention(nn.Module):
         wo, bo = self._scaled_out(gamma_v)
         return _lin(self, "out_scaled", ov, wo, bo).to(self.out_v_proj.out_dtype), self.out_l_proj(ol)
 
-    def _forward_split(self, v, l, attention_mask_l, gamma_v, wq, bq, n_keys=None):
+    def _forward_split(self, v, l, attention_mask_l, gamma_v, wq, bq, n_keys=None, resid_v=None):
         """Precision.split3.  image -> text (the update of the 21760-token visual stream, whose error the decoder amplifies): fp32-class
         -- S = Q.K^T per (image, head) as one batched split GEMM from the HL8 projection, masked softmax -> HL8, P.V_text as the second
         batched GEMM (ops.bi_i2t_split).  text -> image (the language stream; its softmax averages over all visual tokens): the fp16
@@ -413,9 +415,13 @@ class BiMultiHeadAttention(nn.Module):
         ov = ops.bi_i2t_split(q_hl8.view(B, Nv, -1), k32.view(B, L, -1), vl32.view(B, L, -1), keep, H, clamp=50000.0, n_keys=n_keys)
         # text -> image: queries = text tokens, keys / values = visual tokens, no mask on that side (fuse_helper.py:85-95)
         ol = ops.flash_attn(k32.half().view(B, L, H, hd), q16, vv16, 1.0, clamp=50000.0, out_f32=True)
+        self.resid_fused = False
         if gamma_v is None:
             return self.out_v_proj(ov), self.out_l_proj(ol)
         wo, bo = self._scaled_out(gamma_v)
+        if resid_v is not None and resid_v.dtype == torch.float32 and resid_v.is_contiguous() and self.out_v_proj.out_dtype == torch.float32:
+            self.resid_fused = True
+            return ops.split_linear(ov, self, "out_scaled", wo, bo, resid=resid_v), self.out_l_proj(ol)
         return _lin(self, "out_scaled", ov, wo, bo).to(self.out_v_proj.out_dtype), self.out_l_proj(ol)
 
     def _scaled_out(self, gamma):
@@ -448,7 +454,9 @@ class BiAttentionBlockForCheckpoint(nn.Module):
 
     def forward(self, v, l, attention_mask_l=None, task=None, n_keys=None):
         v, l = self.layer_norm_v(v), self.layer_norm_l(l)
-        dv, dl = self.attn(v, l, attention_mask_l=attention_mask_l, gamma_v=self.gamma_v, n_keys=n_keys)
+        dv, dl = self.attn(v, l, attention_mask_l=attention_mask_l, gamma_v=self.gamma_v, n_keys=n_keys, resid_v=v)
+        if self.attn.resid_fused:
+            return dv, l + self.gamma_l * dl
         # gamma_v is folded into the visual output projection (weights only), so the 21760-token stream stays in its own
         # dtype: `v + gamma_v * dv` would promote it to fp32 and every later encoder GEMM would cast it back
         return v + dv.to(v.dtype), l + self.gamma_l * dl
