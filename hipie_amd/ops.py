@@ -443,6 +443,59 @@ def mask_einsum(mask_embed, mask_features, precision=1, out_dtype=torch.float32,
     return out
 
 
+def _pad_last(x, n):
+    if x.shape[-1] == n:
+        return x.contiguous()
+    out = torch.zeros(*x.shape[:-1], n, dtype=x.dtype, device=x.device)
+    out[..., :x.shape[-1]] = x
+    return out
+
+
+@_timed("mask_einsum_bwd")
+def mask_einsum_backward(mask_embed, mask_features, grad_out):
+    """gradients of einsum("bqc,bchw->bqhw") (row f-4): mask_embed (B,Q,C), mask_features (B,C,H,W), grad_out (B,Q,H,W) fp32 ->
+    (grad_embed (B,Q,C), grad_features (B,C,H,W)) fp32, both at fp32-class accuracy on hipie_gemm_batched (split operands):
+      grad_embed[b]    = G[b] (Q x HW) . F[b]^T (HW x C)   -- K = HW split into up to 32 chunks (one problem each: Q x C is 2-5 tiles
+                         per image, far fewer than the CUs), the partial products summed afterwards;
+      grad_features[b] = E[b]^T (C x Q) . G[b] (Q x HW)    -- as A . W^T with A = E^T and W = G^T (both K = Q contiguous, Q padded to 32).
+    The row-bias gradient of the forward's `row_bias` is grad_out.sum((2, 3)) (the caller's)."""
+    lib = _lib.load()
+    B, Q, C = mask_embed.shape
+    _, _, Hh, Ww = mask_features.shape
+    HW = Hh * Ww
+    if tuple(grad_out.shape) != (B, Q, Hh, Ww) or tuple(mask_features.shape[:2]) != (B, C) or not grad_out.is_cuda:
+        raise RuntimeError("mask_einsum_backward: mask_embed (B,Q,C), mask_features (B,C,H,W), grad_out (B,Q,H,W) device tensors")
+    if C % 8:
+        raise RuntimeError("mask_einsum_backward: C must be a multiple of 8")
+    dev = grad_out.device
+    G = grad_out.float().reshape(B, Q, HW)
+    F_ = mask_features.float().reshape(B, C, HW)
+    # ---- grad_embed: K = HW in nk chunks ----
+    HWp = (HW + 31) // 32 * 32
+    nk = max(n for n in range(1, 33) if (HWp // 32) % n == 0)
+    Kc = HWp // nk
+    gh, fh = to_hl8(_pad_last(G, HWp)), to_hl8(_pad_last(F_, HWp))              # (B, Q | C, 2 HWp)
+    part = torch.empty(B, nk, Q, C, dtype=torch.float32, device=dev)
+    rc = lib.hipie_gemm_batched(gh.data_ptr(), 2 * HWp, Q * 2 * HWp, 2 * Kc, fh.data_ptr(), 2 * HWp, C * 2 * HWp, 2 * Kc,
+                                part.data_ptr(), C, nk * Q * C, Q * C, B, nk, Q, C, Kc, F32, 1.0, _stream())
+    _lib.check(rc, "hipie_gemm_batched")
+    grad_e = part.sum(1) if nk > 1 else part[:, 0]
+    # ---- grad_features: K = Q ----
+    Qp = (Q + 31) // 32 * 32
+    N8 = (HW + 7) // 8 * 8
+    eT = to_hl8(_pad_last(mask_embed.float().transpose(1, 2), Qp))              # (B, C, 2 Qp)
+    gT = torch.zeros(B, N8, Qp, dtype=torch.float32, device=dev) if (N8 != HW or Qp != Q) else torch.empty(B, N8, Qp, dtype=torch.float32, device=dev)
+    gT[:, :HW, :Q] = G.transpose(1, 2)
+    gTh = to_hl8(gT)                                                             # (B, N8, 2 Qp)
+    gf = torch.empty(B, C, N8, dtype=torch.float32, device=dev)
+    rc = lib.hipie_gemm_batched(eT.data_ptr(), 2 * Qp, C * 2 * Qp, 0, gTh.data_ptr(), 2 * Qp, N8 * 2 * Qp, 0, gf.data_ptr(), N8, C * N8, 0,
+                                B, 1, C, N8, Qp, F32, 1.0, _stream())
+    _lib.check(rc, "hipie_gemm_batched")
+    if N8 != HW:
+        gf = gf[..., :HW].contiguous()
+    return grad_e, gf.view(B, C, Hh, Ww)
+
+
 @_timed("mask_einsum")
 def mask_einsum16(mask_embed, mask_features, split=True, out_dtype=None, row_bias=None):
     """einsum("bqc,bchw->bqhw") on 16-bit features: mask_embed (B,Q,C) f32 (split here into 16-bit hi + lo parts: two MFMAs per

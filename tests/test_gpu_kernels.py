@@ -1152,6 +1152,71 @@ def test_msda_backward_through_the_reference_module_name_and_contended_pixels():
         sys.modules.pop("MultiScaleDeformableAttention")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", ["four_levels", "three_levels", "gapped_layout", "few_queries"])
+def test_msda_backward_d32_geometries(geom):
+    """hipie_msda_backward at the production head width (D = 32, fp32) against autograd through the oracle's formulation in double:
+    pyramids of 4 and 3 levels with sampling points outside the maps, level_start with gaps between the levels (the gap rows of
+    grad_value stay zero), and fewer queries than one workgroup holds.  (The same cases qualified the LDS-accumulating variant of
+    profiles/r05_msda_bwd_lds_study.txt, which was correct and slower.)"""
+    from hipie_amd import ops
+    M, D, P = 8, 32, 4
+    shapes = {"four_levels": [(40, 40), (20, 20), (10, 10), (5, 5)], "three_levels": [(60, 80), (30, 40), (15, 20)],
+              "gapped_layout": [(16, 16), (8, 8), (4, 4)], "few_queries": [(24, 24), (12, 12), (6, 6), (3, 3)]}[geom]
+    B, Lq = (2, 7) if geom == "few_queries" else (2, 3001)
+    L = len(shapes)
+    sh = torch.as_tensor(shapes, dtype=torch.long)
+    ls = _lsi(sh)
+    S = int(sh.prod(1).sum())
+    if geom == "gapped_layout":
+        ls = ls + torch.arange(L) * 5                   # 5 unused rows between the levels
+        S += 5 * L
+    g = torch.Generator().manual_seed(11)
+    value = torch.randn(B, S, M, D, generator=g, dtype=torch.float64)
+    loc = torch.rand(B, Lq, M, L, P, 2, generator=g, dtype=torch.float64) * 1.2 - 0.1        # some points outside the maps
+    attn = torch.softmax(torch.randn(B, Lq, M, L * P, generator=g, dtype=torch.float64), -1).view(B, Lq, M, L, P)
+    gout = torch.randn(B, Lq, M * D, generator=g, dtype=torch.float64)
+    # the oracle's formulation works on the packed layout: pick the levels' rows out of the (possibly gapped) value
+    rows = torch.cat([torch.arange(int(ls[l]), int(ls[l]) + shapes[l][0] * shapes[l][1]) for l in range(L)])
+    with torch.enable_grad():
+        v, l_, a = value.clone().requires_grad_(True), loc.clone().requires_grad_(True), attn.clone().requires_grad_(True)
+        want = torch.autograd.grad(oo.ms_deform_attn_core(v[:, rows], sh, l_, a), (v, l_, a), gout)
+    f = torch.float32
+    got = ops.ms_deform_attn_backward(value.to(f).to(DEV), sh.to(DEV), ls.to(DEV), loc.to(f).to(DEV), attn.to(f).to(DEV), gout.to(f).to(DEV), 64)
+    for w, x, tol in zip(want, got, (3e-6, 2e-5, 2e-5)):
+        assert rel_err(x.cpu(), w) < tol
+    if geom == "gapped_layout":
+        gap = torch.ones(S, dtype=torch.bool)
+        gap[rows] = False
+        assert float(got[0][:, gap.to(DEV)].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Q,C,H,W,bias", [(2, 300, 256, 64, 64, True), (1, 37, 256, 25, 38, False), (2, 1100, 256, 32, 32, True), (1, 5, 64, 3, 7, False)])
+def test_mask_einsum_backward_vs_autograd(B, Q, C, H, W, bias):
+    """row f-4: the backward of the mask contraction (hipie_amd.training.functions.MaskEinsumFunction: forward hipie_mask_einsum, backward
+    two hipie_gemm_batched products) against torch.autograd of the einsum in double -- the formulation of the oracle's mask head
+    (oracle/model.py: einsum("bqc,bchw->bqhw")).  Ragged H x W (950 pixels: K padded to 960, N to 952), Q not a multiple of 32."""
+    from hipie_amd.training.functions import mask_einsum
+    g = torch.Generator().manual_seed(B * 1000 + Q)
+    e = torch.randn(B, Q, C, generator=g, dtype=torch.float64)
+    f = torch.randn(B, C, H, W, generator=g, dtype=torch.float64)
+    rb = torch.randn(B, Q, generator=g, dtype=torch.float64) if bias else None
+    go = torch.randn(B, Q, H, W, generator=g, dtype=torch.float64)
+    with torch.enable_grad():
+        leaves = [t.clone().requires_grad_(True) for t in (e, f)] + ([rb.clone().requires_grad_(True)] if bias else [])
+        ref = torch.einsum("bqc,bchw->bqhw", leaves[0], leaves[1])
+        if bias:
+            ref = ref + leaves[2][:, :, None, None]
+        want = torch.autograd.grad(ref, leaves, go)
+        dl = [t.float().to(DEV).requires_grad_(True) for t in (e, f)] + ([rb.float().to(DEV).requires_grad_(True)] if bias else [])
+        out = mask_einsum(dl[0], dl[1], dl[2] if bias else None)
+        got = torch.autograd.grad(out, dl, go.float().to(DEV))
+    assert rel_err(out.detach().cpu(), ref.detach()) < 3e-5          # the forward's own bound (three bf16 products)
+    for w, x in zip(want, got):
+        assert x.dtype == torch.float32 and rel_err(x.cpu(), w) < 3e-6
+
+
 # --------------------------------------------------------------------------- exact fp32 small attention
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,Nq,Nk,H,hd,masked", [(2, 194, 194, 12, 64, True), (3, 910, 910, 8, 32, False), (2, 300, 300, 8, 32, False),
