@@ -36,6 +36,7 @@ SIGNATURES = {
     "hipie_mask_einsum16": [c_p, c_p, c_p, c_p, c_p] + [c_i] * 6 + [c_p],
     "hipie_dynamic_mask": [c_p, c_p, c_p, c_p] + [c_i] * 7 + [c_p],
     "hipie_dynamic_mask16": [c_p, c_p, c_p, c_p] + [c_i] * 7 + [c_p],
+    "hipie_dynamic_mask_backward": [c_p] * 7 + [c_i] * 6 + [c_p],
     "hipie_vit_relpos": [c_p, c_p, c_p, c_p, c_p] + [c_i] * 6 + [c_p],
     "hipie_add_layernorm": [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_i, c_i, c_i, c_p],
     "hipie_add_layernorm_sum": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_f, c_i, c_i, c_i, c_p],

@@ -542,6 +542,28 @@ def dynamic_mask(mask_feats, ref_points, params, num_queries, stride=8, up=2, ou
     return out
 
 
+@_timed("dynamic_mask_bwd")
+def dynamic_mask_backward(mask_feats, ref_points, params, grad_out, num_queries, stride=8, up=2):
+    """gradients of dynamic_mask (row f-4; hipie_dynamic_mask_backward): mask_feats (B,8,H,W), ref_points (B*Q,2), params (B*Q,169),
+    grad_out (B*Q, up*H, up*W) fp32 -> (grad_feats (B,8,H,W), grad_refs (B*Q,2), grad_params (B*Q,169)) fp32."""
+    lib = _lib.load()
+    B, C, H, W = mask_feats.shape
+    n = B * num_queries
+    if C != 8 or params.shape[-1] != 169 or params.numel() != n * 169 or ref_points.numel() != n * 2:
+        raise RuntimeError("dynamic_mask_backward: expects 8 feature channels, (B*Q, 169) parameters and (B*Q, 2) reference points")
+    if tuple(grad_out.shape[-2:]) != (up * H, up * W) or grad_out.numel() != n * up * up * H * W:
+        raise RuntimeError("dynamic_mask_backward: grad_out must be (B*Q, up*H, up*W), got %s" % (tuple(grad_out.shape),))
+    dev = mask_feats.device
+    gf = torch.empty(B, 8, H, W, dtype=torch.float32, device=dev)
+    gr = torch.empty(n, 2, dtype=torch.float32, device=dev)
+    gp = torch.empty(n, 169, dtype=torch.float32, device=dev)
+    rc = lib.hipie_dynamic_mask_backward(_chk(mask_feats, "mask_feats", torch.float32), _chk(ref_points, "ref_points", torch.float32),
+                                         _chk(params, "params", torch.float32), _chk(grad_out, "grad_out", torch.float32),
+                                         gf.data_ptr(), gr.data_ptr(), gp.data_ptr(), B, num_queries, H, W, int(stride), int(up), _stream())
+    _lib.check(rc, "hipie_dynamic_mask_backward")
+    return gf, gr, gp
+
+
 @_timed("vit_relpos")
 def vit_relpos(qkv, tab_h, tab_w, grid_hw, heads):
     """qkv (B, N, 3*heads*hd) 16-bit; tab_h (2gh-1, hd), tab_w (2gw-1, hd) same dtype -> rel_h (B*heads, gh, N), rel_w

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPIE_ABI_VERSION 11
+#define HIPIE_ABI_VERSION 12
 
 /* element types of activations */
 #define HIPIE_F32 0
@@ -213,6 +213,18 @@ int hipie_mask_einsum16(const void* embed_hi, const void* embed_lo, const void* 
  */
 int hipie_dynamic_mask(const float* feats, const float* refs, const float* params, void* out,
                        int B, int Q, int H, int W, int stride, int up, int out_dtype, void* stream);
+
+/*
+ * Backward of hipie_dynamic_mask (fp32, up in {1,2}): gradients of a scalar loss with respect to the mask features, the reference
+ * points and the 169 controller parameters per instance, given grad_out (B*Q, up*H, up*W) f32 = d loss / d out.
+ * Replaces: torch.autograd through DDETRSegmUniDN.dynamic_mask_with_coords / mask_heads_forward / aligned_bilinear
+ *           (models/ddetrs_dn.py:1411-1502, 1390-1408, 1832-1854) in the training forward (coco_forward, :264-750).
+ *   grad_feats (B,8,H,W), grad_refs (B*Q,2), grad_params (B*Q,169) f32, overwritten (zeroed here, then accumulated: fp32 atomics, so the
+ *   sums over pixels / instances run in arrival order like the reference's cuDNN / atomics-based conv backward).
+ *   Ragged instance counts per image (the matched instances of training): one call per image with B = 1.
+ */
+int hipie_dynamic_mask_backward(const float* feats, const float* refs, const float* params, const float* grad_out, float* grad_feats,
+                                float* grad_refs, float* grad_params, int B, int Q, int H, int W, int stride, int up, void* stream);
 
 /*
  * hipie_dynamic_mask (up = 2) with the three layers on the matrix pipe: 16-bit operands (`dtype` f16 / bf16: the features,

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_all():
     lib = _lib.load()
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.hipie_version() == 11
+    assert lib.hipie_version() == 12
     assert lib.hipie_last_error() == b""
 
 

@@ -113,3 +113,75 @@ def test_single_rank_group_runs_the_collectives():
     assert p.exitcode == 0
     assert (r, w) == (0, 1) and fresh and same and msame and t == 0.5
     assert dp["backend"] == "gloo" and dp["rccl_ranks"] == 1 and dp["gathered_block_shape"] == [2, 3, 7]
+
+
+# --------------------------------------------------------------------------- training side: bucketed gradient all-reduce (row f-4)
+def _toy_model():
+    torch.manual_seed(5)
+    m = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+    m.unused = torch.nn.Parameter(torch.ones(4))            # receives no gradient: its bucket is launched by finish()
+    return m
+
+
+def _toy_grads(rank):
+    m = _toy_model()
+    x = torch.randn(9, 6, generator=torch.Generator().manual_seed(100 + rank))
+    m(x).square().sum().backward()
+    return [None if p.grad is None else p.grad.clone() for p in m.parameters()]
+
+
+def _ddp_worker(rank, world, port, fp16, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from hipie_amd import parallel
+    from hipie_amd.training import GradientBuckets
+    parallel.init_from_env(backend="gloo")
+    m = _toy_model()
+    gb = GradientBuckets(m.parameters(), bucket_mb=600 / (1 << 20), fp16_compression=fp16)       # 600-byte buckets: several of them
+    outs = []
+    for step in range(2):                                   # second step: zero_grad + the same hooks again
+        x = torch.randn(9, 6, generator=torch.Generator().manual_seed(100 + rank))
+        m(x).square().sum().backward()
+        n = gb.finish()
+        outs.append([p.grad.clone().tolist() for p in m.parameters()])
+        gb.zero_grad()
+    parallel.barrier()
+    q.put((rank, len(gb.buckets), n, outs))
+
+
+def _run_ddp(fp16):
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_ddp_worker, args=(r, world, port, fp16, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in ps], key=lambda x: x[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    return got
+
+
+def test_gradient_buckets_average_over_two_ranks():
+    """GradientBuckets (detectron2/engine/defaults.py:60-79 create_ddp_model's job): after backward + finish() every rank holds the MEAN of
+    the two ranks' gradients, for every bucket, on both steps; the parameter without a gradient stays zero and does not hang its bucket."""
+    got = _run_ddp(False)
+    g0, g1 = _toy_grads(0), _toy_grads(1)
+    assert got[0][1] > 2 and got[0][2] == got[0][1]                        # several buckets, one all-reduce each
+    for step in range(2):
+        for a, b, x0, x1 in zip(got[0][3][step], got[1][3][step], g0, g1):
+            a, b = torch.tensor(a), torch.tensor(b)
+            assert torch.equal(a, b)
+            want = torch.zeros_like(a) if x0 is None else (x0 + x1) / 2
+            assert torch.allclose(a, want, rtol=1e-6, atol=1e-7)
+
+
+def test_gradient_buckets_fp16_wire():
+    """the reference's optional fp16_compress_hook: fp16 on the wire, averages within fp16 rounding of the fp32 mean."""
+    got = _run_ddp(True)
+    g0, g1 = _toy_grads(0), _toy_grads(1)
+    for a, x0, x1 in zip(got[0][3][0], g0, g1):
+        a = torch.tensor(a)
+        want = torch.zeros_like(a) if x0 is None else (x0 + x1) / 2
+        assert torch.allclose(a, want, rtol=2e-3, atol=1e-3 * float(want.abs().max() + 1e-6))

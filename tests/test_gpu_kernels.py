@@ -1217,6 +1217,42 @@ def test_mask_einsum_backward_vs_autograd(B, Q, C, H, W, bias):
         assert x.dtype == torch.float32 and rel_err(x.cpu(), w) < 3e-6
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Q,H,W,up", [(2, 37, 32, 32, 2), (1, 40, 9, 6, 2), (1, 2100, 2, 2, 2), (2, 5, 9, 6, 2), (1, 11, 16, 24, 1), (3, 1, 1, 2, 2),
+                                        (1, 300, 40, 56, 2)])
+def test_dynamic_mask_backward_vs_oracle_autograd(B, Q, H, W, up):
+    """row f-4: hipie_dynamic_mask_backward (through hipie_amd.training.functions.DynamicMaskFunction) against torch.autograd of the
+    oracle's dynamic_mask in double (oracle/ops.py: relative coordinates, three per-instance 1x1 layers, aligned_bilinear).  Ragged
+    pixel counts (54, 2 pixels: partly dead workgroups; the forward needs an even W), one instance, instance chunks of 1 and of 3 instances, up = 1.
+    The last case evaluates 10.7 M ReLUs: a handful of pre-activations within fp32 rounding of 0 take the other branch than in double
+    and move the few gradient elements they feed by one (instance, pixel) term -- that case is held to the bound on 99 % of the
+    elements and to 5e-2 everywhere (a wrong kernel is off everywhere); the small cases are held to it on every element."""
+    from hipie_amd.training.functions import dynamic_mask
+    g = torch.Generator().manual_seed(H * 100 + Q)
+    feats = torch.randn(B, 8, H, W, generator=g, dtype=torch.float64)
+    refs = torch.rand(B * Q, 2, generator=g, dtype=torch.float64) * torch.tensor([8.0 * W, 8.0 * H], dtype=torch.float64)
+    params = torch.randn(B * Q, 169, generator=g, dtype=torch.float64) * 0.3
+    params[:, :80].view(-1, 8, 10)[:, :, :2] *= 0.02                  # coordinate weights: inputs of ~100 pixels
+    go = torch.randn(B * Q, up * H, up * W, generator=g, dtype=torch.float64)
+    with torch.enable_grad():
+        leaves = [t.clone().requires_grad_(True) for t in (feats, refs, params)]
+        ref = oo.dynamic_mask(leaves[0], leaves[1][None], leaves[2][None], [Q] * B, stride=8, up=up)[0]
+        want = torch.autograd.grad(ref, leaves, go)
+        dl = [t.float().to(DEV).requires_grad_(True) for t in (feats, refs, params)]
+        out = dynamic_mask(dl[0], dl[1], dl[2], Q, 8, up)
+        got = torch.autograd.grad(out, dl, go.float().to(DEV))
+    assert rel_err(out.detach().cpu(), ref.detach()) < 1e-5
+    big = B * Q * H * W > 500000
+    for w, x, name in zip(want, got, ("feats", "refs", "params")):
+        assert x.dtype == torch.float32 and x.shape == w.shape
+        err = (x.cpu().double() - w).abs() / w.abs().max()
+        if big:
+            assert float(err.flatten().kthvalue(max(1, int(0.99 * err.numel()))).values) < 2e-5, name
+            assert float(err.max()) < 5e-2, name
+        else:
+            assert float(err.max()) < 2e-5, name
+
+
 # --------------------------------------------------------------------------- exact fp32 small attention
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,Nq,Nk,H,hd,masked", [(2, 194, 194, 12, 64, True), (3, 910, 910, 8, 32, False), (2, 300, 300, 8, 32, False),

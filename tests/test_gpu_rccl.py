@@ -43,6 +43,21 @@ for _ in range(4):
 out2 = parallel.all_gather_predictions(block * 2)
 torch.cuda.synchronize()
 assert torch.equal(out2, block * 2)
+# training side: the bucketed gradient all-reduce on the same backend (one rank: the mean is the gradient itself, but the collectives run)
+from hipie_amd.training import GradientBuckets
+torch.manual_seed(0)
+m = torch.nn.Sequential(torch.nn.Linear(256, 512), torch.nn.ReLU(), torch.nn.Linear(512, 256)).to(dev)
+x = torch.randn(64, 256, device=dev)
+m(x).square().sum().backward()
+want = [p.grad.clone() for p in m.parameters()]
+m.zero_grad(set_to_none=True)
+gb = GradientBuckets(m.parameters(), bucket_mb=0.3)
+m(x).square().sum().backward()
+n_allreduce = gb.finish()
+torch.cuda.synchronize()
+assert n_allreduce == len(gb.buckets) >= 2
+for p, w in zip(m.parameters(), want):
+    assert torch.allclose(p.grad, w, rtol=1e-5, atol=1e-6)
 parallel.shutdown()
 print("RCCL_OK " + json.dumps({"ranks": ranks, "t": t, "dp": dp, "world": 1}))
 """
