@@ -42,6 +42,7 @@ struct FAParams {
   const uint8_t* key_mask;
   float scale, clamp, defer;
   int nqt, ntiles, swz, prio;
+  int k_cs;                     // elements between consecutive 8-element chunks of a K row: 8, or 16 with HIPIE_K_HL8_HI (the hi halves of an HL8 row)
   int out_f32;                  // HIPIE_OUT_F32: `out` is fp32 (strides in fp32 elements) -- no 16-bit rounding of the attention output
 };
 
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(WAVES * 64, ((WAVES == 8 || HD <= 80) && QB == 1) ?
     cval[c] = (c * NT + tid) < NCH;
     crow_[c] = row;
     const int rowc = min(row, nkeys_full - 1);             // padded rows re-read the last valid key (finite data, P = 0)
-    koff[c] = rowc * (int)p.k_st + ch * 8;
+    koff[c] = rowc * (int)p.k_st + ch * p.k_cs;
     voff[c] = rowc * (int)p.v_st + ch * 8;
     lk[c] = row * KSTR + ch * 8;
     lv[c] = row * VSTR + ch * 8;
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(WAVES * 64, ((WAVES == 8 || HD <= 80) && QB == 1) ?
       _Pragma("unroll") for (int c = 0; c < CPT; ++c) {                                               \
         const int rc_ = min(crow_[c], nk_ - 1);                                                       \
         const int ch8_ = lk[c] - crow_[c] * KSTR;                                                     \
-        kr[c] = *reinterpret_cast<const u32x4*>(kb_ + (long)rc_ * p.k_st + ch8_);                     \
+        kr[c] = *reinterpret_cast<const u32x4*>(kb_ + (long)rc_ * p.k_st + (ch8_ >> 3) * p.k_cs);     \
         vr[c] = *reinterpret_cast<const u32x4*>(vb_ + (long)rc_ * p.v_st + ch8_);                     \
       }                                                                                               \
     }                                                                                                 \
@@ -583,6 +584,8 @@ static int flash_attn_impl(FAParams p, int hd, int dtype, void* stream) {
   for (long s : strides) HIPIE_REQUIRE(s % 8 == 0, "flash_attn: strides must be multiples of 8 elements (16 bytes), got %ld", s);
   HIPIE_REQUIRE((((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v | (uintptr_t)p.out) & 15) == 0, "flash_attn: pointers must be 16-byte aligned");
   p.swz = ((p.B * p.H) % 8 == 0) ? 1 : 0;
+  p.k_cs = (dtype & HIPIE_K_HL8_HI) ? 16 : 8;
+  dtype &= ~HIPIE_K_HL8_HI;
   p.defer = ((dtype & ~HIPIE_OUT_F32) == HIPIE_F16) ? 0.f : kDefer;      // fp16 = parity policy: classic running max
   // diagnostic switches: read from the environment once per process
   { static const float defer_env = [] { const char* d = getenv("HIPIE_FA_DEFER"); return d ? (float)atof(d) : -1.f; }();

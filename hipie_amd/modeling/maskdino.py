@@ -119,8 +119,8 @@ class MaskDINOEncoder(nn.Module):
             B, _, H, W = z.shape
             wt = ct.weight                                                   # (C_in, C_out, 2, 2)
             rows = z.permute(0, 2, 3, 1).reshape(B * H * W, C)
-            y = ops.split_linear(rows.float().contiguous(), ct, "convt", wt, None, weight_fn=lambda: wt.permute(2, 3, 1, 0).reshape(-1, C))
-            y = y.view(B, H, W, 2, 2, -1).permute(0, 5, 1, 3, 2, 4).reshape(B, -1, 2 * H, 2 * W)
+            # (ops.convt2x2_split: one linear per tap, written through a row map into the up-sampled channels-last map -- no shuffle pass)
+            y = ops.convt2x2_split(rows, ct, "convt", wt, None, B, H, W).permute(0, 3, 1, 2)
         else:
             y = F.conv_transpose2d(z.contiguous().to(ct.weight.dtype), ct.weight, None, ct.stride, ct.padding, ct.output_padding, ct.groups, ct.dilation)
         if out_dtype is not None:

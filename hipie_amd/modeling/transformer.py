@@ -407,14 +407,13 @@ class BiMultiHeadAttention(nn.Module):
         vh = ops.to_hl8(v.float().contiguous())                                 # the visual stream once, for its three projections
         q_hl8 = _lin(self, "q_scaled", vh, wq, bq, out_fmt=ops.HL8, x_hl8=True)
         # the text -> image direction reads the same scaled projection as single fp16: that is the `hi` half of every HL8 group (hi = fp16(x)
-        # by construction of hl_split) -- one strided copy instead of a second 174080 x 2048 x 256 GEMM
-        q16 = q_hl8.view(B * Nv, H * hd // 8, 2, 8)[:, :, 0, :].reshape(B, Nv, H, hd)
+        # by construction of hl_split), read in place by the attention kernel (HIPIE_K_HL8_HI) -- no second 174080 x 2048 x 256 GEMM, no copy
         vv16 = self.values_v_proj(vh, x_hl8=True, out_fmt=ops.F16).view(B, Nv, H, hd)
         k32 = self.l_proj(l)
         vl32 = self.values_l_proj(l)
         ov = ops.bi_i2t_split(q_hl8.view(B, Nv, -1), k32.view(B, L, -1), vl32.view(B, L, -1), keep, H, clamp=50000.0, n_keys=n_keys)
         # text -> image: queries = text tokens, keys / values = visual tokens, no mask on that side (fuse_helper.py:85-95)
-        ol = ops.flash_attn(k32.half().view(B, L, H, hd), q16, vv16, 1.0, clamp=50000.0, out_f32=True)
+        ol = ops.flash_attn(k32.half().view(B, L, H, hd), q_hl8.view(B, Nv, 2 * H * hd), vv16, 1.0, clamp=50000.0, out_f32=True, k_hl8=True)
         self.resid_fused = False
         if gamma_v is None:
             return self.out_v_proj(ov), self.out_l_proj(ol)

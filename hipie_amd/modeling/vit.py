@@ -433,12 +433,12 @@ class ViT(nn.Module):
         B, H, W, E = x.shape
         wt = self.fpn1[0].weight                                           # (E, E/2, 2, 2)
         b4 = self.fpn1[0].bias.to(wt.dtype).repeat_interleave(4)
-        if self.precision.split and x.is_cuda and ops.split_ok(E):
-            y = ops.split_linear(x.float().contiguous(), self, "fpn1", wt, self.fpn1[0].bias, weight_fn=lambda: wt.reshape(E, -1).t(),
-                                 bias_fn=lambda: b4).view(B, H, W, E // 2, 2, 2)
+        if self.precision.split and x.is_cuda and ops.split_ok(E) and (E // 2) % 8 == 0:
+            # one linear per tap, each writing its rows of the up-sampled map directly (ops.convt2x2_split): no shuffle pass
+            res3 = ops.convt2x2_split(x.reshape(B * H * W, E), self, "fpn1", wt, self.fpn1[0].bias, B, H, W).to(ad).permute(0, 3, 1, 2)
         else:
             y = F.linear(x.to(wt.dtype), wt.reshape(E, -1).t(), b4).view(B, H, W, E // 2, 2, 2)
-        res3 = y.permute(0, 1, 4, 2, 5, 3).reshape(B, 2 * H, 2 * W, E // 2).to(ad).permute(0, 3, 1, 2)
+            res3 = y.permute(0, 1, 4, 2, 5, 3).reshape(B, 2 * H, 2 * W, E // 2).to(ad).permute(0, 3, 1, 2)
         xp = x.permute(0, 3, 1, 2)
         return {"res3": res3, "res4": xp, "res5": self.fpn3(xp)}
 

@@ -11,6 +11,7 @@ from . import _lib
 _DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 F32, F16, BF16, HL8 = 0, 1, 2, 4          # include/hipie_mi355.h: HIPIE_F32 / F16 / BF16 / HL8
 OUT_F32 = 0x100                           # HIPIE_OUT_F32
+K_HL8_HI = 0x200       # hipie_flash_attn: keys are the hi halves of an HL8 buffer (HIPIE_K_HL8_HI)
 
 
 class _Profile(object):
@@ -194,13 +195,18 @@ def msda_fused(value, spatial_shapes, level_start_index, ref, offsets, logits):
 
 
 @_timed("flash_attn")
-def flash_attn(q, k, v, scale, bias_h=None, bias_w=None, key_mask=None, clamp=0.0, out_f32=False):
+def flash_attn(q, k, v, scale, bias_h=None, bias_w=None, key_mask=None, clamp=0.0, out_f32=False, k_hl8=False):
     """q (B,Nq,H,hd), k,v (B,Nk,H,hd) 16-bit (may be strided views with hd contiguous) -> (B,Nq,H*hd) in the operand dtype, or
-    fp32 with out_f32.  bias_h (B*H,kh,Nq) / bias_w (B*H,Nq,kw) f32 decomposed rel-pos bias; key_mask (B,Nk) uint8/bool."""
+    fp32 with out_f32.  bias_h (B*H,kh,Nq) / bias_w (B*H,Nq,kw) f32 decomposed rel-pos bias; key_mask (B,Nk) uint8/bool.
+    k_hl8: k is a contiguous (B, Nk, 2*H*hd) fp16 HL8 buffer whose hi halves are the keys (read in place, HIPIE_K_HL8_HI)."""
     lib = _lib.load()
     B, Nq, H, hd = q.shape
     Nk = k.shape[1]
-    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+    if k_hl8:
+        if k.dtype != torch.float16 or q.dtype != torch.float16 or not k.is_contiguous() or tuple(k.shape) != (B, Nk, 2 * H * hd):
+            raise RuntimeError("flash_attn: k_hl8 expects a contiguous (B, Nk, 2*H*hd) fp16 HL8 buffer and fp16 q / v")
+        ks = (Nk * 2 * H * hd, 2 * H * hd, 2 * hd)
+    for t, n in ((q, "q"), (v, "v")) + (() if k_hl8 else ((k, "k"),)):
         if not t.is_cuda:
             raise RuntimeError("Not implemented on the CPU (%s)" % n)
         if t.stride(-1) != 1 or t.dtype != q.dtype or t.dtype not in (torch.float16, torch.bfloat16):
@@ -215,9 +221,10 @@ def flash_attn(q, k, v, scale, bias_h=None, bias_w=None, key_mask=None, clamp=0.
         key_mask = key_mask.to(torch.uint8).contiguous()
         mp = _chk(key_mask, "key_mask")
     rc = lib.hipie_flash_attn(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, Nq, Nk, hd,
-                              q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+                              q.stride(0), q.stride(1), q.stride(2), *(ks if k_hl8 else (k.stride(0), k.stride(1), k.stride(2))),
                               v.stride(0), v.stride(1), v.stride(2), Nq * H * hd, H * hd, hd,
-                              bhp, bwp, kh, kw, mp, float(scale), float(clamp), _DT[q.dtype] | (OUT_F32 if out_f32 else 0), _stream())
+                              bhp, bwp, kh, kw, mp, float(scale), float(clamp),
+                              _DT[q.dtype] | (OUT_F32 if out_f32 else 0) | (K_HL8_HI if k_hl8 else 0), _stream())
     _lib.check(rc, "hipie_flash_attn")
     return out
 
@@ -1182,6 +1189,42 @@ def split_linear(x, owner, key, weight, bias=None, act=ACT_NONE, out_fmt=F32, re
     out = gemm(a, w, b, resid, out_fmt=out_fmt, act=act, split=True, tag=tag)
     if N != w.shape[0]:
         out = out[..., :(2 * N if out_fmt == HL8 else N)].contiguous()
+    return out
+
+
+_SHUFFLE_MAPS = {}
+
+
+def _shuffle_maps(B, H, W, device):
+    """row maps of ConvTranspose2d(k = 2, s = 2) as four linears: input pixel (b, h, w), tap (i, j) -> row of the (B, 2H, 2W, C) output."""
+    key = (B, H, W, str(device))
+    m = _SHUFFLE_MAPS.get(key)
+    if m is None:
+        b = torch.arange(B, device=device).view(B, 1, 1)
+        h = torch.arange(H, device=device).view(1, H, 1)
+        w = torch.arange(W, device=device).view(1, 1, W)
+        m = [((b * 2 * H + 2 * h + i) * 2 * W + 2 * w + j).reshape(-1).to(torch.int32).contiguous() for i in range(2) for j in range(2)]
+        if len(_SHUFFLE_MAPS) > 16:
+            _SHUFFLE_MAPS.clear()
+        _SHUFFLE_MAPS[key] = m
+    return m
+
+
+def convt2x2_split(rows, owner, key, weight, bias, B, H, W):
+    """ConvTranspose2d(kernel 2, stride 2) of a channels-last map at fp32-class accuracy: rows (B*H*W, C_in) fp32 pixel rows, weight
+    (C_in, C_out, 2, 2), bias (C_out) or None -> (B, 2H, 2W, C_out) fp32 channels-last.  One split linear per tap whose output rows go
+    straight to their place in the up-sampled map (hipie_gemm's row map): the pixel shuffle costs no pass of its own."""
+    Cin, Cout = weight.shape[0], weight.shape[1]
+    if rows.dim() != 2 or rows.shape[0] != B * H * W or rows.shape[1] != Cin or Cout % 8:
+        raise RuntimeError("convt2x2_split: rows (B*H*W, C_in), weight (C_in, C_out, 2, 2) with C_out %% 8 == 0, got %s / %s" % (tuple(rows.shape), tuple(weight.shape)))
+    out = torch.empty(B, 2 * H, 2 * W, Cout, dtype=torch.float32, device=rows.device)
+    o2 = out.view(-1, Cout)
+    maps = _shuffle_maps(B, H, W, rows.device)
+    a = rows if rows.dtype == torch.float32 and rows.is_contiguous() else rows.float().contiguous()
+    for t in range(4):
+        i, j = divmod(t, 2)
+        split_linear(a, owner, "%s_tap%d" % (key, t), weight, bias, weight_fn=lambda i=i, j=j: weight[:, :, i, j].t().contiguous(),
+                     out=o2, out_row=maps[t], tag="gemm_convt")
     return out
 
 

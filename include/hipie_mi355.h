@@ -35,6 +35,9 @@ extern "C" {
 
 #define HIPIE_OUT_F32 0x100   /* or-ed into the `dtype` of hipie_flash_attn / hipie_bi_xattn(_ws): q, k, v stay 16 bit, the OUTPUT(S) are written as
                                 fp32 (output strides in fp32 elements): the attention result enters the next linear unrounded */
+#define HIPIE_K_HL8_HI 0x200  /* or-ed into the `dtype` of hipie_flash_attn: `k` points at an HIPIE_HL8 buffer and the keys are its `hi` halves (hi = fp16(x)
+                                by construction): the 8-element chunks of a head row are 16 elements apart; k_sb / k_st / k_sh are strides of
+                                the HL8 buffer in fp16 elements (k_sh = 2 * head_dim).  Saves the strided copy that extracts them. */
 
 /* flags of the attention entry points that take a `flags` argument */
 #define HIPIE_ATTN_FAST 1    /* deferred running max (rescale only when a row maximum grows by > 2^8) and, where the head dim

@@ -1253,6 +1253,28 @@ def test_dynamic_mask_backward_vs_oracle_autograd(B, Q, H, W, up):
             assert float(err.max()) < 2e-5, name
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("Nk,L", [(21760, 194), (1000, 37), (333, 7)])
+def test_flash_attn_reads_keys_from_hl8_hi_halves(Nk, L):
+    """HIPIE_K_HL8_HI: the text -> image direction of the fusion takes its keys from the hi halves of the HL8 visual projection in place
+    (8-element chunks 16 elements apart) -- bit-identical to the same call on a strided copy of those halves, full and ragged last tile."""
+    from hipie_amd import ops
+    B, H, hd = 2, 8, 256
+    g = torch.Generator().manual_seed(Nk)
+    x = (torch.randn(B, Nk, H * hd, generator=g) * 0.05).to(DEV)
+    hl8 = ops.to_hl8(x)
+    hi = hl8.view(B * Nk, H * hd // 8, 2, 8)[:, :, 0, :].reshape(B, Nk, H, hd)
+    assert torch.equal(hi, x.half().view(B, Nk, H, hd))
+    q = (torch.randn(B, L, H, hd, generator=g) * 0.5).half().to(DEV)
+    v = torch.randn(B, Nk, H, hd, generator=g).half().to(DEV)
+    a = ops.flash_attn(q, hi, v, 1.0, clamp=50000.0, out_f32=True)
+    b = ops.flash_attn(q, hl8, v, 1.0, clamp=50000.0, out_f32=True, k_hl8=True)
+    assert torch.equal(a, b)
+    ref = torch.softmax(torch.einsum("blhd,bnhd->bhln", q.float(), hi.float()), -1)
+    ref = torch.einsum("bhln,bnhd->blhd", ref, v.float()).reshape(B, L, H * hd)
+    assert rel_err(b.cpu(), ref.cpu()) < 2e-3
+
+
 # --------------------------------------------------------------------------- exact fp32 small attention
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,Nq,Nk,H,hd,masked", [(2, 194, 194, 12, 64, True), (3, 910, 910, 8, 32, False), (2, 300, 300, 8, 32, False),

@@ -617,3 +617,25 @@ def test_msda_im2col_step_is_validated_like_the_reference_op():
         ops.ms_deform_attn_backward(v, sh, ls, loc, w, torch.zeros(6, 3, 256), 4)
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):      # a valid step (3 divides 6) gets as far as the device check
         ops.ms_deform_attn_forward(v, sh, ls, loc, w, 3)
+
+
+def test_convt2x2_row_maps_reproduce_the_transposed_convolution():
+    """ops.convt2x2_split's row maps (ConvTranspose2d(k = 2, s = 2) as one linear per tap, each row written to its place in the up-sampled
+    channels-last map): emulated with torch matmuls on the CPU against F.conv_transpose2d."""
+    import torch.nn.functional as F
+    from hipie_amd import ops
+    B, H, W, Cin, Cout = 2, 3, 5, 8, 16
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    wt = torch.randn(Cin, Cout, 2, 2, generator=g)
+    bias = torch.randn(Cout, generator=g)
+    rows = x.permute(0, 2, 3, 1).reshape(B * H * W, Cin)
+    out = torch.zeros(B * 2 * H * 2 * W, Cout)
+    maps = ops._shuffle_maps(B, H, W, torch.device("cpu"))
+    assert len(maps) == 4 and all(m.dtype == torch.int32 and m.numel() == B * H * W for m in maps)
+    assert torch.equal(torch.cat(maps).sort().values, torch.arange(B * 4 * H * W, dtype=torch.int32))     # every output row exactly once
+    for t, m in enumerate(maps):
+        i, j = divmod(t, 2)
+        out[m.long()] = rows @ wt[:, :, i, j] + bias
+    want = F.conv_transpose2d(x, wt, bias, stride=2)
+    assert torch.allclose(out.view(B, 2 * H, 2 * W, Cout).permute(0, 3, 1, 2), want, atol=1e-5)
