@@ -126,7 +126,8 @@ def _toy_model():
 def _toy_grads(rank):
     m = _toy_model()
     x = torch.randn(9, 6, generator=torch.Generator().manual_seed(100 + rank))
-    m(x).square().sum().backward()
+    with torch.enable_grad():                               # the suite runs with grad mode off (conftest)
+        m(x).square().sum().backward()
     return [None if p.grad is None else p.grad.clone() for p in m.parameters()]
 
 
@@ -140,7 +141,8 @@ def _ddp_worker(rank, world, port, fp16, q):
     outs = []
     for step in range(2):                                   # second step: zero_grad + the same hooks again
         x = torch.randn(9, 6, generator=torch.Generator().manual_seed(100 + rank))
-        m(x).square().sum().backward()
+        with torch.enable_grad():
+            m(x).square().sum().backward()
         n = gb.finish()
         outs.append([p.grad.clone().tolist() for p in m.parameters()])
         gb.zero_grad()

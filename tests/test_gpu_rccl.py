@@ -48,6 +48,7 @@ from hipie_amd.training import GradientBuckets
 torch.manual_seed(0)
 m = torch.nn.Sequential(torch.nn.Linear(256, 512), torch.nn.ReLU(), torch.nn.Linear(512, 256)).to(dev)
 x = torch.randn(64, 256, device=dev)
+torch.set_grad_enabled(True)
 m(x).square().sum().backward()
 want = [p.grad.clone() for p in m.parameters()]
 m.zero_grad(set_to_none=True)
