@@ -229,7 +229,7 @@ class BertEncoder(nn.Module):
         B, L = ids.shape
         mask_h = None if mask.is_cuda else mask
         if L <= 512:
-            ids, mask = ids.to(dev), mask.to(dev)
+            ids, mask = _h2d(ids, dev), _h2d(mask, dev)
             out = {"masks": mask, "hidden": self.model(ids, mask)}
             if mask_h is not None:
                 out["n_keys"] = _n_keys(mask_h)
@@ -268,7 +268,7 @@ class BertEncoder(nn.Module):
                 inp = inp[n:]
                 begin += n
                 covered = max(covered, begin)
-        hid = self.model(torch.stack([c[1] for c in chunks]).to(dev), torch.stack([c[2] for c in chunks]).to(dev))
+        hid = self.model(_h2d(torch.stack([c[1] for c in chunks]), dev), _h2d(torch.stack([c[2] for c in chunks]), dev))
         attended = _n_attended(mask_h)
         live = L
         if compact:
@@ -277,10 +277,22 @@ class BertEncoder(nn.Module):
         out = torch.zeros(B, live, hid.shape[-1], dtype=torch.float32, device=dev)
         for i, (b, _, _, (s0, s1, t0, t1)) in enumerate(chunks):
             out[b, t0:t1] = hid[i, s0:s1]
-        res = {"masks": mask_h[:, :live].to(dev), "hidden": out, "n_keys": min(live, (max(attended, 1) + 31) // 32 * 32)}
+        res = {"masks": _h2d(mask_h[:, :live].contiguous(), dev), "hidden": out, "n_keys": min(live, (max(attended, 1) + 31) // 32 * 32)}
         if live < L:
             res["full_len"] = L
         return res
+
+
+def _h2d(t, dev):
+    """host tensor -> device without synchronising the stream: through a pinned staging block (torch's caching host allocator recycles
+    it only after the copy has completed) and a non-blocking copy.  A plain .to(device) of pageable memory waits for everything queued
+    before it -- at the head of a step that is the whole previous step, and the host falls behind on the latency-bound configurations
+    (configs[0]: 17.7 instead of 14.6 ms per image)."""
+    if t.is_cuda or torch.device(dev).type != "cuda":
+        return t.to(dev)
+    pin = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    pin.copy_(t)
+    return pin.to(dev, non_blocking=True)
 
 
 def _n_attended(mask_h):
