@@ -26,6 +26,9 @@
 #ifndef HIPIE_VS_TAIL
 #define HIPIE_VS_TAIL 1        // 0: hd 80 as three 32-row blocks with a ones column (the round-4 form), for A/B timing builds only
 #endif
+#ifndef HIPIE_VS_TAIL_MAXNB
+#define HIPIE_VS_TAIL_MAXNB 3  // the tail form is used by instances of up to this many 32-key blocks per tile (2: the 96-slot instance keeps three padded blocks)
+#endif
 
 namespace hipie {
 
@@ -89,6 +92,16 @@ __device__ __forceinline__ void vs_settle(unsigned int (&h)[4], unsigned int (&l
 #endif
 }
 
+// The other direction: the probabilities come out of v_exp_f32, and on gfx950 a transcendental result needs one wait state before a
+// non-transcendental VALU instruction reads it.  hipcc inserts it for instructions it can see -- not for the asm statements of vs_split2.
+// Where the scheduler happened to put something between the two nothing showed; in the 96-slot instance with the 16-row tail it did not,
+// and the splits read stale registers (garbage outputs, round 5).  One s_nop behind the block of exps, tied to all of them.
+__device__ __forceinline__ void vs_exp_settle(float (&pv)[8]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_nop 0" : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]), "+v"(pv[7]));
+#endif
+}
+
 // LDS-DMA of 16 bytes per lane: LDS[lds_dst + 16 * lane] <- *(sbase + voff) for the lanes of `mask` (see gemm.hip / vit_attn.hip for the
 // inline-asm form).  The lane mask (a tile's row-padding chunks are neither fetched nor written) is applied inside the statement --
 // s_and_saveexec / s_mov exec around the load, no branch -- and M0 is simply overwritten (nothing else in this kernel uses it): 5 scalar
@@ -129,9 +142,8 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
   // pipe is the power-limited resource of this kernel: time follows the MFMA work issued, not the instruction count).  The tail's B operand
   // needs a lane's 16 queries x 4 k-groups where the S^T layout has 32 queries x 2 halves: two v_permlane16_swap per VGPR re-deal the two
   // 16-key steps of a 32-key block into the fragments of queries 0-15 (X) and 16-31 (Y); see the PV loop.
-  // (NB <= 2 only: the 96-slot instance of the 84 x 84 grid keeps the three-block form -- its tail variant gave wrong results and was not
-  // debugged in round 5; that instance is not on the headline path)
-  constexpr bool TAIL = (HD % 32 == 16) && (HIPIE_VS_TAIL != 0) && NB <= 2;
+  // (all instances; the 96-slot one of the 84 x 84 grid gave garbage with it until vs_exp_settle: its splits read v_exp_f32 results early)
+  constexpr bool TAIL = (HD % 32 == 16) && (HIPIE_VS_TAIL != 0) && NB <= HIPIE_VS_TAIL_MAXNB;
   constexpr int DBB = TAIL ? HD / 32 : DB;     // full 32-row d blocks that run on the 32x32x16 MFMA
   constexpr bool ONES = (DB * 32 > HD) && !TAIL;
   static_assert(R == 1 || (KW > 0 && R * KW <= KT), "R key rows of KW keys must fit the tile");
@@ -429,11 +441,14 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
       u32x4 p_h[2][2], p_l[2][2];
       auto make_p = [&](const int blk, const int st, u32x4& Hh, u32x4& Ll) {
         unsigned int hh[4], ll[4];
+        float pv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pv[j] = __builtin_amdgcn_exp2f(S[blk][8 * st + j] + off);
+        vs_exp_settle(pv);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float p0 = __builtin_amdgcn_exp2f(S[blk][8 * st + 2 * j] + off), p1 = __builtin_amdgcn_exp2f(S[blk][8 * st + 2 * j + 1] + off);
-          l_run += p0 + p1;                    // fp32 row sums of the unrounded probabilities (no spare O^T row for a ones column here)
-          vs_split2(p0, p1, hh[j], ll[j]);
+          l_run += pv[2 * j] + pv[2 * j + 1];  // fp32 row sums of the unrounded probabilities (no spare O^T row for a ones column here)
+          vs_split2(pv[2 * j], pv[2 * j + 1], hh[j], ll[j]);
         }
         vs_settle(hh, ll);
 #pragma unroll
@@ -505,11 +520,14 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
     frag pf, pfl;                // the probabilities of a 16-key step as an fp16 pair: hi, and lo = fp16(p - hi)
     {
       unsigned int hh[4], ll[4];
+      float pv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pv[j] = __builtin_amdgcn_exp2f(S[0][j] + off);
+      vs_exp_settle(pv);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float p0 = __builtin_amdgcn_exp2f(S[0][2 * j] + off), p1 = __builtin_amdgcn_exp2f(S[0][2 * j + 1] + off);
-        if (!ONES) l_run += p0 + p1;
-        vs_split2(p0, p1, hh[j], ll[j]);
+        if (!ONES) l_run += pv[2 * j] + pv[2 * j + 1];
+        vs_split2(pv[2 * j], pv[2 * j + 1], hh[j], ll[j]);
       }
       vs_settle(hh, ll);
       pf = __builtin_bit_cast(frag, (u32x4){hh[0], hh[1], hh[2], hh[3]});
@@ -535,11 +553,14 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
         if (npl == 0) {           // a new step follows: its probabilities
           const int nb_ = nstep >> 1, ns_ = nstep & 1;
           unsigned int hh[4], ll[4];
+          float pv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pv[j] = __builtin_amdgcn_exp2f(S[nb_][8 * ns_ + j] + off);
+          vs_exp_settle(pv);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float p0 = __builtin_amdgcn_exp2f(S[nb_][8 * ns_ + 2 * j] + off), p1 = __builtin_amdgcn_exp2f(S[nb_][8 * ns_ + 2 * j + 1] + off);
-            if (!ONES) l_run += p0 + p1;
-            vs_split2(p0, p1, hh[j], ll[j]);
+            if (!ONES) l_run += pv[2 * j] + pv[2 * j + 1];
+            vs_split2(pv[2 * j], pv[2 * j + 1], hh[j], ll[j]);
           }
           vs_settle(hh, ll);
           pn = __builtin_bit_cast(frag, (u32x4){hh[0], hh[1], hh[2], hh[3]});

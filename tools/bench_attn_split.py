@@ -32,3 +32,9 @@ q2 = ops.to_hl8(torch.randn(200, 196, 3 * C, device="cuda") * 0.8)
 t2h, t2w = ops.hl8_pack(torch.randn(27, hd) * 0.2).cuda(), ops.hl8_pack(torch.randn(27, hd) * 0.2).cuda()
 t2 = bench(lambda: ops.vit_attn_split(q2, t2h, t2w, (14, 14), heads))
 print("windows 14x14 x200: %.3f ms  %.0f TFLOP/s algorithmic" % (t2, 4.0 * 196 * 196 * C * 200 / 1e9 / t2))
+# the 96-slot instance: 84 x 84 token grid (1344-pixel images, BASELINE configs[4]), one image
+H3 = W3 = 84
+q3 = ops.to_hl8(torch.randn(1, H3 * W3, 3 * C, device="cuda") * 0.8)
+t3h, t3w = ops.hl8_pack(torch.randn(2 * H3 - 1, hd) * 0.2).cuda(), ops.hl8_pack(torch.randn(2 * W3 - 1, hd) * 0.2).cuda()
+t3 = bench(lambda: ops.vit_attn_split(q3, t3h, t3w, (H3, W3), heads))
+print("global 84x84 B=1: %.3f ms  %.0f TFLOP/s algorithmic" % (t3, 4.0 * (H3 * W3) ** 2 * C / 1e9 / t3))
