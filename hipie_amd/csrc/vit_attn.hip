@@ -292,6 +292,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void vit_attn_kernel(const VAParams 
     float mx = -INFINITY;
     if (ABL == 2) mx = S[0][0];
     else {
+      // first link in C++ on the LAST score block: with R == 1 the chain below reads MFMA results directly, and hipcc places the
+      // MFMA -> VALU wait states only for reads it can see (not inside the v_max3 asm statements); MFMAs retire in order
+      mx = __builtin_fmaxf(S[NB - 1][14], S[NB - 1][15]);
 #pragma unroll
       for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
