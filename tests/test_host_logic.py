@@ -639,3 +639,23 @@ def test_convt2x2_row_maps_reproduce_the_transposed_convolution():
         out[m.long()] = rows @ wt[:, :, i, j] + bias
     want = F.conv_transpose2d(x, wt, bias, stride=2)
     assert torch.allclose(out.view(B, 2 * H, 2 * W, Cout).permute(0, 3, 1, 2), want, atol=1e-5)
+
+
+def test_training_operator_functions_have_no_host_path():
+    """hipie_amd.training.functions (mask contraction, dynamic mask head): forward and backward run on libhipie_mi355.so only -- host
+    tensors raise, nothing falls back to PyTorch or to the oracle."""
+    from hipie_amd import ops
+    from hipie_amd.training import functions
+    e, f = torch.zeros(1, 2, 8), torch.zeros(1, 8, 2, 2)
+    with pytest.raises(RuntimeError):
+        functions.mask_einsum(e, f)
+    with pytest.raises(RuntimeError):
+        ops.mask_einsum_backward(e, f, torch.zeros(1, 2, 2, 2))
+    feats, refs, params = torch.zeros(1, 8, 2, 2), torch.zeros(3, 2), torch.zeros(3, 169)
+    with pytest.raises(RuntimeError):
+        functions.dynamic_mask(feats, refs, params, 3, 8, 2)
+    with pytest.raises(RuntimeError):
+        ops.dynamic_mask_backward(feats, refs, params, torch.zeros(3, 4, 4), 3, stride=8, up=2)
+    import inspect
+    src = inspect.getsource(functions)
+    assert "oracle" not in src.replace("oracle's", "")
