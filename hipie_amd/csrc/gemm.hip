@@ -744,7 +744,8 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, con
   const bool wide = (N % 320 == 0);
   // problems that fill less than 3/8 of the CUs with 256-row tiles go to the 64 x 128 tile kernel (HIPIE_GEMM_SMALL=0: never; A/B timing)
   static const int small_on = [] { const char* e = getenv("HIPIE_GEMM_SMALL"); return e ? atoi(e) : 1; }();
-  const bool small_ok = small_on && (long)((M + 255) / 256) * ((N + (wide ? 319 : 255)) / (wide ? 320 : 256)) < 96;
+  static const long small_tiles = [] { const char* e = getenv("HIPIE_GEMM_SMALL_MAXTILES"); return e ? atol(e) : 96L; }();      // A/B runs: tools/bench_gemm_small.py big
+  const bool small_ok = small_on && (long)((M + 255) / 256) * ((N + (wide ? 319 : 255)) / (wide ? 320 : 256)) < small_tiles;
 #ifdef HIPIE_GEMM_VARIANTS
   { const char* e = getenv("HIPIE_GEMM_VARIANT"); const int v = e ? atoi(e) : 0;
     if (split && wide && v == 1) return launch_gemm<320, true, 1>(p, st);

@@ -28,9 +28,13 @@ def bench(fn, n=50):
     return a.elapsed_time(b) / n
 
 
+# the K = 256 projections over all pyramid tokens (tile kernel by default; HIPIE_GEMM_SMALL_MAXTILES=1000000 forces the 64 x 128 tile kernel)
+BIG = [(174080, 256, 256, True, 34), (174080, 256, 256, False, 12), (174080, 256, 384, False, 12), (131072, 256, 1024, True, 1)]
+
+
 def main():
     tot = 0.0
-    for M, K, N, f32, n in SHAPES:
+    for M, K, N, f32, n in (BIG if len(sys.argv) > 1 and sys.argv[1] == "big" else SHAPES):
         x = torch.randn(M, K, device="cuda")
         w = torch.randn(N, K, device="cuda") * K ** -0.5
         b = torch.randn(N, device="cuda")
@@ -39,7 +43,7 @@ def main():
         out = ops.gemm(a, ws, b, out_fmt=ops.F32, split=True)
         ref = (x.double() @ w.double().t() + b.double())
         err = float((out.double() - ref).abs().max() / ref.abs().max())
-        t = bench(lambda: ops.gemm(a, ws, b, out_fmt=ops.F32, split=True))
+        t = bench(lambda: ops.gemm(a, ws, b, out_fmt=ops.F32, split=True), 20 if M > 100000 else 50)
         tot += t * n
         print("M=%6d K=%4d N=%4d %s  %.4f ms x %2d   err %.1e" % (M, K, N, "f32" if f32 else "hl8", t, n, err), flush=True)
     print("HIPIE_GEMM_SMALL=%s: sum over the step's launches %.2f ms" % (os.environ.get("HIPIE_GEMM_SMALL", "1"), tot))
