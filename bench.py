@@ -614,8 +614,9 @@ def main():
             "dtype": {"split": "f16x3 (split-fp16 operands, fp32 accumulate: fp32-class)", "fast": "f16", "parity": "f32+f16attn", "bf16": "bf16",
                       "default": "bf16+f32head"}[args.precision],
             "data": "synthetic (uint8-valued random images resident in HBM BEFORE the timed region -- the 12.6 MB / image host-to-device copy that the "
-                    "reference's timer includes (detectron2/evaluation/evaluator.py:157-161) is outside the step; synthetic BERT token ids handed over "
-                    "as host tensors like a tokenizer's output; random-init weights)",
+                    "reference's timer includes (detectron2/evaluation/evaluator.py:157-161) is outside the step; synthetic BERT token ids "
+                    + ("resident on the device (hipGraph capture)" if args.graph else "handed over as host tensors like a tokenizer's output")
+                    + "; random-init weights)",
             "config": {"workload": "BASELINE.json configs[%s]: %s, %dx%d, batch %d per GPU, %d %s (L=%d), %s"
                                    % (str(args.config) if args.config is not None else
                                       {80: "1" if args.model == "r50" else ("2" if world == 1 else "2 per GPU (weak scaling of the metric's workload: "
