@@ -292,9 +292,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void vit_attn_kernel(const VAParams 
     float mx = -INFINITY;
     if (ABL == 2) mx = S[0][0];
     else {
-      // first link in C++ on the LAST score block: with R == 1 the chain below reads MFMA results directly, and hipcc places the
-      // MFMA -> VALU wait states only for reads it can see (not inside the v_max3 asm statements); MFMAs retire in order
-      mx = __builtin_fmaxf(S[NB - 1][14], S[NB - 1][15]);
+      // first link in C++ over one element of EVERY score block: with R == 1 the chain below reads MFMA results directly, and hipcc places
+      // the MFMA -> VALU wait states only for reads it can see (not inside the v_max3 asm statements)
+      mx = __builtin_fmaxf(S[0][0], S[0][1]);            // a real VALU instruction also when NB == 1
+#pragma unroll
+      for (int blk = 1; blk < NB; ++blk) mx = __builtin_fmaxf(mx, S[blk][0]);
 #pragma unroll
       for (int blk = 0; blk < NB; ++blk)
 #pragma unroll

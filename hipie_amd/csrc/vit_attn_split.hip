@@ -393,11 +393,16 @@ __global__ __launch_bounds__(WAVES * 64, (NB >= 3 ? 1 : 2)) void vit_attn_split_
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[blk][r] += (32 * blk + crow(r, hi) < kw) ? bh0 : bh1;
     }
-    // four independent v_max3 chains: a single chain made hipcc put a wait state behind every link (inline-asm VALU feeding the next one)
-    // The first link of two chains is a C++ fmaxf on an element of the FIRST and of the LAST score block: a VALU read of MFMA results that
-    // hipcc can see, so it places the MFMA -> VALU wait states there (it does not look inside the v_max3 asm statements, which could
-    // otherwise read an accumulator the matrix pipe has not finished writing); everything behind reads completed registers.
-    float mx = __builtin_fmaxf(S[0][0], S[0][1]), mxb = __builtin_fmaxf(S[NB - 1][2], S[NB - 1][3]), mxc = -INFINITY, mxd = -INFINITY;
+    // four independent v_max3 chains: a single chain made hipcc put a wait state behind every link (inline-asm VALU feeding the next one).
+    // hipcc places the MFMA -> VALU wait states only for reads it can see, not for the v_max3 asm statements -- which it is free to schedule
+    // right behind the MFMA that writes their operand (tools/isa_hazard_lint.py found chains that started from -inf doing exactly that, 0
+    // wait states after the MFMA; harmless in practice only because a stale maximum merely moves the softmax reference point).  So every
+    // chain starts from `t0`, a C++ maximum over one element of EVERY score block: the compiler waits for each block's last MFMA before
+    // it, and every asm link depends on it.
+    float t0 = __builtin_fmaxf(S[0][0], S[0][1]);           // a real VALU instruction also when NB == 1 (a plain copy would be folded into the asm operand)
+#pragma unroll
+    for (int blk = 1; blk < NB; ++blk) t0 = __builtin_fmaxf(t0, S[blk][0]);
+    float mx = t0, mxb = t0, mxc = t0, mxd = t0;
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk)
 #pragma unroll

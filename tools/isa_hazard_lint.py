@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Static check of the wait states around INLINE-ASM VALU statements in the gfx950 ISA of a .hip file.
+
+hipcc's hazard recogniser does not look inside inline asm (round 5 found two such hazards the hard way: DESIGN.md section 9):
+  A. an asm VALU statement READS a VGPR whose latest writer is
+       - a transcendental instruction (v_exp / v_log / v_rcp / v_rsq / v_sqrt / v_sin / v_cos): 1 wait state needed,
+       - an MFMA: passes + 3 wait states needed (32x32x16 f16: 8 passes, 16x16x32: 4);
+  B. an MFMA or v_permlane*_swap READS a VGPR whose latest writer is an asm VALU statement: 2 wait states needed.
+Every instruction between writer and reader is one wait state, `s_nop N` is N + 1.  The scan is per basic block (a label or a branch ends the
+look-back: a writer in another block is not judged).  The compiler marks asm statements with ;;#ASMSTART / ;;#ASMEND in its -S output.
+
+  python tools/isa_hazard_lint.py hipie_amd/csrc/vit_attn_split.hip [extra hipcc flags ...]      # exit status 1 when something is flagged
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+TRANS = re.compile(r"^v_(exp|log|rcp|rsq|sqrt|sin|cos)_")
+REG = re.compile(r"(?<![A-Za-z0-9_])v(\d+)(?![A-Za-z0-9_\[])|(?<![A-Za-z0-9_])v\[(\d+):(\d+)\]")
+PASSES = {"32x32x16": 8, "16x16x32": 4, "32x32x8": 8, "16x16x16": 4, "32x32x4": 8, "16x16x4": 4, "4x4x4": 2, "32x32x2": 16, "16x16x8": 4, "32x32x64": 16, "16x16x128": 8}
+
+
+def regs(text):
+    out = []
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.append(int(m.group(1)))
+        else:
+            out.extend(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def parse(line):
+    """-> (mnemonic, dst registers, src registers) of a VALU / MFMA / memory instruction line, or None"""
+    code = line.split(";")[0].strip()
+    if not code or code.endswith(":") or code.startswith("."):
+        return None
+    parts = code.split(None, 1)
+    mn = parts[0]
+    ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+    if mn.startswith("v_") and not mn.startswith("v_nop") and not mn.startswith("v_cmp") and not mn.startswith("v_readlane") and not mn.startswith("v_readfirstlane"):
+        if mn.startswith("v_permlane") and "swap" in mn:            # both operands are read and written
+            return mn, regs(ops[0]) + regs(ops[1]), regs(ops[0]) + regs(ops[1])
+        dst = regs(ops[0]) if ops else []
+        src = [r for o in ops[1:] for r in regs(o)]
+        if mn.startswith("v_fma_mixhi") or mn.startswith("v_mad_mixhi"):
+            src += dst                                               # the high half is merged into the old value
+        return mn, dst, src
+    if mn.startswith(("global_load", "buffer_load", "ds_read", "ds_bpermute", "ds_permute", "flat_load", "scratch_load", "ds_swizzle")):
+        dst = regs(ops[0]) if ops else []
+        return mn, dst, [r for o in ops[1:] for r in regs(o)]
+    if mn.startswith(("v_readlane", "v_readfirstlane", "v_cmp")):
+        return mn, [], [r for o in ops for r in regs(o)]
+    return mn, [], [r for o in ops for r in regs(o)]
+
+
+def lint(asm_text, name):
+    findings = []
+    func = "?"
+    block = []          # (mnemonic, dst, src, in_asm, waits, lineno, text)
+    in_asm = False
+    for lineno, line in enumerate(asm_text.splitlines(), 1):
+        s = line.strip()
+        if s.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if s.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        m = re.match(r"^([A-Za-z_][\w$.]*):", s)
+        if m:
+            if not m.group(1).startswith(".L"):
+                func = m.group(1)
+            block = []
+            continue
+        p = parse(line)
+        if p is None:
+            continue
+        mn, dst, src = p
+        if mn.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc", "s_swappc")):
+            block = []
+            continue
+        waits = 1
+        if mn == "s_nop":
+            waits = int(s.split()[1]) + 1
+        is_valu = mn.startswith("v_") and not mn.startswith("v_mfma") and not mn.startswith("v_smfmac")
+        # ---- checks for this instruction as a READER ----
+        need_check_a = in_asm and is_valu
+        need_check_b = mn.startswith("v_mfma") or (mn.startswith("v_permlane") and "swap" in mn)
+        if (need_check_a or need_check_b) and src:
+            for r in sorted(set(src)):
+                gap = 0
+                for (wmn, wdst, _, w_asm, wwaits, wline, wtext) in reversed(block):
+                    if r in wdst:
+                        if need_check_a:
+                            if TRANS.match(wmn) and gap < 1:
+                                findings.append((name, func, lineno, "asm `%s` reads v%d %d wait states after `%s` (line %d): transcendental result, 1 needed"
+                                                 % (s, r, gap, wtext, wline)))
+                            elif wmn.startswith("v_mfma"):
+                                shape = re.search(r"_(\d+x\d+x\d+)", wmn)
+                                need = PASSES.get(shape.group(1) if shape else "", 16) + 3
+                                if gap < need:
+                                    findings.append((name, func, lineno, "asm `%s` reads v%d %d wait states after `%s` (line %d): MFMA result, %d needed"
+                                                     % (s, r, gap, wtext, wline, need)))
+                        if need_check_b and w_asm and wmn.startswith("v_") and gap < 2 and not (in_asm and need_check_a):
+                            findings.append((name, func, lineno, "`%s` reads v%d %d wait states after asm `%s` (line %d): 2 needed" % (s, r, gap, wtext, wline)))
+                        break
+                    gap += wwaits
+        block.append((mn, dst, src, in_asm, waits, lineno, s))
+    return findings
+
+
+def compile_to_asm(path, flags):
+    out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
+    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, path] + list(flags)
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    os.unlink(out)
+    return text
+
+
+def main():
+    if len(sys.argv) < 2:
+        print(__doc__)
+        return 2
+    path, flags = sys.argv[1], sys.argv[2:]
+    text = open(path).read() if path.endswith(".s") else compile_to_asm(path, flags)
+    f = lint(text, os.path.basename(path))
+    n_asm = text.count(";;#ASMSTART")
+    for (name, func, lineno, msg) in f[:40]:
+        print("%s: %s: line %d: %s" % (name, func[:60], lineno, msg))
+    print("%s: %d inline-asm statements, %d findings" % (os.path.basename(path), n_asm, len(f)))
+    return 1 if f else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
