@@ -10,6 +10,7 @@ Every instruction between writer and reader is one wait state, `s_nop N` is N + 
 look-back: a writer in another block is not judged).  The compiler marks asm statements with ;;#ASMSTART / ;;#ASMEND in its -S output.
 
   python tools/isa_hazard_lint.py hipie_amd/csrc/vit_attn_split.hip [extra hipcc flags ...]      # exit status 1 when something is flagged
+  python tools/isa_hazard_lint.py --all hipie_amd/csrc/msda.hip       # rule A for every VALU instruction (compiler-generated code included)
 """
 import os
 import re
@@ -56,7 +57,8 @@ def parse(line):
     return mn, [], [r for o in ops for r in regs(o)]
 
 
-def lint(asm_text, name):
+def lint(asm_text, name, check_all=False):
+    """check_all: judge EVERY VALU reader by rule A, not only the asm statements (what the compiler itself left behind)"""
     findings = []
     func = "?"
     block = []          # (mnemonic, dst, src, in_asm, waits, lineno, text)
@@ -87,7 +89,7 @@ def lint(asm_text, name):
             waits = int(s.split()[1]) + 1
         is_valu = mn.startswith("v_") and not mn.startswith("v_mfma") and not mn.startswith("v_smfmac")
         # ---- checks for this instruction as a READER ----
-        need_check_a = in_asm and is_valu
+        need_check_a = (in_asm or check_all) and is_valu
         need_check_b = mn.startswith("v_mfma") or (mn.startswith("v_permlane") and "swap" in mn)
         if (need_check_a or need_check_b) and src:
             for r in sorted(set(src)):
@@ -125,9 +127,10 @@ def main():
     if len(sys.argv) < 2:
         print(__doc__)
         return 2
-    path, flags = sys.argv[1], sys.argv[2:]
+    args = [a for a in sys.argv[1:] if a != "--all"]
+    path, flags = args[0], args[1:]
     text = open(path).read() if path.endswith(".s") else compile_to_asm(path, flags)
-    f = lint(text, os.path.basename(path))
+    f = lint(text, os.path.basename(path), check_all="--all" in sys.argv)
     n_asm = text.count(";;#ASMSTART")
     for (name, func, lineno, msg) in f[:40]:
         print("%s: %s: line %d: %s" % (name, func[:60], lineno, msg))
