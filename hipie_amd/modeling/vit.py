@@ -110,7 +110,11 @@ class _QkvBuffers(object):
 
     def get(self, owner, rows, width, device, pad_rows, bias_row, bias_ver):
         import weakref
-        key = (rows, width, str(device))
+        # the key names the GEOMETRY, not only the size: two token grids with the same padded window count (50x76 and 50x72 at ws 14:
+        # 4704 rows either way) have their padding rows in different places, and rows that were real tokens of the previous geometry
+        # would otherwise keep its qkv instead of the bias.  pad_rows is the cached per-geometry index tensor (window_pad_rows), so
+        # its address identifies the geometry for the life of the process.
+        key = (rows, width, str(device), pad_rows.data_ptr(), pad_rows.numel())
         st = owner.__dict__.get("_qkv_state")
         if st is not None and st[0] == key:
             if id(owner) in self.entries:
