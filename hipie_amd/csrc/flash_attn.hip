@@ -585,6 +585,8 @@ static int flash_attn_impl(FAParams p, int hd, int dtype, void* stream) {
   HIPIE_REQUIRE((((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v | (uintptr_t)p.out) & 15) == 0, "flash_attn: pointers must be 16-byte aligned");
   p.swz = ((p.B * p.H) % 8 == 0) ? 1 : 0;
   p.k_cs = (dtype & HIPIE_K_HL8_HI) ? 16 : 8;
+  // the hi halves of an HL8 buffer are fp16: read as bf16 they would be garbage keys without any error
+  HIPIE_REQUIRE(!(dtype & HIPIE_K_HL8_HI) || (dtype & 0xff) == HIPIE_F16, "flash_attn: HIPIE_K_HL8_HI needs fp16 operands (dtype %d)", dtype & 0xff);
   dtype &= ~HIPIE_K_HL8_HI;
   p.defer = ((dtype & ~HIPIE_OUT_F32) == HIPIE_F16) ? 0.f : kDefer;      // fp16 = parity policy: classic running max
   // diagnostic switches: read from the environment once per process

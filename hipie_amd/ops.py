@@ -1099,6 +1099,7 @@ def conv3x3_split_ok(x, conv):
 
 
 _CONV_STAGE = {}
+_RETIRED = []           # evicted cache entries stay alive: a captured hipGraph may still hold their addresses (as _Workspace.retired does)
 
 
 @_timed("conv3x3_split")
@@ -1118,7 +1119,7 @@ def conv3x3_split(x, conv, act=ACT_NONE):
     buf = _CONV_STAGE.get(skey)
     if buf is None:
         if len(_CONV_STAGE) >= 8:
-            _CONV_STAGE.pop(next(iter(_CONV_STAGE)))
+            _RETIRED.append(_CONV_STAGE.pop(next(iter(_CONV_STAGE))))
         buf = _CONV_STAGE[skey] = torch.zeros(rows + 2 * guard, C, dtype=torch.float32, device=x.device)
     buf[guard:guard + rows].view(B, Hp, Wp, C)[:, 1:-1, 1:-1].copy_(x.permute(0, 2, 3, 1))
     w, b, _ = split_weight(conv, "w3x3", [conv.weight] + ([conv.bias] if conv.bias is not None else []),
@@ -1205,6 +1206,7 @@ def _shuffle_maps(B, H, W, device):
         w = torch.arange(W, device=device).view(1, 1, W)
         m = [((b * 2 * H + 2 * h + i) * 2 * W + 2 * w + j).reshape(-1).to(torch.int32).contiguous() for i in range(2) for j in range(2)]
         if len(_SHUFFLE_MAPS) > 16:
+            _RETIRED.extend(_SHUFFLE_MAPS.values())
             _SHUFFLE_MAPS.clear()
         _SHUFFLE_MAPS[key] = m
     return m

@@ -11,16 +11,21 @@ import torch.distributed as dist
 class GradientBuckets:
     """usage:  gb = GradientBuckets(model.parameters());  loss.backward();  gb.finish();  optimizer.step();  gb.zero_grad()
 
-    Parameters are bucketed in REVERSE registration order (the order autograd produces their gradients in); a bucket's all-reduce is
-    launched asynchronously from the hook of the last parameter of the bucket to receive its gradient.  finish() waits for the
-    outstanding collectives and divides by the world size (launching any bucket a skipped parameter left incomplete).  Without an
-    initialised process group everything degrades to a no-op average over one rank."""
+    Parameters are bucketed in REVERSE registration order (the order autograd produces their gradients in).  A bucket becomes READY when
+    the last of its parameters has received its gradient; collectives are ISSUED strictly in bucket order -- bucket i only once buckets
+    0 .. i-1 are issued -- so every rank issues the same all-reduces in the same order whatever subset of its parameters took part in
+    the step (a data-dependent branch that leaves a parameter without a gradient on one rank only delays that bucket to finish(), it
+    does not reorder it: mismatched collective order hangs RCCL).  finish() issues what is left, waits, and the result is the MEAN over
+    the ranks.  ONE backward per finish(): a second backward before finish() would add into gradients that are already being reduced, so
+    its hooks raise.  Without an initialised process group everything degrades to a no-op average over one rank.
+    `fp16_compression`: the wire carries fp16 of grad / world (divide BEFORE the reduce, like torch's fp16_compress_hook, so the sum of
+    the ranks cannot overflow where the mean would not); arrival is converted back to fp32."""
 
     def __init__(self, params, bucket_mb=64.0, fp16_compression=False, group=None):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.fp16 = bool(fp16_compression)
-        self.buckets = []                   # (flat, [params], pending set of ids)
+        self.buckets = []                   # [flat, [params], set of ids seen this step]
         cap = int(bucket_mb * (1 << 20))
         cur, cur_bytes = [], 0
         for p in reversed(self.params):
@@ -33,6 +38,7 @@ class GradientBuckets:
         if cur:
             self._close(cur)
         self._work = []
+        self._issued = 0                    # buckets [0, _issued) have their collective in flight (or done) this step
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(bi)) for bi, (_, ps, _) in enumerate(self.buckets) for p in ps]
 
     def _close(self, ps):
@@ -43,43 +49,50 @@ class GradientBuckets:
             off += p.numel()
         self.buckets.append((flat, ps, set()))
 
+    def _active(self):
+        return dist.is_initialized() and not (dist.get_world_size(self.group) == 1 and dist.get_backend(self.group) != "nccl")
+
     def _make_hook(self, bi):
         def hook(p):
             flat, ps, seen = self.buckets[bi]
+            if bi < self._issued or id(p) in seen:
+                raise RuntimeError("GradientBuckets: a second backward reached a bucket before finish(); gradient accumulation over several "
+                                   "backward passes needs finish() after the LAST one only -- build the object with the hooks removed "
+                                   "(remove()) for the earlier passes")
             seen.add(id(p))
-            if len(seen) == len(ps):
-                self._launch(bi)
+            while self._issued < len(self.buckets) and len(self.buckets[self._issued][2]) == len(self.buckets[self._issued][1]):
+                self._launch(self._issued)
         return hook
 
     def _launch(self, bi):
+        assert bi == self._issued
+        self._issued += 1
         flat, ps, seen = self.buckets[bi]
-        seen.clear()
-        seen.add("launched")
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1 and dist.get_backend(self.group) != "nccl":
+        if not self._active():
             return
         for p in ps:                                             # a hook-less path may have replaced .grad: keep the views authoritative
             if p.grad is not None and p.grad.untyped_storage().data_ptr() != flat.untyped_storage().data_ptr():
                 raise RuntimeError("GradientBuckets: a parameter's .grad was re-allocated outside its bucket")
+        world = dist.get_world_size(self.group)
         if self.fp16 and flat.dtype == torch.float32:
-            wire = flat.half()
-            self._work.append((dist.all_reduce(wire, group=self.group, async_op=True), flat, wire))
+            wire = (flat / world).half()
+            self._work.append((dist.all_reduce(wire, group=self.group, async_op=True), flat, wire, 1))
         else:
-            self._work.append((dist.all_reduce(flat, group=self.group, async_op=True), flat, None))
+            self._work.append((dist.all_reduce(flat, group=self.group, async_op=True), flat, None, world))
 
     def finish(self):
-        """wait for every bucket, average.  Returns the number of all-reduces that ran."""
-        for bi, (flat, ps, seen) in enumerate(self.buckets):
-            if "launched" not in seen:                           # some parameter of the bucket got no gradient this step
-                self._launch(bi)
+        """issue what is left (in bucket order), wait for every bucket, average.  Returns the number of all-reduces that ran."""
+        while self._issued < len(self.buckets):                  # a bucket some parameter left incomplete this step, and all behind it
+            self._launch(self._issued)
         n = len(self._work)
-        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        for work, flat, wire in self._work:
+        for work, flat, wire, div in self._work:
             work.wait()
             if wire is not None:
                 flat.copy_(wire)
-            if world > 1:
-                flat.div_(world)
+            if div > 1:
+                flat.div_(div)
         self._work = []
+        self._issued = 0
         for _, _, seen in self.buckets:
             seen.clear()
         return n

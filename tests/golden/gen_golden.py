@@ -544,6 +544,16 @@ def gen_e2e_full_c80():
     print("e2e_full_c80: %.0f s" % (time.time() - t0))
 
 
+def gen_e2e_r50_512():
+    """BASELINE configs[0] literally: the reference's detectron2 ResNet-50 with the SHIPPED head sizes (encoder 6 / decoder 6 / MaskDINO
+    encoder 6 + decoder 9, FFN 2048, 900 + 10 / 300 queries, 12-layer BERT) on ONE 512 x 512 image with ONE referring expression, through
+    the reference's own coco_inference on the CPU (MODEL.DEVICE = cpu: about a minute); the detection task with the 9-class prompt rides along."""
+    import time
+    t0 = time.time()
+    gen_e2e(dict(FULL, backbone="r50"), "e2e_r50_512", (("grounding", 1), ("detection", 9)), sizes=((512, 512),))
+    print("e2e_r50_512: %.0f s" % (time.time() - t0))
+
+
 def gen_e2e_padmax():
     """MODEL.LANGUAGE_BACKBONE.PAD_MAX with MAX_QUERY_LEN 4096, the shipped eval setting (configs/eval/image_joint_vit_huge_32g_pan_maskdino_ade_test.yaml:10-11,
     hipie_img.py:904-909): the e2e_tiny inputs with the 9-class caption padded to 4096 tokens.  BertEncoder's > 512 branch then leaves the
@@ -801,7 +811,7 @@ def gen_manifest_full():
 
 ALL = dict(manifest_full=gen_manifest_full, prompts=gen_prompts, post=gen_post, resnet50=gen_resnet50, msda=gen_msda, msda_bwd=gen_msda_bwd, vit_attn=gen_vit_attn, vit_backbone=gen_vit_backbone, bi_attn=gen_bi_attn, bert=gen_bert,
            dynamic_mask=gen_dynamic_mask, e2e=gen_e2e, stages=gen_stages, stages_full=gen_stages_full, e2e_r50=gen_e2e_r50, e2e_long=gen_e2e_long, e2e_deep=gen_e2e_deep, e2e_full=gen_e2e_full, maskclip=gen_maskclip, refinit_stats=gen_refinit_stats, e2e_full_refinit=gen_e2e_full_refinit, e2e_full_c80=gen_e2e_full_c80,
-           e2e_padmax=gen_e2e_padmax)
+           e2e_padmax=gen_e2e_padmax, e2e_r50_512=gen_e2e_r50_512)
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(ALL)

@@ -57,6 +57,10 @@ def test_new_entry_points_validate_on_the_host():
     assert lib.hipie_vit_attn_rel(p, p, p, p, 1, 14, 14, 1, 48, 2, 0, None) == -22 and b"head_dim" in lib.hipie_last_error()
     assert lib.hipie_mask_finalize(p, 0, None, 1, 8, 8, 4, 40, 32, 32, 32, 0.5, p, None) == -22              # crop outside the mask
     assert lib.hipie_add_layernorm_rows(p, None, p, p, None, p, 4, 6, 1e-6, 0, 0, 0, None, None, None) == -22  # C % 4
+    # HIPIE_K_HL8_HI (keys = hi halves of an HL8 buffer, which are fp16) with bf16 operands would read garbage keys: refused
+    st = [64 * 128, 128, 64] * 4
+    assert lib.hipie_flash_attn(p, p, p, p, 1, 2, 64, 64, 64, *st, None, None, 0, 0, None, 1.0, 0.0, 2 | 0x200, None) == -22
+    assert b"HL8_HI" in lib.hipie_last_error()
     # empty work is a no-op even with null data pointers
     assert lib.hipie_batched_nms(None, None, None, None, None, 0, 0, 0.7, 1, None) == 0
     assert lib.hipie_mask_finalize(None, 0, None, 0, 8, 8, 4, 32, 32, 32, 32, 0.5, None, None) == 0

@@ -187,3 +187,67 @@ def test_gradient_buckets_fp16_wire():
         a = torch.tensor(a)
         want = torch.zeros_like(a) if x0 is None else (x0 + x1) / 2
         assert torch.allclose(a, want, rtol=2e-3, atol=1e-3 * float(want.abs().max() + 1e-6))
+
+
+def _ddp_uneven_worker(rank, world, port, q):
+    """rank 1 never uses the middle Linear (a data-dependent branch); large gradients on the fp16 wire; a second backward is refused"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from hipie_amd import parallel
+    from hipie_amd.training import GradientBuckets
+    parallel.init_from_env(backend="gloo")
+    m = _toy_model()
+    gb = GradientBuckets(m.parameters(), bucket_mb=600 / (1 << 20))
+    x = torch.randn(9, 6, generator=torch.Generator().manual_seed(100 + rank))
+    with torch.enable_grad():
+        h = m[1](m[0](x))
+        if rank == 0:
+            h = m[3](m[2](h))
+        m[4](h).square().sum().backward()
+    n = gb.finish()
+    grads = [p.grad.clone().tolist() for p in m.parameters()]
+    gb.zero_grad()
+    refused = False
+    with torch.enable_grad():
+        m(x).square().sum().backward()
+        try:
+            m(x).square().sum().backward()                   # a second backward before finish(): the buckets are already on the wire
+        except RuntimeError:
+            refused = True
+    gb.finish()
+    gb.remove()
+    big = torch.nn.Linear(4, 4)
+    gb2 = GradientBuckets(big.parameters(), fp16_compression=True)
+    with torch.enable_grad():
+        (big(torch.ones(2, 4)).sum() * 3e4).backward()       # gradients of 6e4: the SUM over two ranks overflows fp16, the mean does not
+    gb2.finish()
+    finite = bool(all(torch.isfinite(p.grad).all() for p in big.parameters()))
+    top = float(max(p.grad.abs().max() for p in big.parameters()))
+    parallel.barrier()
+    q.put((rank, n, len(gb.buckets), grads, refused, finite, top))
+
+
+def test_gradient_buckets_uneven_participation_and_wire_range():
+    """(1) ranks whose unused-parameter sets differ issue the SAME collectives in the SAME order (no hang, mean gradients, zero
+    contribution from the rank that skipped the layer); (2) a second backward before finish() is refused instead of reducing a bucket
+    twice; (3) the fp16 wire divides before the reduce: 6e4-sized gradients stay finite."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_ddp_uneven_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in ps], key=lambda x: x[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0][1] == got[0][2] == got[1][1]               # every bucket reduced once on both ranks
+    for a, b in zip(got[0][3], got[1][3]):
+        assert torch.equal(torch.tensor(a), torch.tensor(b))
+    m = _toy_model()
+    x0 = torch.randn(9, 6, generator=torch.Generator().manual_seed(100))
+    with torch.enable_grad():
+        m(x0).square().sum().backward()
+    names = [n for n, _ in m.named_parameters()]
+    mid = torch.tensor(got[0][3][names.index("2.weight")])    # weight of the middle Linear: only rank 0 contributed
+    assert torch.allclose(mid, m[2].weight.grad / 2, rtol=1e-6, atol=1e-7)
+    assert got[0][4] and got[1][4] and got[0][5] and got[1][5] and 5e4 < got[0][6] < 7e4

@@ -161,6 +161,39 @@ def test_windowed_qkv_buffers_persistent_and_shared_modes_agree():
         vit.QKV_BUFFERS.shared.clear()
 
 
+def test_windowed_qkv_buffers_follow_the_geometry_not_the_size():
+    """token grids 50 x 76 and 50 x 72 both pad to 56 x 84 = 4704 window rows at ws 14, with their padding rows in
+    DIFFERENT places.  A persistent qkv buffer keyed on (rows, width) alone kept the first image's qkv in rows that are padding for the
+    second (they entered the window softmax as keys).  Alternating the two geometries on one model must give, for each, exactly what a
+    model that has only ever seen that geometry gives."""
+    from hipie_amd.config import HipieConfig, Precision
+    from hipie_amd.modeling import vit
+    from hipie_amd.modeling.vit import D2ViT
+    g = Golden("vit_backbone")
+    cfg = HipieConfig.from_dict(g.meta["cfg"])
+    sd = _synth.synth_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}, seed=31)
+
+    def fresh():
+        m = D2ViT(cfg, Precision.split3())
+        m.load_state_dict(sd)
+        return m.cuda().eval().cast_weights()
+
+    xa = _synth.synth_tensor("vit_in_a", (1, 3, 800, 1216), seed=33).cuda()       # 50 x 76 tokens
+    xb = _synth.synth_tensor("vit_in_b", (1, 3, 800, 1152), seed=34).cuda()       # 50 x 72 tokens: same 4704 window rows
+    saved = vit.QKV_BUFFERS.budget
+    try:
+        vit.QKV_BUFFERS.budget = 8 << 30
+        want_a, want_b = fresh()(xa), fresh()(xb)
+        m = fresh()
+        got = [m(xa), m(xb), m(xa), m(xb)]
+        torch.cuda.synchronize()
+        for k in ("res3", "res4", "res5"):
+            for i, want in enumerate((want_a, want_b, want_a, want_b)):
+                assert torch.equal(got[i][k], want[k]), (k, i, float((got[i][k] - want[k]).abs().max()))
+    finally:
+        vit.QKV_BUFFERS.budget = saved
+
+
 def test_e2e_pad_max_4096_is_trimmed():
     """The shipped eval setting (MODEL.LANGUAGE_BACKBONE.PAD_MAX, MAX_QUERY_LEN 4096: configs/eval/image_joint_vit_huge_32g_pan_maskdino_ade_test.yaml:10-11,
     hipie_img.py:904-909) in the TIMED policy against the reference's own coco_inference on the same 4096-column inputs
@@ -270,6 +303,50 @@ def test_e2e_r50_tiny(task):
         out = model.forward_raw(inputs(g, task))
         for k in KEYS:
             assert rel_err(g.like(task + "_" + k, out[k].float().cpu()), g[task + "_" + k]) < tol, (k, str(prec))
+
+
+@pytest.mark.parametrize("task", ["grounding", "detection"])
+def test_e2e_r50_512_literal_config0(task):
+    """BASELINE configs[0] LITERALLY (`grounding`): the reference's R50 with the SHIPPED head sizes on ONE 512 x 512 image with ONE
+    referring expression, against the reference's own CPU coco_inference (tests/golden/e2e_r50_512.npz, about half a minute of
+    MODEL.DEVICE = cpu); `detection` = the same model with a class prompt.  Timed (split3) policy and the fp32 parity policy: 1e-3."""
+    from hipie_amd.config import Precision
+    for prec in (Precision.split3(), Precision.parity()):
+        g, model = build(prec, "e2e_r50_512")
+        assert tuple(g.meta["sizes"][0]) == (512, 512) and len(g.meta["sizes"]) == 1
+        model.pin_topk(g[task + "_topk_fg"], g[task + "_topk_md"])
+        out = model.forward_raw(inputs(g, task))
+        errs = {k: rel_err(g.like(task + "_" + k, out[k].float().cpu()), g[task + "_" + k]) for k in KEYS}
+        print("configs[0] literal (R50, 512^2, %s), %s policy: " % (task, prec.name) + " ".join("%s=%.1e" % kv for kv in errs.items()))
+        for k in KEYS:
+            assert errs[k] < 1e-3, (k, errs[k], str(prec))
+
+
+def test_full_size_r50_bs4():
+    """BASELINE configs[1] at FULL SIZE inside the suite: R50, 1024 x 1024, batch 4, the 80-class caption (L = 194), shipped head sizes, timed
+    policy.  No reference run exists at this size (the fixture above pins the same model at 512^2), so the checks are the size-independent
+    ones: finite outputs of the a22 shapes, and batch exchange -- image i's rows do not depend on its neighbours (pinned top-k)."""
+    import bench
+    from hipie_amd.config import HipieConfig, Precision
+    from hipie_amd.hipie_img import HIPIE_IMG
+    g = Golden("e2e_r50_512")
+    cfg = HipieConfig.from_dict(g.meta["cfg"])
+    model = HIPIE_IMG(cfg, Precision.split3(), device="cuda")
+    sd = _synth.synth_full_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}, dist=g.meta.get("dist"))
+    model.load_state_dict(sd, strict=True)
+    model.finalize()
+    batch = bench.synth_batch(None, 4, 1024, 80, 194, "cuda", seed=0, task="detection")
+    out = model.forward_raw(batch)
+    fg, md = model.last_topk()
+    assert out["pred_logits"].shape[:2] == (4, 910) and out["pred_masks"].shape[0] == 4 and out["pred_masks_maskdino"].shape[:2] == (4, 300)
+    for k in KEYS:
+        assert torch.isfinite(out[k].float()).all(), k
+    perm = [2, 0, 3, 1]
+    model.pin_topk(fg[perm], md[perm])
+    out2 = model.forward_raw([batch[i] for i in perm])
+    for k in KEYS:
+        a, b = out[k].float()[perm], out2[k].float()
+        assert rel_err(b.cpu(), a.cpu()) < 1e-4, (k, rel_err(b.cpu(), a.cpu()))
 
 
 def test_stage_vit_backbone():

@@ -243,6 +243,46 @@ def test_maskclip_device_path(split):
     assert e1 < 1e-3 and e2 < 1e-3 and e3 < 1e-3          # the image-token attention runs on fp16 operands
 
 
+def test_maskclip_full_size():
+    """f-2 at the size the eval yamls run it (MODEL.CLIP.NAME ViT-L-14-336: width 1024, 24 layers, 577 image tokens) with the mask-token
+    count of one image of the shipped model (910 detection + 300 MaskDINO queries = 1210): random CLIP weights, one 1024 x 1024 image,
+    blob-shaped mask logits.  The device path (mask tokens as extra rows reading the image tokens' keys through their patch masks; split
+    GEMM linears, image-token attention on hipie_flash_attn) against the oracle's restatement of MaskCLIP.get_mask_embed with the full
+    (Q + 577)^2 boolean attention mask (oracle/clip.py <- hipie/open_vocab/clip.py:258-353) on the CPU: 1e-3 on the mask embeddings."""
+    import time
+    from oracle import clip as oc
+    from hipie_amd.modeling.transformer import set_split
+    from hipie_amd.open_vocab import CLIP_CONFIGS, MaskCLIP
+    from util import rel_err
+    torch.manual_seed(11)
+    m = MaskCLIP("ViT-L-14-336", tokenize=lambda t: None)
+    cfg = CLIP_CONFIGS["ViT-L-14-336"]
+    sd = {k: v.detach().clone() for k, v in torch.nn.Module.state_dict(m.clip).items()}
+    m.loaded = True
+    m = m.cuda().eval()
+    set_split(m, True)
+    gen = torch.Generator().manual_seed(12)
+    Q = 1210
+    image = torch.rand(1, 3, 1024, 1024, generator=gen)
+    coarse = torch.randn(1, Q, 12, 12, generator=gen) * 3.0 - 1.5           # blobs: every mask token sees its own subset of the 24 x 24 patches
+    mask = torch.nn.functional.interpolate(coarse, size=(256, 256), mode="bilinear", align_corners=False)
+    got = m.get_mask_embed(image.cuda(), mask.cuda())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = m.get_mask_embed(image.cuda(), mask.cuda())
+    torch.cuda.synchronize()
+    t_dev = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    want = oc.get_mask_embed(image, mask, sd, "", cfg)
+    t_cpu = time.perf_counter() - t0
+    err = rel_err(got.float().cpu(), want)
+    blocked = (torch.nn.functional.max_pool2d(torch.nn.functional.interpolate(mask, size=(336, 336), mode="bilinear", align_corners=False).sigmoid(), 14, 14) < 0.5)
+    print("maskclip FULL SIZE (ViT-L/14-336, Q = %d): device %.1f ms, oracle on the CPU %.1f s, rel err %.1e; patches blocked per token %.0f%%"
+          % (Q, t_dev * 1e3, t_cpu, err, 100 * float(blocked.float().mean())))
+    assert got.shape == (1, Q, cfg["embed_dim"]) and err < 1e-3
+    assert 0.2 < float(blocked.float().mean()) < 0.95                        # the masks really restrict the attention
+
+
 def test_post_product_with_maskclip_matches_reference():
     """postprocess.inference with MODEL.CLIP.ENABLED (both call sites of the fusion, hipie_img.py:592-609 and :735-747) against
     the reference's own HIPIE_IMG.inference run with its MaskCLIP: classes exactly, scores / boxes / semantic map to 1e-3,

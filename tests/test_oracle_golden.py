@@ -208,6 +208,19 @@ def test_e2e_full_c80_bench_inputs():
             assert rel_err(g.like(task + "_" + k, out[k]), g[task + "_" + k]) < 2e-4, (task, k)
 
 
+def test_e2e_r50_512_literal_config0():
+    """BASELINE configs[0] LITERALLY: R50 with the shipped head sizes, ONE 512 x 512 image, ONE referring expression -- the oracle against the
+    reference's own CPU run (tests/golden/gen_golden.py::gen_e2e_r50_512)."""
+    g = Golden("e2e_r50_512")
+    cfg, sd, imgs, ids, mask = e2e_inputs(g, "grounding")
+    assert len(imgs) == 1 and tuple(imgs[0].shape[-2:]) == (512, 512) and g.meta["grounding"]["n_classes"] == 1
+    ids, mask = ids[:1], mask[:1]                                # one prompt row per image
+    lang = om.bert_encoder(ids, mask, sd, "text_encoder.body.model.", cfg)
+    out = om.coco_inference(imgs, lang, sd, cfg, task="grounding", topk_fg=g["grounding_topk_fg"], topk_md=g["grounding_topk_md"])
+    for k in E2E_KEYS:
+        assert rel_err(g.like("grounding_" + k, out[k]), g["grounding_" + k]) < 2e-4, k
+
+
 @pytest.mark.parametrize("task", ["detection", "grounding"])
 def test_e2e_r50_tiny(task):
     """BASELINE configs[0] (R50, one text prompt: grounding) / [1] (R50, class prompts): a22 against the reference run behind its own
