@@ -24,8 +24,9 @@
 //   * LDS rows are 128 B, which would put a ds_read_b128 lane group on two 16-byte slots (8-way conflict); the 16-byte chunk c
 //     of row r is therefore stored at chunk position c ^ ((r >> 1) & 7).  The DMA writes LDS lane-linearly, so the swizzle is
 //     applied to the per-lane global SOURCE address; the reader applies the same XOR.  Conflict-free for every b128 lane group;
-//   * block -> tile map: the blocks of one XCD (blockIdx % 8) walk a contiguous range of tiles with the N index fastest, so
-//     the workgroups resident on an XCD share a few A row panels and the W panels through that XCD's L2.
+//   * block -> tile map: the blocks of one XCD (blockIdx % 8) walk a contiguous range of tiles -- N index fastest for up to 4 column
+//     tiles, else in groups of 8 row panels with the row panel fastest (GemmParams::group_m) -- so the 32 workgroups resident on an
+//     XCD share 8 A row panels and 4 W panels through that XCD's L2.
 // Epilogue (runtime switches, once per tile): * alpha, + bias, exact-erf GELU | ReLU, + fp32 residual, then the output as
 // fp32, fp16 or HL8 (optionally scaled) -- the HL8 form is directly the A operand of the next GEMM.
 #include <stdlib.h>
@@ -44,6 +45,7 @@ struct GemmParams {
   int M, N, K;
   int nkt;                    // 128-byte k tiles
   int tiles_m, tiles_n;
+  int group_m;                // block -> tile order: 0 / 1 = N fastest; g > 1 = groups of g M-panels, M fastest inside a group
   int out_fmt, act;
   float alpha, oscale;
   // batched form (hipie_gemm_batched): blockIdx.y = outer * nbi + inner; operand / output base offsets in BYTES per outer / inner index
@@ -168,6 +170,11 @@ __device__ __forceinline__ void gm_epi_vals(const float (&x)[NG][4], const int G
     for (int g = 0; g < NG; ++g)
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], 0.f);
+  } else if (act == 3) {                       // QuickGELU of the OpenAI CLIP weights: y * sigmoid(1.702 y) (open_clip's QuickGELU; hipie/open_vocab/clip.py towers)
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[g][e] = v[g][e] / (1.f + expf(-1.702f * v[g][e]));
   }
   if (has_res) {
 #pragma unroll
@@ -266,8 +273,16 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams pin) {
     const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
     const int q = nblk >> 3, r = nblk & 7;
     const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    tm = v / p.tiles_n;
-    tn = v - tm * p.tiles_n;
+    if (p.group_m > 1) {
+      const int gsz = p.group_m * p.tiles_n;
+      const int g = v / gsz, w = v - g * gsz;
+      const int rows = min(p.group_m, p.tiles_m - g * p.group_m);      // the last group may be shorter
+      tn = w / rows;
+      tm = g * p.group_m + (w - tn * rows);
+    } else {
+      tm = v / p.tiles_n;
+      tn = v - tm * p.tiles_n;
+    }
   }
   const int m0 = tm * BM, n0 = tn * BN;
 
@@ -656,6 +671,10 @@ static int launch_gemm(GemmParams& p, hipStream_t st, int batches = 1) {
   constexpr size_t lds = (size_t)2 * (256 + BN) * 128;
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = (p.N + BN - 1) / BN;
+  // wide outputs (qkv: 12 column tiles, fc1: 16): the blocks of an XCD walk groups of 8 row panels with the row panel fastest, so the 32
+  // workgroups resident on an XCD hold 8 A panels x 4 W panels instead of 2 x 16 -- 40 % fewer operand rows through that XCD's L2.
+  // Same-box A/B (profiles/r06_gemm_tile_order.txt): qkv 0.894 -> 0.874 ms, fc1 1.099 -> 1.076 ms; up to 4 column tiles the plain order already is 8 x 4.
+  p.group_m = p.tiles_n > 4 ? 8 : 0;
   auto kern = gemm_kernel<BN, SPLIT, VAR>;
   static bool lds_set[64] = {false};
   int dev = 0;
@@ -707,7 +726,7 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, con
   HIPIE_REQUIRE(in_fmt == HIPIE_F16 || in_fmt == HIPIE_HL8 || in_fmt == HIPIE_F32, "gemm: operand format %d (HIPIE_F16 | HIPIE_HL8 | HIPIE_F32)",
                 in_fmt);
   HIPIE_REQUIRE(out_fmt == HIPIE_F32 || out_fmt == HIPIE_F16 || out_fmt == HIPIE_HL8, "gemm: output format %d", out_fmt);
-  HIPIE_REQUIRE(act >= 0 && act <= 2, "gemm: activation %d (0 none, 1 gelu, 2 relu)", act);
+  HIPIE_REQUIRE(act >= 0 && act <= 3, "gemm: activation %d (0 none, 1 gelu, 2 relu, 3 quick-gelu)", act);
   HIPIE_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0, "gemm: M=%d N=%d K=%d (N must be a multiple of 8)", M, N, K);
   const bool a_f32 = in_fmt == HIPIE_F32;       // A rows are plain fp32 (lda in fp32 elements), split in the kernel; W is HL8
   const bool split = in_fmt == HIPIE_HL8 || a_f32;

@@ -10,9 +10,15 @@ are meaningless; `HIPIE_IMG` says so once.
 
 Device path.  In the reference every token may attend only to the class token and the patches (mask tokens are never attended to,
 clip.py:318-321), so the (Q + 577)^2 masked attention decomposes: the 577 image tokens run a plain ViT-L/14 (hipie_flash_attn, head dim
-64), and the Q mask tokens -- copies of the class token -- run beside them as extra ROWS of the same linears, reading the image tokens'
-keys / values of each layer through their (Q x 577) patch masks.  Nothing of size (Q + 577)^2 is built.  The linears are policy-aware
-(PLinear: the split-fp16 GEMM under Precision.split3), LayerNorm / softmax fp32.
+64) that does not depend on the masks at all, and the Q mask tokens -- copies of the class token -- are extra ROWS of the same block
+weights that read the image tokens' keys / values of each layer through their (Q x 577) patch masks.  Nothing of size (Q + 577)^2 is
+built.  Round 6 (the full-size measurement: 176 ms of CLIP behind a 200 ms bs-8 forward) split the two for good:
+  * MaskCLIP.encode_images runs the image tokens ONCE per image and keeps every layer's keys / values (113 MB per image in fp32);
+    HIPIE_IMG.inference calls the fusion twice per image (instances, hipie_img.py:592-609; semantic / panoptic, :735-747) -- both read
+    the same state, and the images of a batch go through the tower together (M = 577 B rows per GEMM instead of B launches of 577);
+  * MaskCLIP.mask_rows runs the mask tokens of all images as one batch of rows, ragged counts padded with fully blocked rows; a mask
+    token's keys and values are never used, so its in-projection is the QUERY third only.
+The linears are policy-aware (PLinear: the split-fp16 GEMM under Precision.split3), LayerNorm / softmax fp32.
 """
 import math
 import os
@@ -65,9 +71,15 @@ class ResidualAttentionBlock(nn.Module):
         self.heads, self.quick_gelu = heads, quick_gelu
 
     def _mlp(self, x):
-        h = self.mlp.c_fc(self.ln_2(x))
+        fc, pj = self.mlp.c_fc, self.mlp.c_proj
+        if fc.split and x.is_cuda and fc.weight.dtype == torch.float32 and ops.split_ok(fc.in_features) and ops.split_ok(pj.in_features):
+            # the activation in the first GEMM's epilogue, its output as the HL8 operand of the second, the residual in the second's epilogue:
+            # no (rows x 4 D) fp32 tensor, no elementwise passes
+            h = ops.split_linear(self.ln_2(x), fc, "w", fc.weight, fc.bias, act=ops.ACT_QGELU if self.quick_gelu else ops.ACT_GELU, out_fmt=ops.HL8)
+            return ops.split_linear(h, pj, "w", pj.weight, pj.bias, resid=x.contiguous(), x_hl8=True)
+        h = fc(self.ln_2(x))
         h = h * torch.sigmoid(1.702 * h) if self.quick_gelu else F.gelu(h)
-        return x + self.mlp.c_proj(h)
+        return x + pj(h)
 
     def forward(self, x, add_mask=None):
         """plain block on (N, L, D) with an optional additive (L, L) mask (the text tower's causal mask)."""
@@ -81,25 +93,43 @@ class ResidualAttentionBlock(nn.Module):
         o = (s.softmax(-1) @ v).transpose(1, 2).reshape(N, L, D)
         return self._mlp(x + self.attn.out_proj(o))
 
-    def forward_masked(self, x, Q, blocked):
-        """x (N, Q + T, D) = [Q mask tokens | T image tokens]; blocked (N, Q, T) bool: mask token q may not see image token t.
-        Keys / values are the image tokens only (no token attends to a mask token)."""
-        N, L, D = x.shape
-        T = L - Q
+    def forward_image(self, x):
+        """the image tokens alone, x (N, T, D) -> (block output, keys (N, T, H, hd), values (N, T, H, hd)) -- what the mask tokens of this
+        layer attend to."""
+        N, T, D = x.shape
         H, hd = self.heads, D // self.heads
-        qkv = _lin(self.attn, "in", self.ln_1(x), self.attn.in_proj_weight, self.attn.in_proj_bias).view(N, L, 3, H, hd)
-        qi, ki, vi = qkv[:, Q:, 0], qkv[:, Q:, 1], qkv[:, Q:, 2]                      # (N, T, H, hd) strided views
+        qkv = _lin(self.attn, "in", self.ln_1(x), self.attn.in_proj_weight, self.attn.in_proj_bias).view(N, T, 3, H, hd)
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]                              # (N, T, H, hd) strided views
         if x.is_cuda:
-            oi = ops.flash_attn(qi.half(), ki.half(), vi.half(), hd ** -0.5, out_f32=True)      # (N, T, D): the plain ViT rows
+            o = ops.flash_attn(q.half(), k.half(), v.half(), hd ** -0.5, out_f32=True)  # (N, T, D)
         else:
-            s = (qi.transpose(1, 2) * hd ** -0.5) @ ki.permute(0, 2, 3, 1)
-            oi = (s.softmax(-1) @ vi.transpose(1, 2)).transpose(1, 2).reshape(N, T, D)
-        # the mask tokens' rows: (N, H, Q, T) scores against the image keys, blocked patches at -inf
-        s = (qkv[:, :Q, 0].transpose(1, 2).float() * hd ** -0.5) @ ki.permute(0, 2, 3, 1).float()
-        s = s.masked_fill(blocked[:, None], float("-inf"))
-        om = (s.softmax(-1) @ vi.transpose(1, 2).float()).transpose(1, 2).reshape(N, Q, D)
-        o = torch.cat([om, oi.to(om.dtype)], dim=1)
-        return self._mlp(x + self.attn.out_proj(o))
+            sc = (q.transpose(1, 2) * hd ** -0.5) @ k.permute(0, 2, 3, 1)
+            o = (sc.softmax(-1) @ v.transpose(1, 2)).transpose(1, 2).reshape(N, T, D)
+        return self._mlp(x + self.attn.out_proj(o.to(x.dtype))), k, v
+
+    def _q_only(self, h):
+        """the query third of the in-projection (a mask token's keys / values are never read)"""
+        D = h.shape[-1]
+        w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
+        if getattr(self.attn, "split", False) and h.is_cuda and w.dtype == torch.float32 and ops.split_ok(D):
+            return ops.split_linear(h, self.attn, "inq", w, b, weight_fn=lambda: w[:D], bias_fn=lambda: b[:D], params=[w, b])
+        return F.linear(h.to(w.dtype), w[:D], b[:D])
+
+    def forward_mask_rows(self, xm, k, v, blocked):
+        """the mask tokens' rows: xm (N, Q, D); k, v (N, T, H, hd) of the image tokens of THIS layer; blocked (N, Q, T) bool (True: mask
+        token q may not see image token t; the class token, t = 0, is always visible, so no row is fully blocked)."""
+        N, Q, D = xm.shape
+        H, hd = self.heads, D // self.heads
+        q = self._q_only(self.ln_1(xm)).view(N, Q, H, hd)
+        sc = (q.transpose(1, 2).float() * hd ** -0.5) @ k.permute(0, 2, 3, 1).float()   # (N, H, Q, T)
+        sc = sc.masked_fill(blocked[:, None], float("-inf"))
+        om = (sc.softmax(-1) @ v.transpose(1, 2).float()).transpose(1, 2).reshape(N, Q, D)
+        return self._mlp(xm + self.attn.out_proj(om))
+
+    def forward_masked(self, x, Q, blocked):
+        """x (N, Q + T, D) = [Q mask tokens | T image tokens] -> the same layout one block later (the one-call form of the two above)."""
+        xi, k, v = self.forward_image(x[:, Q:])
+        return torch.cat([self.forward_mask_rows(x[:, :Q], k, v, blocked), xi], dim=1)
 
 
 class _Transformer(nn.Module):
@@ -240,26 +270,58 @@ class MaskCLIP(nn.Module):
 
     # ---- clip.py:291-353 ------------------------------------------------------------------------------------
     @torch.no_grad()
-    def get_mask_embed(self, image, mask):
-        """image (N,3,H,W) in 0..1, mask (N,Q,h,w) logits -> (N,Q,embed_dim)."""
+    def encode_images(self, image):
+        """image (N,3,H,W) in 0..1 -> the mask-independent state of the visual tower: {"cls0": (N,1,D) the ln_pre'd class token every mask
+        token starts from, "k" / "v": per layer (N, 577, H, hd) keys / values of the image tokens}.  One pass per image, shared by every
+        get_mask_embed / mask_rows call on it."""
         vis, c = self.clip.visual, self.cfg
-        S = self.image_size
-        image = F.interpolate(image.float(), size=S, mode="bilinear", align_corners=False)
-        mask = F.interpolate(mask.float(), size=S, mode="bilinear", align_corners=False)
+        image = F.interpolate(image.float(), size=self.image_size, mode="bilinear", align_corners=False)
         mean = torch.tensor(CLIP_MEAN, device=image.device).view(1, 3, 1, 1)
         std = torch.tensor(CLIP_STD, device=image.device).view(1, 3, 1, 1)
         image = (image - mean) / std                                    # clip_preprocess: Resize / CenterCrop are no-ops at this size
-        N, Q = mask.shape[:2]
-        patch_mask = F.max_pool2d(mask.sigmoid(), kernel_size=c["patch"], stride=c["patch"])
-        blocked = torch.cat([torch.zeros(N, Q, 1, dtype=torch.bool, device=mask.device), (patch_mask < 0.5).reshape(N, Q, -1)], 2)
+        N = image.shape[0]
         x = F.conv2d(image, vis.conv1.weight.float(), None, stride=c["patch"])
         x = x.reshape(N, x.shape[1], -1).permute(0, 2, 1)
         x = torch.cat([vis.class_embedding.float().expand(N, 1, -1), x], dim=1) + vis.positional_embedding.float()
         x = vis.ln_pre(x)
-        x = torch.cat([x[:, 0:1].expand(-1, Q, -1), x], dim=1)          # [mask tokens | class token | patches]
+        state = {"cls0": x[:, 0:1].clone(), "k": [], "v": []}
         for blk in vis.transformer.resblocks:
-            x = blk.forward_masked(x, Q, blocked)
-        return vis.ln_post(x[:, :Q]) @ vis.proj.float()
+            x, k, v = blk.forward_image(x)
+            state["k"].append(k)
+            state["v"].append(v)
+        return state
+
+    @staticmethod
+    def state_of(state, i):
+        """the state of image i of a batched state (views)"""
+        return {"cls0": state["cls0"][i:i + 1], "k": [k[i:i + 1] for k in state["k"]], "v": [v[i:i + 1] for v in state["v"]]}
+
+    @torch.no_grad()
+    def blocked_patches(self, mask):
+        """mask (N,Q,h,w) logits -> (N, Q, 1 + g*g) bool, True = the mask token may NOT attend to that image token (clip.py:299-321: a
+        patch is visible when the sigmoid mask, resized to the CLIP input, reaches 0.5 somewhere inside it; the class token always is)."""
+        c = self.cfg
+        mask = F.interpolate(mask.float(), size=self.image_size, mode="bilinear", align_corners=False)
+        N, Q = mask.shape[:2]
+        patch_mask = F.max_pool2d(mask.sigmoid(), kernel_size=c["patch"], stride=c["patch"])
+        return torch.cat([torch.zeros(N, Q, 1, dtype=torch.bool, device=mask.device), (patch_mask < 0.5).reshape(N, Q, -1)], 2)
+
+    @torch.no_grad()
+    def mask_rows(self, state, blocked):
+        """state of N images (encode_images), blocked (N, Q, T) -> mask embeddings (N, Q, embed_dim)."""
+        vis = self.clip.visual
+        N, Q = blocked.shape[:2]
+        xm = state["cls0"].expand(-1, Q, -1)
+        for l, blk in enumerate(vis.transformer.resblocks):
+            xm = blk.forward_mask_rows(xm, state["k"][l], state["v"][l], blocked)
+        return vis.ln_post(xm) @ vis.proj.float()
+
+    @torch.no_grad()
+    def get_mask_embed(self, image, mask, state=None):
+        """image (N,3,H,W) in 0..1, mask (N,Q,h,w) logits -> (N,Q,embed_dim).  state: encode_images(image) when the caller already has it."""
+        if state is None:
+            state = self.encode_images(image)
+        return self.mask_rows(state, self.blocked_patches(mask))
 
     def pred_logits(self, mask_embed, text_embed, labels):
         lg = torch.einsum("bqc,nc->bqn", F.normalize(mask_embed.float(), dim=-1), F.normalize(text_embed.float(), dim=-1)) * self.logit_scale
@@ -283,22 +345,15 @@ class MaskCLIP(nn.Module):
         return self.cache_text[key]
 
     @torch.no_grad()
-    def forward(self, image, mask, text_embed, labels):
-        emb = self.get_mask_embed(image, mask)
+    def forward(self, image, mask, text_embed, labels, state=None):
+        emb = self.get_mask_embed(image, mask, state)
         out = {"mask_embed": emb}
         if text_embed is not None and labels is not None:
             out["mask_pred_open_logits"] = self.pred_logits(emb, text_embed, labels)
         return out
 
 
-def get_clip_logits(clip, image01, mask_logits, test_label_names, train_label_names, pred_open_prob, alpha, beta, agg_mode="MUL"):
-    """HIPIE_IMG.get_clip_logits (hipie_img.py:811-868) for ONE image: image01 (3,H,W) in 0..1, mask_logits (Q,h,w), test / train label
-    names = lists of synonym lists, pred_open_prob (Q,C) -> fused class logits (Q,C)."""
-    labels = prompt_labels_photo(test_label_names)
-    train = {l for syn in train_label_names for l in syn}
-    ov = torch.tensor([int(not train.isdisjoint(set(syn))) for syn in test_label_names], dtype=torch.long, device=pred_open_prob.device)
-    text_embed = clip.build_text_embed(labels).to(pred_open_prob.device)
-    lg = clip(image01[None], mask_logits[None], text_embed, labels)["mask_pred_open_logits"][0]
+def _fuse(lg, pred_open_prob, ov, alpha, beta, agg_mode):
     mp = lg.sigmoid() if lg.shape[-1] == 1 else lg.softmax(dim=-1)
     p = pred_open_prob.float()
     if agg_mode == "ADD":
@@ -308,3 +363,36 @@ def get_clip_logits(clip, image01, mask_logits, test_label_names, train_label_na
         base = (p ** (1 - alpha) * mp ** alpha).log() * ov
         novel = (p ** (1 - beta) * mp ** beta).log() * (1 - ov)
     return base + novel
+
+
+def _vocab(clip, test_label_names, train_label_names, device):
+    labels = prompt_labels_photo(test_label_names)
+    train = {l for syn in train_label_names for l in syn}
+    ov = torch.tensor([int(not train.isdisjoint(set(syn))) for syn in test_label_names], dtype=torch.long, device=device)
+    return labels, ov, clip.build_text_embed(labels).to(device)
+
+
+def get_clip_logits(clip, image01, mask_logits, test_label_names, train_label_names, pred_open_prob, alpha, beta, agg_mode="MUL", state=None):
+    """HIPIE_IMG.get_clip_logits (hipie_img.py:811-868) for ONE image: image01 (3,H,W) in 0..1, mask_logits (Q,h,w), test / train label
+    names = lists of synonym lists, pred_open_prob (Q,C) -> fused class logits (Q,C).  state: MaskCLIP.encode_images of this image."""
+    labels, ov, text_embed = _vocab(clip, test_label_names, train_label_names, pred_open_prob.device)
+    lg = clip(None if image01 is None else image01[None], mask_logits[None], text_embed, labels, state=state)["mask_pred_open_logits"][0]
+    return _fuse(lg, pred_open_prob, ov, alpha, beta, agg_mode)
+
+
+def get_clip_logits_batched(clip, state, mask_logits, test_label_names, train_label_names, pred_open_prob, alpha, beta, agg_mode="MUL"):
+    """the same for the N images of a batched state in ONE pass of the mask tokens: mask_logits / pred_open_prob are lists of (Q_i,h_i,w_i) /
+    (Q_i,C) tensors (ragged Q_i: rows are padded with mask tokens that see the class token only and dropped again) -> list of (Q_i,C).
+    Every row's result is what get_clip_logits gives for its image alone (rows of a GEMM do not interact; the softmax is per row)."""
+    dev = pred_open_prob[0].device
+    labels, ov, text_embed = _vocab(clip, test_label_names, train_label_names, dev)
+    blocked = [clip.blocked_patches(m[None])[0] for m in mask_logits]          # per image: the (Q_i, 336, 336) resize is the big transient
+    qs = [b.shape[0] for b in blocked]
+    Qm = max(qs)
+    pad = torch.ones(len(qs), Qm, blocked[0].shape[-1], dtype=torch.bool, device=dev)
+    pad[:, :, 0] = False
+    for i, b in enumerate(blocked):
+        pad[i, :qs[i]] = b
+    emb = clip.mask_rows(state, pad)
+    lg = clip.pred_logits(emb, text_embed, labels)
+    return [_fuse(lg[i, :qs[i]], pred_open_prob[i], ov, alpha, beta, agg_mode) for i in range(len(qs))]

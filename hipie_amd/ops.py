@@ -940,7 +940,7 @@ def fill_rows(dst, rows, src_row):
     return dst
 
 
-ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_QGELU = 0, 1, 2, 3
 
 
 def _gemm_tag(a, w, *args, **kw):

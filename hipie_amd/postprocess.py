@@ -165,22 +165,50 @@ def _segments_info(tables):
     return out
 
 
-def _clip_logits(model, batched_inputs, i, mask_logits, pred_open_prob):
-    """HIPIE_IMG.get_clip_logits for image i (hipie_img.py:811-868).  The image is the un-normalised input / 255 (:349-351); the test
-    vocabulary is the input's `open_seg_labels` ([{"name": "a,b,..."}] per class, data/coco_dataset_mapper_uni.py), the training
-    vocabulary model.train_labels."""
-    from .open_vocab import get_clip_logits
-    x = batched_inputs[i]
-    test = x.get("open_seg_labels")
+def _clip_vocab(model, batched_inputs):
+    test = batched_inputs[0].get("open_seg_labels")
     if test is None:
         raise ValueError("MODEL.CLIP.ENABLED needs `open_seg_labels` in every input (the test-time mapper provides it)")
     if getattr(model, "train_labels", None) is None:
         raise RuntimeError("MaskCLIP: the training vocabulary is missing -- set model.train_labels (get_openseg_labels('coco_panoptic', "
                            "prompt_engineered=True)) or provide the reference's openseg_labels directory (HIPIE_ASSETS)")
+    return [t["name"].split(",") for t in test], [t["name"].split(",") for t in model.train_labels]
+
+
+def _clip_states(model, batched_inputs, out):
+    """the mask-independent pass of MaskCLIP's visual tower over the images of this call (open_vocab.MaskCLIP.encode_images), ONCE per
+    inference call: both fusion sites (instances, semantic / panoptic) read it.  Images of one size go through the tower as one batch.
+    Kept in the output dict of the call, so its lifetime is the call's.  The image is the un-normalised input / 255 (hipie_img.py:349-351)."""
+    st = out.get("_clip_states")
+    if st is None:
+        dev = out["pred_logits"].device
+        imgs = [x["image"].to(dev).float() / 255.0 for x in batched_inputs]
+        if len(set(tuple(t.shape) for t in imgs)) == 1:
+            st = ("batched", model.clip.encode_images(torch.stack(imgs)))
+        else:
+            st = ("list", [model.clip.encode_images(t[None]) for t in imgs])
+        out["_clip_states"] = st
+    return st
+
+
+def _clip_logits_all(model, batched_inputs, out, mask_logits, pred_open_prob):
+    """HIPIE_IMG.get_clip_logits (hipie_img.py:811-868) for every image of the call: mask_logits / pred_open_prob = per-image lists of
+    (Q_i, h, w) / (Q_i, C) -> list of fused (Q_i, C).  The test vocabulary is the inputs' `open_seg_labels` ([{"name": "a,b,..."}] per
+    class, data/coco_dataset_mapper_uni.py; one vocabulary per call, as one task per call: hipie_img.py:285), the training vocabulary
+    model.train_labels."""
+    from .open_vocab import get_clip_logits, get_clip_logits_batched
+    test, train = _clip_vocab(model, batched_inputs)
     cfg = model.cfg
-    img = x["image"].to(mask_logits.device).float() / 255.0
-    return get_clip_logits(model.clip, img, mask_logits, [t["name"].split(",") for t in test],
-                           [t["name"].split(",") for t in model.train_labels], pred_open_prob, cfg.clip_alpha, cfg.clip_beta, cfg.clip_agg_mode)
+    kind, st = _clip_states(model, batched_inputs, out)
+    if kind == "batched" and all(x.get("open_seg_labels") == batched_inputs[0].get("open_seg_labels") for x in batched_inputs):
+        return get_clip_logits_batched(model.clip, st, mask_logits, test, train, pred_open_prob, cfg.clip_alpha, cfg.clip_beta, cfg.clip_agg_mode)
+    res = []
+    for i, x in enumerate(batched_inputs):
+        test_i = [t["name"].split(",") for t in x["open_seg_labels"]]
+        state = st[i] if kind == "list" else model.clip.state_of(st, i)
+        res.append(get_clip_logits(model.clip, None, mask_logits[i], test_i, train, pred_open_prob[i], cfg.clip_alpha, cfg.clip_beta,
+                                   cfg.clip_agg_mode, state=state))
+    return res
 
 
 # ------------------------------------------------------------------------------------------------ the entry point
@@ -226,7 +254,7 @@ def _instances_on_device(model, out, batched_inputs, do_postprocess=True):
             hm = -(-image_sizes[i][0] // 32) * 32 // s
             wm = -(-image_sizes[i][1] // 32) * 32 // s
             return pred_masks[i][:, :min(hm, pred_masks.shape[-2]), :min(wm, pred_masks.shape[-1])]
-        fused = torch.stack([_clip_logits(model, batched_inputs, i, own_canvas(i), p_det[i]) for i in range(B)])
+        fused = torch.stack(_clip_logits_all(model, batched_inputs, out, [own_canvas(i) for i in range(B)], [p_det[i] for i in range(B)]))
         allowed = (logits[:, :1] != NEG).float()                                  # the reference's is_thing_mask (first query row)
         prob = torch.sqrt((fused.sigmoid() * allowed) ** cfg.clip_fg_a * iou.sigmoid() ** cfg.clip_fg_b)
     else:
@@ -279,6 +307,7 @@ def inference_compact(model, out, batched_inputs, topk=100, do_postprocess=True)
     the instances are packed to the front of every row with a stable sort instead of a host round trip, so a data-parallel
     evaluation loop never synchronises with the host between the forward and the all-gather."""
     d = _instances_on_device(model, out, batched_inputs, do_postprocess)
+    out.pop("_clip_states", None)
     ok = d["ok"]
     B, K = ok.shape
     order = torch.sort((~ok).to(torch.int8), dim=1, stable=True)[1]                  # instances first, original (score) order kept
@@ -292,6 +321,13 @@ def inference_compact(model, out, batched_inputs, topk=100, do_postprocess=True)
 
 @torch.no_grad()
 def inference(model, out, batched_inputs, do_postprocess=True, with_masks=True, with_sem_pan=True):
+    try:
+        return _inference(model, out, batched_inputs, do_postprocess, with_masks, with_sem_pan)
+    finally:
+        out.pop("_clip_states", None)            # MaskCLIP's per-call image state (_clip_states) does not outlive the call
+
+
+def _inference(model, out, batched_inputs, do_postprocess=True, with_masks=True, with_sem_pan=True):
     """a22 dictionary -> list of {"instances": Instances, "panoptic_seg": (label map, segments_info), "sem_seg"} like
     HIPIE_IMG.forward's eval branch (hipie_img.py:313-362).  with_masks / with_sem_pan False skip the instance masks /
     the semantic + panoptic maps (e.g. a detection-only consumer, or the compact all-gather block of parallel.py)."""
@@ -325,6 +361,7 @@ def inference(model, out, batched_inputs, do_postprocess=True, with_masks=True, 
         logits_bg = convert_grounding_to_od_logits(md_logits, C, pmap, is_thing, mode, cfg.mode_free, cfg.max_pool)
         if not cfg.use_bg_for_pano:
             count_h = count.tolist()
+        cls_list, masks_list = [], []
         for i in range(B):
             if cfg.use_bg_for_pano:
                 logits_all, masks_all = logits_bg[i], md_masks[i]
@@ -336,12 +373,18 @@ def inference(model, out, batched_inputs, do_postprocess=True, with_masks=True, 
                 cls_all = F.softmax(logits_all.sigmoid() / cfg.pano_temp, dim=-1)
             else:
                 cls_all = logits_all.sigmoid()
-            if getattr(model, "enable_clip", False):
-                # hipie_img.py:731-747: the masks the reference hands to CLIP are the x4 up-sampled logits cropped to the image
-                up = F.interpolate(masks_all[:, None].float(), scale_factor=float(s), mode="bilinear", align_corners=False)
-                up = up[:, 0, :image_sizes[i][0], :image_sizes[i][1]]
-                cls_all = _clip_logits(model, batched_inputs, i, up, cls_all).softmax(-1)
-            sem, tab = _sem_pan(cls_all, masks_all, s, image_sizes[i], out_sizes[i], thing_vector(is_thing[i], C, dev), cfg,
+            cls_list.append(cls_all)
+            masks_list.append(masks_all)
+        if getattr(model, "enable_clip", False):
+            # hipie_img.py:731-747: the masks the reference hands to CLIP are the x4 up-sampled logits cropped to the image
+            ups = []
+            for i in range(B):
+                up = F.interpolate(masks_list[i][:, None].float(), scale_factor=float(s), mode="bilinear", align_corners=False)
+                ups.append(up[:, 0, :image_sizes[i][0], :image_sizes[i][1]])
+            cls_list = [c.softmax(-1) for c in _clip_logits_all(model, batched_inputs, out, ups, cls_list)]
+            del ups
+        for i in range(B):
+            sem, tab = _sem_pan(cls_list[i], masks_list[i], s, image_sizes[i], out_sizes[i], thing_vector(is_thing[i], C, dev), cfg,
                                 0 if getattr(getattr(model, "precision", None), "einsum", 0) in (0, 1, 4) else 1)
             results[i]["sem_seg"] = sem
             tables.append(tab)

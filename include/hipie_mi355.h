@@ -418,7 +418,8 @@ int hipie_box_refine(const void* delta, const float* ref, float* out, int64_t n,
  *            as hipie_to_hl8 followed by the HL8 form, bit for bit, without the conversion launch.
  *   lda, ldw row strides in fp16 elements (multiples of 8);  K a multiple of 64 (F16) / 32 (HL8);  N a multiple of 8
  *   bias     (N) f32 or NULL;   resid (M, N) f32 with row stride ldr, or NULL
- *   epilogue y = alpha * acc + bias;  act 1: exact-erf GELU(y), 2: ReLU(y);  y = (y + resid) * oscale
+ *   epilogue y = alpha * acc + bias;  act 1: exact-erf GELU(y), 2: ReLU(y), 3: QuickGELU y * sigmoid(1.702 y) (the OpenAI CLIP towers of
+ *            MaskCLIP, hipie/open_vocab/clip.py via open_clip);  y = (y + resid) * oscale
  *   out      (M, N) in out_fmt HIPIE_F32 | HIPIE_F16 | HIPIE_HL8 (row stride ldo in elements of that format; HL8: fp16 elements >= 2N):
  *            the HL8 form is directly the A operand of a following hipie_gemm.  out may alias resid (in-place residual update).
  *   out_row  (M) int32 or NULL: product row m is written to output row out_row[m] and takes its residual from resid row out_row[m];

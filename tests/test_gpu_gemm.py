@@ -39,6 +39,8 @@ def _ref(a, w, bias, resid, act, alpha, oscale):
         y = torch.nn.functional.gelu(y)
     elif act == 2:
         y = torch.relu(y)
+    elif act == 3:                                   # QuickGELU (open_clip, the OpenAI CLIP weights)
+        y = y * torch.sigmoid(1.702 * y)
     if resid is not None:
         y = y + resid.double()
     return y * oscale
@@ -112,7 +114,7 @@ def test_gemm_plain_fp16(M, N, K):
 @gpu
 @pytest.mark.parametrize("split", [True, False])
 @pytest.mark.parametrize("out_fmt", ["f32", "f16", "hl8"])
-@pytest.mark.parametrize("act,with_res", [(0, False), (1, False), (2, True), (0, True)])
+@pytest.mark.parametrize("act,with_res", [(0, False), (1, False), (2, True), (0, True), (3, False), (3, True)])
 def test_gemm_epilogues(split, out_fmt, act, with_res):
     from hipie_amd import ops
     M, N, K = 333, 640, 512
