@@ -328,3 +328,36 @@ def msda_bwd_inputs(tag, D=None):
     attn = attn / attn.sum(-1, keepdim=True).sum(-2, keepdim=True)
     gout = torch.randn(B, Lq, M * D, generator=g, dtype=f64)
     return value, shapes, loc, attn, gout
+
+
+def hash_uniform(call, shape, device="cpu"):
+    """the `call`-th random tensor of a step as a counter-based hash: uniform in [0, 1) with 24 bits, bit-identical on every device (int64
+    arithmetic only).  gen_train_step_golden.py feeds the REFERENCE these values in place of torch.rand / rand_like / randint_like (its
+    algorithms do not care which uniform numbers they get), and the product's training step draws the same ones in the same order -- so a
+    whole training step can be compared without storing megabytes of point coordinates."""
+    n = 1
+    for s in shape:
+        n *= int(s)
+    x = torch.arange(n, dtype=torch.int64, device=device) * 2654435761 + (int(call) + 1) * 40503 + 97
+    x = x & 0xFFFFFFFF
+    x = x ^ (x >> 15)
+    x = (x * 2246822519) & 0xFFFFFFFF
+    x = x ^ (x >> 13)
+    x = (x * 3266489917) & 0xFFFFFFFF
+    x = x ^ (x >> 16)
+    return ((x & 0xFFFFFF).to(torch.float32) / 16777216.0).reshape(tuple(int(s) for s in shape))
+
+
+class HashDraws:
+    """the step's source of random numbers: rand(shape) / randint(low, high, shape) in call order (see hash_uniform)"""
+
+    def __init__(self):
+        self.calls = 0
+
+    def rand(self, shape, device="cpu"):
+        r = hash_uniform(self.calls, shape, device)
+        self.calls += 1
+        return r
+
+    def randint(self, low, high, shape, device="cpu"):
+        return (self.rand(shape, device) * (high - low)).floor().long() + low
