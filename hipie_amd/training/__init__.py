@@ -1,9 +1,18 @@
-"""Training-side host logic of the reference, device-agnostic PyTorch: matching costs + assignment, the
-set-prediction losses of the two heads, contrastive de-noising query preparation.  The operator backward it goes with is
-``hipie_msda_backward`` (csrc/msda_bwd.hip); functions.py holds the autograd Functions of the kernels that have a backward (mask
-contraction, CondInst dynamic mask head), ddp.py the bucketed gradient all-reduce.  NOT a training step: the ViT / encoder / decoder
-kernels of the inference path have no backward and there is no coco_forward, so nothing here is on a timed path.  Every function that draws random numbers in the reference takes them as an
-argument (or from a ``draw`` callable) so that results can be compared with the reference bit for bit."""
+"""The training side of the path.
+
+  step.py      ONE TRAINING STEP: the training branch of HIPIE_IMG.forward around DDETRSegmUniDN.coco_forward (de-noising queries, the three
+               query groups with their matchings and DINO criterion calls, the MaskDINO branch and its criterion) as a weighted loss
+               dictionary over the product model's parameters -- loss entries, total and every parameter gradient pinned against the
+               reference's own step (tests/golden/train_step_tiny.npz, tests/test_training.py::test_train_step_*);
+  net.py       the differentiable network under it: hand-written HIP forward AND backward for multi-scale deformable attention, the mask
+               contraction and the CondInst dynamic mask head (functions.py, ../msda_shim.py); the dense layers on the library kernels
+               with torch.autograd (the inference path's fused split-fp16 kernels have no backward);
+  matcher.py, criterion.py, dn.py, targets.py, weights.py, boxes.py
+               the host logic: matching costs + assignment (Hungarian, SimOTA), the set-prediction losses of both heads, contrastive
+               de-noising queries, target preparation, loss weighting -- each pinned against the reference's classes;
+  ddp.py       bucketed gradient all-reduce over RCCL (what create_ddp_model does for the reference).
+Every function that draws random numbers in the reference takes them as an argument (or from a ``draw`` callable), so results compare
+with the reference entry for entry."""
 from .boxes import box_cxcywh_to_xyxy, generalized_box_iou, paired_giou_loss, paired_iou      # noqa: F401
 from .matcher import HungarianMatcher, MatchWeights                                            # noqa: F401
 from .dn import cdn_queries, dn_split_outputs, dn_match_indices, maskdino_dn_queries           # noqa: F401
@@ -11,3 +20,4 @@ from .criterion import DetCriterion, MaskCriterion                              
 from .weights import maskdino_loss_plan, weighted_merge                                        # noqa: F401
 from .targets import prepare_targets, split_things_stuff                                       # noqa: F401
 from .ddp import GradientBuckets                                                               # noqa: F401
+from .step import TrainStep                                                                    # noqa: F401

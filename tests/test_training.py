@@ -325,3 +325,108 @@ def test_prepare_targets_and_the_thing_stuff_split():
         assert len(f_["labels"]) == n_thing and len(b_["labels"]) == len(t["labels"]) - n_thing and bool(f_["is_thing"].all()) and not bool(b_["is_thing"].any())
         assert torch.equal(f_["boxes"], t["boxes"][t["is_thing"]]) and torch.equal(b_["masks"], t["masks"][~t["is_thing"]]) and f_["image_size"] is t["image_size"]
     assert prepare_targets(insts, half=True)[0]["boxes"].dtype == torch.float16
+
+
+# --------------------------------------------------------------------------------------------- ONE TRAINING STEP against the reference's own
+class _OracleBackend:
+    """the three operator kernels of training/net.py as the oracle's CPU restatements (tests may use oracle/; the product's default backend is
+    the HIP library and has no host path) -- lets the CPU suite check the step's host logic and autograd graph without a GPU"""
+
+    @staticmethod
+    def msda(value, shapes, loc, aw):
+        from oracle import ops as oo
+        return oo.ms_deform_attn_core(value, shapes, loc, aw)
+
+    @staticmethod
+    def mask_einsum(e, f):
+        from oracle import ops as oo
+        return oo.mask_einsum(e, f)
+
+    @staticmethod
+    def dynamic_mask(mask_feats, ref_points, params, num_insts, stride, up):
+        from oracle import ops as oo
+        return oo.dynamic_mask(mask_feats, ref_points[None], params[None], num_insts, stride=stride, up=up)[0]
+
+
+def _train_step_case(dev):
+    import json
+    import sys
+    sys.path.insert(0, GOLD)
+    import _synth
+    from hipie_amd.config import HipieConfig, Precision
+    from hipie_amd.hipie_img import HIPIE_IMG
+    from hipie_amd.training.step import TrainStep
+    z = np.load(os.path.join(GOLD, "train_step_tiny.npz"))
+    meta = json.loads(bytes(z["cfg_json"]).decode())
+    model = HIPIE_IMG(HipieConfig.from_dict(meta["cfg"]), Precision.parity(), device=dev)
+    model.load_state_dict(_synth.synth_full_state_dict({k: tuple(v) for k, v in meta["manifest"].items()}), strict=True)
+    model.finalize()
+    sizes = [tuple(s) for s in meta["sizes"]]
+    imgs = _synth.synth_images(sizes, seed=73)
+    ids, mask, _ = _synth.synth_token_ids(2, meta["n_classes"], meta["max_len"], seed=74)
+    targets = []
+    for i in range(len(sizes)):
+        t = {k: torch.from_numpy(z["t%d_%s" % (i, k)]) for k in ("labels", "boxes", "positive_map", "is_thing", "masks", "image_size")}
+        t["masks"] = t["masks"].float()
+        targets.append(t)
+    step = TrainStep(model, backend=_OracleBackend if dev == "cpu" else None, draws=_synth.HashDraws(), dn_number=meta["dn_number"],
+                     num_points=meta["num_points"], md_num_points=meta["num_points"], fusion_dropout=0.0)
+    batch = [{"image": im, "input_ids": ids[i], "attention_mask": mask[i]} for i, im in enumerate(imgs)]
+    return z, meta, model, step, batch, targets
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+def test_train_step_losses_and_gradients_match_the_reference(dev):
+    """ONE TRAINING STEP on the e2e_tiny configuration against the REFERENCE's own (tests/golden/train_step_tiny.npz:
+    DDETRSegmUniDN.coco_forward + three DINO criterion calls + the MaskDINO criterion + backward, run on the CPU through
+    tests/golden/gen_train_step_golden.py): every entry of the weighted loss dictionary, the total, and the gradient of EVERY trainable
+    parameter (407 tensors, large ones on a strided subsample).  cpu: the step's host logic with the oracle's operator kernels plugged in;
+    cuda (-m gpu): the product as shipped -- hipie_msda_forward / _backward, the mask contraction and the dynamic mask head on their HIP
+    kernels (forward AND backward), the dense layers on the library with torch.autograd."""
+    import json
+    z, meta, model, step, batch, targets = _train_step_case(dev)
+    with torch.enable_grad():
+        losses = step.loss_dict(batch, targets)
+        total = sum(losses.values())
+        total.backward()
+    assert step.draws.calls == int(z["n_rand"])                               # the same random draws, in the same order
+    want = {k[5:]: float(z[k]) * float(z["weight/" + k[5:]]) for k in z.files if k.startswith("loss/")}
+    assert sorted(losses) == sorted(want)
+    tol = 2e-4 if dev == "cpu" else 2e-3
+    worst_l = max((abs(float(losses[k]) - want[k]) / max(1.0, abs(want[k])), k) for k in want)
+    assert worst_l[0] < tol, worst_l
+    assert abs(float(total) - float(z["total"])) < tol * float(z["total"])
+    steps = json.loads(bytes(z["grad_steps"]).decode())
+    params = dict(model.named_parameters(remove_duplicate=False))
+    errs = []
+    for k in z.files:
+        if not k.startswith("grad/"):
+            continue
+        name = k[5:]
+        p = params[name]
+        g = (torch.zeros_like(p) if p.grad is None else p.grad).reshape(-1).cpu()
+        if name in steps:
+            g = g[::steps[name]]
+        w = torch.from_numpy(z[k])
+        errs.append((float((g - w).abs().max() / (w.abs().max() + 1e-12)), name))
+    errs.sort(reverse=True)
+    # The convolutions of the CondInst mask head read the encoder memory at PADDED tokens too (a 3 x 3 window at the image border does not
+    # know about the padding mask).  Those tokens are ill-conditioned -- nothing attends to them, and the same product code gives values 5e-3
+    # apart there on the host and on the GPU while the valid tokens agree to 9e-7 (tools/train_step_diag2.py) -- so the gradients of these
+    # five convolutions carry that difference on any device other than the one the fixture was made on: measured 3.4e-2 at worst, with every
+    # operator swapped for plain torch alike (tools/train_step_diag.py).  Everything else is held to the tight bound.
+    border = [e for e in errs if e[1].startswith("detr.mask_head.")]
+    rest = [e for e in errs if not e[1].startswith("detr.mask_head.")]
+    print("train step on %s: total %.5f (reference %.5f), worst loss entry %.1e (%s), worst of %d parameter gradients %.1e (%s); mask-head convolutions %.1e (%s)"
+          % (dev, float(total), float(z["total"]), worst_l[0], worst_l[1], len(rest), rest[0][0], rest[0][1], border[0][0], border[0][1]))
+    assert len(errs) > 400 and rest[0][0] < (1e-3 if dev == "cpu" else 5e-3), rest[:5]
+    assert border[0][0] < (1e-3 if dev == "cpu" else 8e-2), border[:5]
+
+
+def test_train_step_has_no_host_path_by_default():
+    """the default backend is the HIP library: on host tensors the step fails loudly instead of computing something else"""
+    z, meta, model, step, batch, targets = _train_step_case("cpu")
+    from hipie_amd.training import net
+    step.be = net.HipBackend
+    with pytest.raises(RuntimeError), torch.enable_grad():
+        step.loss_dict(batch, targets)

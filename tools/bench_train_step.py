@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""forward + backward time of ONE TRAINING STEP (hipie_amd/training/step.py) at the reference's training batch: ViT-H, 1024 x 1024, 2 images per
+GPU (configs/training/vit_huge_32g.yaml:1 -- 32 GPUs x 2), the 80-class caption, 8 synthetic targets per image (6 things, 2 stuff), DN_NUMBER 100,
+12544 mask points, random-init weights.  Prints ms for the forward (loss dictionary), the backward, and the peak memory.
+    python tools/bench_train_step.py [batch] [steps]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+from hipie_amd.config import HipieConfig, Precision  # noqa: E402
+from hipie_amd.hipie_img import HIPIE_IMG  # noqa: E402
+from hipie_amd.training.step import TrainStep  # noqa: E402
+
+
+def targets_for(batch, n_things, n_stuff, size, L, dev, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(batch):
+        n = n_things + n_stuff
+        c = torch.rand(n, 2, generator=g) * 0.6 + 0.2
+        s = torch.rand(n, 2, generator=g) * 0.3 + 0.05
+        pm = torch.zeros(n, L, dtype=torch.bool)
+        for t in range(n):
+            a = int(torch.randint(1, L - 3, (1,), generator=g))
+            pm[t, a:a + 2] = True
+        thing = torch.ones(n, dtype=torch.bool)
+        thing[n_things:] = False
+        masks = torch.zeros(n, size, size)
+        for t in range(n):
+            x0, y0 = int((c[t, 0] - s[t, 0] / 2) * size), int((c[t, 1] - s[t, 1] / 2) * size)
+            masks[t, y0:y0 + max(4, int(s[t, 1] * size)), x0:x0 + max(4, int(s[t, 0] * size))] = 1
+        out.append({"labels": torch.randint(0, 80, (n,), generator=g).to(dev), "boxes": torch.cat((c, s), 1).to(dev), "positive_map": pm.to(dev),
+                    "is_thing": thing.to(dev), "masks": masks.to(dev), "image_size": torch.tensor([size, size, size, size], dtype=torch.float, device=dev)})
+    return out
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    dev = torch.device("cuda", 0)
+    cfg = HipieConfig.vit_huge()
+    torch.manual_seed(0)
+    model = HIPIE_IMG(cfg, Precision.parity(), device=dev)
+    bench.randomize_degenerate_inits(model)
+    model.finalize()
+    for p in model.text_encoder.parameters():
+        p.requires_grad_(False)
+    size, L = 1024, 194
+    batch = bench.synth_batch(cfg, B, size, 80, L, dev)
+    targets = targets_for(B, 6, 2, size, L, dev)
+    step = TrainStep(model)
+    n_par = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    fw, bw = [], []
+    for it in range(steps + 1):
+        model.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.enable_grad():
+            losses = step.loss_dict(batch, targets)
+            total = sum(losses.values())
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        total.backward()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if it:
+            fw.append(t1 - t0)
+            bw.append(t2 - t1)
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
+    print("training step, ViT-H 1024^2, %d images / GPU, %.0f M trainable parameters, %d loss entries: forward %.1f ms, backward %.1f ms, total %.1f ms "
+          "(%.2f images/s per GPU); loss %.3f, gradient norm %.3e, finite %s; peak memory %.1f GB"
+          % (B, n_par / 1e6, len(losses), 1e3 * sum(fw) / len(fw), 1e3 * sum(bw) / len(bw), 1e3 * (sum(fw) + sum(bw)) / len(fw),
+             B * len(fw) / (sum(fw) + sum(bw)), float(total), gn, bool(torch.isfinite(total)) and gn == gn, torch.cuda.max_memory_allocated() / 2 ** 30))
+
+
+if __name__ == "__main__":
+    main()

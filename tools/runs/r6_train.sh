@@ -1,0 +1,5 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_training.py -x -q -m gpu -k "train_step" -s 2>&1 | grep -E "train step|passed|failed|Error|error" | tail -8 > gpurun_out/r6_train_step_test.txt
+timeout 1200 python tools/bench_train_step.py 2 3 > gpurun_out/r6_train_step_bench.txt 2>&1
+tail -3 gpurun_out/r6_train_step_bench.txt
