@@ -20,4 +20,4 @@ from .criterion import DetCriterion, MaskCriterion                              
 from .weights import maskdino_loss_plan, weighted_merge                                        # noqa: F401
 from .targets import prepare_targets, split_things_stuff                                       # noqa: F401
 from .ddp import GradientBuckets                                                               # noqa: F401
-from .step import TrainStep                                                                    # noqa: F401
+from .step import TrainStep, build_optimizer, train_iteration                                  # noqa: F401

@@ -50,3 +50,52 @@ class DynamicMaskFunction(torch.autograd.Function):
 
 def dynamic_mask(mask_feats, ref_points, params, num_queries, stride=8, up=2):
     return DynamicMaskFunction.apply(mask_feats, ref_points, params, num_queries, stride, up)
+
+
+class SplitLinearFunction(torch.autograd.Function):
+    """F.linear(x, weight, bias) with forward AND backward on hipie_gemm's split-fp16 operands (three MFMA products, fp32 accumulation:
+    fp32-class results at ~2.7x the rate of the fp32 matrix pipe): the linears of the training step that carry its flops (ViT qkv / proj /
+    fc1 / fc2, the encoder FFNs).
+        y  = x . W^T + b            hipie_gemm(A = x fp32 rows, W as HL8)
+        dx = dy . W                 hipie_gemm(A = dy fp32 rows, W^T as HL8)
+        dW = dy^T . x               hipie_gemm(A = dy^T fp32 rows, (x^T) as HL8): the contraction runs over the M rows (padded to 32)
+        db = sum_m dy
+    The two transposed operands cost one pass each; the HL8 copies of W and W^T are cached per parameter version on `owner`."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, owner, key):
+        w_hl8, _, _ = ops.split_weight(owner, key, [weight], lambda: weight)
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        ctx.save_for_backward(x2, weight)
+        ctx.owner, ctx.key, ctx.lead, ctx.has_bias = owner, key, x.shape[:-1], bias is not None
+        y = ops.gemm(x2, w_hl8, None if bias is None else bias.detach().float().contiguous(), split=True, out_fmt=ops.F32, tag="train_fwd")
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, weight = ctx.saved_tensors
+        N, K = weight.shape
+        g2 = gy.reshape(-1, N).contiguous().float()
+        M = g2.shape[0]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wt_hl8, _, _ = ops.split_weight(ctx.owner, ctx.key + ".T", [weight], lambda: weight.t().contiguous())
+            gx = ops.gemm(g2, wt_hl8, None, split=True, out_fmt=ops.F32, tag="train_dx").view(*ctx.lead, K)
+        if ctx.needs_input_grad[1]:
+            Mp = -(-M // 32) * 32
+            gt = g2.new_zeros(N, Mp)
+            gt[:, :M] = g2.t()
+            xt = x2.new_zeros(K, Mp)
+            xt[:, :M] = x2.t()
+            gw = ops.gemm(gt, ops.to_hl8(xt), None, split=True, out_fmt=ops.F32, tag="train_dw")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g2.sum(0)
+        return gx, gw, gb, None, None
+
+
+def split_linear(x, weight, bias, owner, key):
+    """F.linear on the split GEMM with a backward (SplitLinearFunction); shapes it does not cover fall through to the library"""
+    K, N = weight.shape[1], weight.shape[0]
+    if x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and K % 32 == 0 and N % 32 == 0 and x.numel() // K >= 256:
+        return SplitLinearFunction.apply(x, weight, bias, owner, key)
+    return torch.nn.functional.linear(x, weight, bias)

@@ -21,6 +21,16 @@ import torch.nn.functional as F
 class HipBackend:
     """the operator kernels with a hand-written backward (libhipie_mi355.so); no host path"""
 
+    _owners = {}
+
+    @classmethod
+    def linear(cls, x, sd, p):
+        """the big linears (ViT qkv / proj / mlp, encoder FFN) on the split-fp16 GEMM, forward and backward (functions.SplitLinearFunction);
+        the HL8 weight copies are cached on one small owner object per parameter name"""
+        from .functions import split_linear
+        owner = cls._owners.setdefault(p, type("_W", (), {})())
+        return split_linear(x, sd[p + "weight"], sd.get(p + "bias"), owner, "w")
+
     @staticmethod
     def msda(value, shapes, loc, aw):
         """value (B,S,M,D), shapes [(H,W)], loc (B,Lq,M,L,P,2), aw (B,Lq,M,L,P) -> (B,Lq,M*D)"""
@@ -127,11 +137,17 @@ def get_rel_pos(q_size, k_size, rel_pos):
     return r[rel.long()]
 
 
-def vit_attention(x, sd, p, heads):
+def _blin(x, sd, p, be):
+    """a linear that carries flops: the backend's split-GEMM form when it has one (HipBackend.linear), else F.linear"""
+    f = getattr(be, "linear", None)
+    return f(x, sd, p) if f is not None else lin(x, sd, p)
+
+
+def vit_attention(x, sd, p, heads, be=None):
     """Attention.forward (vit.py:67-83) + add_decomposed_rel_pos (utils.py:96-125): the bias is computed from the UNSCALED q"""
     B, H, W, C = x.shape
     hd = C // heads
-    qkv = lin(x, sd, p + "qkv.").reshape(B, H * W, 3, heads, -1).permute(2, 0, 3, 1, 4)
+    qkv = _blin(x, sd, p + "qkv.", be).reshape(B, H * W, 3, heads, -1).permute(2, 0, 3, 1, 4)
     q, k, v = qkv.reshape(3, B * heads, H * W, -1).unbind(0)
     attn = (q * hd ** -0.5) @ k.transpose(-2, -1)
     Rh, Rw = get_rel_pos(H, H, sd[p + "rel_pos_h"]), get_rel_pos(W, W, sd[p + "rel_pos_w"])
@@ -141,10 +157,10 @@ def vit_attention(x, sd, p, heads):
     attn = (attn.view(B * heads, H, W, H, W) + rel_h[:, :, :, :, None] + rel_w[:, :, :, None, :]).view(B * heads, H * W, H * W)
     o = attn.softmax(dim=-1) @ v
     o = o.view(B, heads, H, W, -1).permute(0, 2, 3, 1, 4).reshape(B, H, W, -1)
-    return lin(o, sd, p + "proj.")
+    return _blin(o, sd, p + "proj.", be)
 
 
-def vit_backbone(x, sd, p, cfg):
+def vit_backbone(x, sd, p, cfg, be=None):
     """ViT.forward (vit.py:357-374) + the simple feature pyramid of D2ViT (fpn1 = ConvTranspose, identity, max pool)"""
     x = F.conv2d(x, sd[p + "patch_embed.proj.weight"], sd[p + "patch_embed.proj.bias"], stride=cfg["vit_patch"]).permute(0, 2, 3, 1)
     x = x + get_abs_pos(sd[p + "pos_embed"], (x.shape[1], x.shape[2]))
@@ -155,12 +171,12 @@ def vit_backbone(x, sd, p, cfg):
         if win > 0:
             H, W = h.shape[1], h.shape[2]
             h, pad_hw = window_partition(h, win)
-        h = vit_attention(h, sd, bp + "attn.", cfg["vit_heads"])
+        h = vit_attention(h, sd, bp + "attn.", cfg["vit_heads"], be)
         if win > 0:
             h = window_unpartition(h, win, pad_hw, (H, W))
         x = x + h
         h = ln(x, sd, bp + "norm2.", 1e-6)
-        x = x + lin(F.gelu(lin(h, sd, bp + "mlp.fc1.")), sd, bp + "mlp.fc2.")
+        x = x + _blin(F.gelu(_blin(h, sd, bp + "mlp.fc1.", be)), sd, bp + "mlp.fc2.", be)
     xp = x.permute(0, 3, 1, 2)
     return {"res3": F.conv_transpose2d(xp, sd[p + "fpn1.0.weight"], sd[p + "fpn1.0.bias"], stride=2), "res4": xp, "res5": F.max_pool2d(xp, 2, 2)}
 
@@ -253,7 +269,7 @@ def msda_module(query, ref_points, src, shapes, pad_mask, sd, p, be, heads=8, le
 def encoder_layer(src, pos, refs, shapes, pad_mask, sd, p, be):
     """DeformableTransformerEncoderLayer.forward (deformable_transformer_dino.py:384-394), dropout 0"""
     src = ln(src + msda_module(src + pos, refs, src, shapes, pad_mask, sd, p + "self_attn.", be), sd, p + "norm1.")
-    return ln(src + lin(F.relu(lin(src, sd, p + "linear1.")), sd, p + "linear2."), sd, p + "norm2.")
+    return ln(src + _blin(F.relu(_blin(src, sd, p + "linear1.", be)), sd, p + "linear2.", be), sd, p + "norm2.")
 
 
 def mha(x_qk, x_v, sd, p, attn_mask=None, heads=8):
@@ -466,13 +482,13 @@ def mask_head_small_conv(feats, sd, p):
     return F.relu(conv(F.relu(conv(x, sd, p + "lay1.", padding=1)), sd, p + "lay2.", padding=1))
 
 
-def backbone_and_projections(x, pad, sd, cfg):
+def backbone_and_projections(x, pad, sd, cfg, be=None):
     """HIPIE_IMG.detr.detr.backbone (MaskedBackbone + Joiner) and input_proj of coco_forward (ddetrs_dn.py:271-320): the three backbone
     levels + the stride-2 extra level whose mask is a resize of the LEVEL-0 mask"""
     p = "detr.detr."
     if cfg.get("backbone", "vit") != "vit":
         raise NotImplementedError("training step: ViT backbones only")
-    feats = vit_backbone(x, sd, p + "backbone.0.backbone.", cfg)
+    feats = vit_backbone(x, sd, p + "backbone.0.backbone.", cfg, be)
     names = ["res3", "res4", "res5"]
     fmasks = [down_mask(pad, feats[n].shape[-2:]) for n in names]
     poses = [pos_sine(m, cfg["hidden_dim"] // 2) for m in fmasks]

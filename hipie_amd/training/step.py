@@ -122,7 +122,7 @@ class TrainStep:
         sd, cfg, be, d = self.params(), self.cfg, self.be, self.draws
         dev = x.device
         gt_fg, gt_bg = split_things_stuff(targets)
-        feats, srcs, masks, poses = net.backbone_and_projections(x, pad, sd, cfg)
+        feats, srcs, masks, poses = net.backbone_and_projections(x, pad, sd, cfg, be)
         nbg, nq = cfg["num_bg_queries"], cfg["num_queries"]
         # ---- contrastive de-noising queries; the label side is the image's (un-fused) text embedding (DYNAMIC_LABEL_ENC) (:324-360)
         pool0 = net.agg_lang_feat(lang["hidden"], lang["masks"])
@@ -273,3 +273,33 @@ class TrainStep:
             else:
                 out[k] = v * (self.weight_dict.get(k, 1.0) * self.loss_weight if k in self.weight_dict else 1.0)
         return out
+
+
+def build_optimizer(model, base_lr=1e-4, backbone_multiplier=0.1, weight_decay=0.01):
+    """SOLVER of configs/training/*.yaml: AdamW, BASE_LR 1e-4, BACKBONE_MULTIPLIER 0.1, WEIGHT_DECAY 0.01 (the text encoder is frozen:
+    MODEL.FREEZE_TEXT_ENCODER)."""
+    bb, rest = [], []
+    for n, p in model.named_parameters():
+        if not p.requires_grad or n.startswith("text_encoder."):
+            continue
+        (bb if ".backbone.0." in n else rest).append(p)
+    return torch.optim.AdamW([{"params": rest, "lr": base_lr}, {"params": bb, "lr": base_lr * backbone_multiplier}], lr=base_lr, weight_decay=weight_decay)
+
+
+def train_iteration(step, optimizer, batched_inputs, targets, buckets=None, clip_norm=0.1, task="detection"):
+    """one iteration of the reference's trainer (detectron2 SimpleTrainer.run_step under create_ddp_model, SOLVER.CLIP_GRADIENTS full_model
+    0.1): forward -> summed loss -> backward (gradients all-reduced bucket by bucket while it runs: training/ddp.py) -> gradient clipping ->
+    optimizer step.  Returns the loss dictionary (detached scalars) and the gradient norm before clipping."""
+    optimizer.zero_grad(set_to_none=buckets is None)
+    if buckets is not None:
+        buckets.zero_grad()
+    with torch.enable_grad():
+        losses = step.loss_dict(batched_inputs, targets, task)
+        total = sum(losses.values())
+        total.backward()
+    if buckets is not None:
+        buckets.finish()
+    params = [p for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
+    norm = torch.nn.utils.clip_grad_norm_(params, clip_norm) if clip_norm else None
+    optimizer.step()
+    return {k: v.detach() for k, v in losses.items()}, norm

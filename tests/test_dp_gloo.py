@@ -251,3 +251,47 @@ def test_gradient_buckets_uneven_participation_and_wire_range():
     mid = torch.tensor(got[0][3][names.index("2.weight")])    # weight of the middle Linear: only rank 0 contributed
     assert torch.allclose(mid, m[2].weight.grad / 2, rtol=1e-6, atol=1e-7)
     assert got[0][4] and got[1][4] and got[0][5] and got[1][5] and 5e4 < got[0][6] < 7e4
+
+
+def _train_dp_worker(rank, world, port, q):
+    """two ranks, one image each of the training fixture: train_iteration with GradientBuckets; both ranks must end with the same weights"""
+    import sys
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_training as TT
+    from hipie_amd import parallel
+    from hipie_amd.training import GradientBuckets, build_optimizer, train_iteration
+    parallel.init_from_env(backend="gloo")
+    torch.set_num_threads(2)
+    z, meta, model, step, batch, targets = TT._train_step_case("cpu")
+    for p in model.text_encoder.parameters():
+        p.requires_grad_(False)
+    opt = build_optimizer(model)
+    gb = GradientBuckets([p for g in opt.param_groups for p in g["params"]], bucket_mb=8.0)
+    before = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+    losses, norm = train_iteration(step, opt, batch[rank:rank + 1], targets[rank:rank + 1], buckets=gb)
+    moved = sum(int(not torch.equal(before[n], p.detach())) for n, p in model.named_parameters() if n in before)
+    digest = float(sum(p.detach().double().sum() for n, p in model.named_parameters() if n in before))
+    parallel.barrier()
+    q.put((rank, float(sum(losses.values())), float(norm), moved, len(before), digest))
+
+
+def test_training_iteration_data_parallel_two_ranks():
+    """row f-4 + (e): the TRAINING iteration under data parallelism on two gloo ranks (what create_ddp_model + SimpleTrainer.run_step do for
+    the reference, detectron2/engine/defaults.py:60-79): each rank runs the step on its own image, the gradients are averaged bucket by
+    bucket during backward, clipped, AdamW steps -- the ranks see different losses, the SAME gradient norm, and end with identical weights."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_train_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in ps], key=lambda x: x[0])
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    (r0, l0, n0, m0, k0, d0), (r1, l1, n1, m1, k1, d1) = got
+    assert abs(l0 - l1) > 1e-3 * abs(l0)                      # different images, different losses
+    assert abs(n0 - n1) <= 1e-5 * n0 and n0 > 0               # one averaged gradient on both ranks
+    assert m0 == m1 and m0 > 0.95 * k0                        # (nearly) every trainable tensor moved
+    assert d0 == d1                                           # bit-identical weights after the step

@@ -356,3 +356,27 @@ def test_gemm_thin_k256_kernel(M, N, f32, monkeypatch):
     pad = torch.full((M + 3, N + 8), 7.0, device="cuda")                     # strided output rows, nothing written outside them
     ops.gemm(a, ops.hl8_pack(w), bias, split=True, out=pad[1:M + 1, :N])
     assert torch.equal(pad[1:M + 1, :N], thin) and bool((pad[0] == 7).all()) and bool((pad[M + 1:] == 7).all()) and bool((pad[:, N:] == 7).all())
+
+
+@gpu
+@pytest.mark.parametrize("M,N,K,bias", [(1000, 320, 256, True), (4096, 1280, 1280, True), (333, 64, 2048, False)])
+def test_split_linear_function_forward_and_backward(M, N, K, bias):
+    """row f-4 (3a): hipie_gemm as an autograd Function -- y = x W^T + b, dx = dy W, dW = dy^T x, db = sum dy, all three products on the
+    split-fp16 GEMM (training/functions.SplitLinearFunction) -- against torch.autograd of F.linear in double."""
+    from hipie_amd.training.functions import SplitLinearFunction
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g, dtype=torch.float64)
+    w = torch.randn(N, K, generator=g, dtype=torch.float64) * K ** -0.5
+    b = torch.randn(N, generator=g, dtype=torch.float64) if bias else None
+    go = torch.randn(M, N, generator=g, dtype=torch.float64)
+    with torch.enable_grad():
+        leaves = [t.clone().requires_grad_(True) for t in (x, w) + ((b,) if bias else ())]
+        want_y = torch.nn.functional.linear(leaves[0], leaves[1], leaves[2] if bias else None)
+        want = torch.autograd.grad(want_y, leaves, go)
+        dl = [t.float().cuda().requires_grad_(True) for t in (x, w) + ((b,) if bias else ())]
+        owner = type("_W", (), {})()
+        y = SplitLinearFunction.apply(dl[0], dl[1], dl[2] if bias else None, owner, "w")
+        got = torch.autograd.grad(y, dl, go.float().cuda())
+    assert rel_err(y.detach().cpu(), want_y.detach()) < 3e-6
+    for a, c, name in zip(got, want, ("dx", "dW", "db")):
+        assert a.shape == c.shape and rel_err(a.cpu(), c) < 5e-6, (name, rel_err(a.cpu(), c))

@@ -53,6 +53,29 @@ def main():
     batch = bench.synth_batch(cfg, B, size, 80, L, dev)
     targets = targets_for(B, 6, 2, size, L, dev)
     step = TrainStep(model)
+    from hipie_amd.training import net
+    if os.environ.get("LIB_LINEAR") == "1":                  # A/B: the big linears on the library instead of the split GEMM Function
+
+        class LibBackend(net.HipBackend):
+            linear = None
+        step.be = LibBackend
+    phases = {}
+    if os.environ.get("PHASES") == "1":                      # synchronised wall time of the forward's phases
+        def wrap(mod, name):
+            f = getattr(mod, name)
+
+            def g(*a, **k):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r = f(*a, **k)
+                torch.cuda.synchronize()
+                phases[name] = phases.get(name, 0.0) + time.perf_counter() - t0
+                return r
+            setattr(mod, name, g)
+        for nm in ("backbone_and_projections", "hipie_transformer", "maskdino_pixel_decoder", "maskdino_decoder"):
+            wrap(net, nm)
+        wrap(step, "maskdino_losses")
+        wrap(step.criterion, "forward")
     n_par = sum(p.numel() for p in model.parameters() if p.requires_grad)
     fw, bw = [], []
     for it in range(steps + 1):
@@ -70,6 +93,8 @@ def main():
         if it:
             fw.append(t1 - t0)
             bw.append(t2 - t1)
+    if phases:
+        print("forward phases (sum over %d steps, ms): %s" % (steps + 1, ", ".join("%s %.1f" % (k, v * 1e3) for k, v in phases.items())))
     gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
     print("training step, ViT-H 1024^2, %d images / GPU, %.0f M trainable parameters, %d loss entries: forward %.1f ms, backward %.1f ms, total %.1f ms "
           "(%.2f images/s per GPU); loss %.3f, gradient norm %.3e, finite %s; peak memory %.1f GB"
