@@ -434,7 +434,7 @@ static int launch_t2i(XTParams& p, hipStream_t st) {
 
 static int t2i_splits(int B, int H, int Nv) {
   const int ntiles = (Nv + 31) / 32;
-  static const int forced = getenv("HIPIE_XT_SP") ? atoi(getenv("HIPIE_XT_SP")) : 0;      // tuning experiments
+  static const int forced = study_env("HIPIE_XT_SP") ? atoi(study_env("HIPIE_XT_SP")) : 0;      // tuning experiments
   int sp = forced > 0 ? forced : (256 + B * H - 1) / (B * H);      // one workgroup per CU (measured at B*H = 64: SP 4 1.22 ms both directions, 8 1.26, 16 1.32)
   sp = std::max(1, std::min(sp, std::min(16, ntiles / 8)));   // at least 8 tiles per split
   return std::max(sp, 1);

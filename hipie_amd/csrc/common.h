@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/hipie_mi355.h"
@@ -61,5 +62,13 @@ __device__ __forceinline__ void hl_split(float x, f16_t& h, f16_t& l) {
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// A/B switches of the kernel studies (tile orders, wave counts, ablations: tools/bench_*.py).  The shipped library has ONE path per policy:
+// the switches exist only in a study build (make EXTRA=-DHIPIE_STUDY_KNOBS), where they are read from the environment once per process.
+#ifdef HIPIE_STUDY_KNOBS
+static inline const char* study_env(const char* name) { return getenv(name); }
+#else
+static inline const char* study_env(const char*) { return nullptr; }
+#endif
 
 }  // namespace hipie

@@ -590,12 +590,12 @@ static int flash_attn_impl(FAParams p, int hd, int dtype, void* stream) {
   dtype &= ~HIPIE_K_HL8_HI;
   p.defer = ((dtype & ~HIPIE_OUT_F32) == HIPIE_F16) ? 0.f : kDefer;      // fp16 = parity policy: classic running max
   // diagnostic switches: read from the environment once per process
-  { static const float defer_env = [] { const char* d = getenv("HIPIE_FA_DEFER"); return d ? (float)atof(d) : -1.f; }();
+  { static const float defer_env = [] { const char* d = study_env("HIPIE_FA_DEFER"); return d ? (float)atof(d) : -1.f; }();
     if (defer_env >= 0.f) p.defer = defer_env; }
-  { static int prio = -1; if (prio < 0) { const char* e = getenv("HIPIE_FA_PRIO"); prio = e ? atoi(e) : 1; } p.prio = prio; }   // +1.5 % (tools/bench_attn.py)
+  { static int prio = -1; if (prio < 0) { const char* e = study_env("HIPIE_FA_PRIO"); prio = e ? atoi(e) : 1; } p.prio = prio; }   // +1.5 % (tools/bench_attn.py)
   // 8 waves (256 queries) per workgroup halve the K/V traffic per query but keep all waves of a CU in lockstep
   bool wide = false;       // measured: two independent 4-wave workgroups per CU (1.09 ms) beat one 8-wave workgroup (1.16 ms)
-  static const int waves_env = [] { const char* e = getenv("HIPIE_FA_WAVES"); return (e && (e[0] == '4' || e[0] == '8')) ? e[0] - '0' : 0; }();
+  static const int waves_env = [] { const char* e = study_env("HIPIE_FA_WAVES"); return (e && (e[0] == '4' || e[0] == '8')) ? e[0] - '0' : 0; }();
   if (waves_env) wide = (waves_env == 8);
   hipStream_t st = (hipStream_t)stream;
   p.out_f32 = (dtype & HIPIE_OUT_F32) ? 1 : 0;
@@ -696,7 +696,7 @@ extern "C" int hipie_bi_xattn_ws(const void* q, const void* k, const void* vv, c
   a.o_sb = (long)Nv * E; a.o_st = E; a.o_sh = hd;
   a.key_mask = text_mask; a.scale = 1.f; a.clamp = clamp;
   // the flash kernel for both directions: diagnostics, and fp32 outputs (the specialised kernels write the operand type)
-  static const bool generic_env = getenv("HIPIE_XATTN_GENERIC") != nullptr;
+  static const bool generic_env = study_env("HIPIE_XATTN_GENERIC") != nullptr;
   const bool generic_only = generic_env || (dtype & HIPIE_OUT_F32) != 0;
   int rc = generic_only ? 1 : xattn_i2t_try(q, k, vl, text_mask, out_v, B, H, Nv, L, hd, E, clamp, dtype, (hipStream_t)stream);
   if (rc == 1) rc = flash_attn_impl(a, hd, dtype, stream);     // shapes the specialised kernel does not cover (L <= 64: one tile; L > 224)

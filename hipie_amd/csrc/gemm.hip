@@ -754,7 +754,7 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, con
   // streams through LDS in 32-feature chunks) where it is faster than the 256-column tiles -- N >= 384 (tools/bench_gemm_k256.py: -20 % at
   // N = 384, -7 % at 1024, -9 % at 2304; level at N = 256).  HIPIE_GEMM_K256=0: never, =1: every eligible shape (A/B timing)
   // (diagnostic switches are read from the environment ONCE per process, not per launch)
-  static const int k256_mode = [] { const char* e = getenv("HIPIE_GEMM_K256"); return e ? atoi(e) : 2; }();
+  static const int k256_mode = [] { const char* e = study_env("HIPIE_GEMM_K256"); return e ? atoi(e) : 2; }();
   const bool k256_on = k256_mode == 1 || (k256_mode == 2 && N >= 384);
   // the thin-K kernel addresses X rows with 32-bit offsets from the base of the whole matrix: M rows must stay below 4 GiB
   if (k256_on && split && K == 256 && out_fmt == HIPIE_F32 && act == 0 && resid == nullptr && out_row == nullptr && a_row == nullptr &&
@@ -762,18 +762,18 @@ static int gemm_impl(const void* A, int64_t lda, const void* W, int64_t ldw, con
     return launch_gemm_k256(A, p.lda_b, a_f32 ? 1 : 0, W, p.ldw_b, bias, (float*)out, ldo, M, N, st);
   const bool wide = (N % 320 == 0);
   // problems that fill less than 3/8 of the CUs with 256-row tiles go to the 64 x 128 tile kernel (HIPIE_GEMM_SMALL=0: never; A/B timing)
-  static const int small_on = [] { const char* e = getenv("HIPIE_GEMM_SMALL"); return e ? atoi(e) : 1; }();
-  static const long small_tiles = [] { const char* e = getenv("HIPIE_GEMM_SMALL_MAXTILES"); return e ? atol(e) : 96L; }();      // A/B runs: tools/bench_gemm_small.py big
+  static const int small_on = [] { const char* e = study_env("HIPIE_GEMM_SMALL"); return e ? atoi(e) : 1; }();
+  static const long small_tiles = [] { const char* e = study_env("HIPIE_GEMM_SMALL_MAXTILES"); return e ? atol(e) : 96L; }();      // A/B runs: tools/bench_gemm_small.py big
   const bool small_ok = small_on && (long)((M + 255) / 256) * ((N + (wide ? 319 : 255)) / (wide ? 320 : 256)) < small_tiles;
 #ifdef HIPIE_GEMM_VARIANTS
-  { const char* e = getenv("HIPIE_GEMM_VARIANT"); const int v = e ? atoi(e) : 0;
+  { const char* e = study_env("HIPIE_GEMM_VARIANT"); const int v = e ? atoi(e) : 0;
     if (split && wide && v == 1) return launch_gemm<320, true, 1>(p, st);
     if (split && wide && v == 3) return launch_gemm<320, true, 3>(p, st); }
 #endif
   p.prio_mode = 0;
   p.variant = 0;
 #ifdef HIPIE_GEMM_VARIANTS
-  { const char* e = getenv("HIPIE_GEMM_VARIANT"); p.variant = e ? atoi(e) : 0; }
+  { const char* e = study_env("HIPIE_GEMM_VARIANT"); p.variant = e ? atoi(e) : 0; }
   p.prio_mode = gemm2_prio();
   if (split && gemm2_mode() == 4) {
     const bool w160 = (N % 160 == 0);

@@ -445,7 +445,7 @@ static int launch_md(const float* e, const float* f, const float* rb, void* out,
   const long total = (long)B * npass * nk4 * ME_QB * 32 * 4;
   hipLaunchKernelGGL(me_split_embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, e, ws, Q, C, npass, nk4, total);
   const int tiles = (P + MX_TP - 1) / MX_TP;
-  static const int xenv = [] { const char* v = getenv("HIPIE_ME_XMAP"); return v ? atoi(v) : 1; }();    // 0: batch-major ids (A/B timing)
+  static const int xenv = [] { const char* v = study_env("HIPIE_ME_XMAP"); return v ? atoi(v) : 1; }();    // 0: batch-major ids (A/B timing)
   hipLaunchKernelGGL((mask_einsum_dma_kernel<PREC, OutT>), dim3((unsigned)((long)B * tiles)), dim3(MX_WAVES * 64), 0, st, (const char*)ws, f, rb,
                      (OutT*)out, Q, C, P, npass, nk4, tiles, (B % 8 == 0 && xenv) ? 1 : 0);
   return check_launch("mask_einsum_ws");
@@ -629,7 +629,7 @@ template <typename T, typename OutT>
 static int launch_me16(const void* eh, const void* el, const void* f, const float* rb, void* out, int B, int Q, int C, int P, hipStream_t st) {
   dim3 grid((P + 255) / 256, B);
 #ifdef HIPIE_VA_ABLATIONS
-  { const char* e = getenv("HIPIE_ME_ABL"); const int a = e ? atoi(e) : 0;
+  { const char* e = study_env("HIPIE_ME_ABL"); const int a = e ? atoi(e) : 0;
     if (a == 1) { hipLaunchKernelGGL((mask_einsum16_kernel<T, OutT, false, 1>), grid, dim3(512), 0, st, (const T*)eh, (const T*)el, (const T*)f, rb, (OutT*)out, Q, C, P); return check_launch("me16"); }
     if (a == 2) { hipLaunchKernelGGL((mask_einsum16_kernel<T, OutT, false, 2>), grid, dim3(512), 0, st, (const T*)eh, (const T*)el, (const T*)f, rb, (OutT*)out, Q, C, P); return check_launch("me16"); } }
 #endif

@@ -356,7 +356,7 @@ static int launch_msda(const void* value, const int64_t* shapes, const int64_t* 
   if (D == 32) {
     // group -> workgroup map (see the kernel): tiles of the pyramid when the queries are its pixels, else runs of 32 queries of
     // one head; HIPIE_MSDA_MAP=0 restores the heads-fastest order (A/B timing: tools/bench_msda.py)
-    static const int map_env = [] { const char* me = getenv("HIPIE_MSDA_MAP"); return me ? atoi(me) : -1; }();      // once per process
+    static const int map_env = [] { const char* me = study_env("HIPIE_MSDA_MAP"); return me ? atoi(me) : -1; }();      // once per process
     const int map = map_env >= 0 ? (map_env == 2 && Lq != S ? 1 : map_env) : (Lq == S ? 2 : 1);
     const long blocks = map == 0 ? (groups + 31) / 32 : (((long)B * Lq + 31) / 32) * M;
     const size_t lds = (size_t)32 * (L * P * 8 + 4) * sizeof(float);

@@ -887,7 +887,7 @@ static int launch_sp(VAParams& p, hipStream_t st) {
   p.nqt = (p.N + WAVES * 32 - 1) / (WAVES * 32);
   p.swz = ((p.B * p.H) % 8 == 0) ? 1 : 0;
   const unsigned grid = (unsigned)(p.nqt * p.B * p.H);
-  { static int prio = -1; if (prio < 0) { const char* e = getenv("HIPIE_VA_PRIO"); prio = e ? atoi(e) : 1; } p.prio = prio; }
+  { static int prio = -1; if (prio < 0) { const char* e = study_env("HIPIE_VA_PRIO"); prio = e ? atoi(e) : 1; } p.prio = prio; }
   auto kern = vit_attn_sp_kernel<T, HD, NB, FAST, ABL>;
   if (lds > 64 * 1024) {
     static size_t lds_set[64] = {0};
@@ -908,10 +908,10 @@ static int dispatch_va(VAParams& p, hipStream_t st) {
   if (p.kw <= 32) return launch_va<T, HD, 1, 4, FAST, 1, 0, 0>(p, st);
   if (p.kw > 32 && p.kw <= 64 && p.kh <= 96 && p.N >= 1024) {
     static int mode = -1;       // 0: plain kernel, 2: software-pipelined 8-wave kernel (default)
-    if (mode < 0) { const char* e = getenv("HIPIE_VA_MODE"); mode = e ? atoi(e) : 2; }
+    if (mode < 0) { const char* e = study_env("HIPIE_VA_MODE"); mode = e ? atoi(e) : 2; }
 #ifdef HIPIE_VA_ABLATIONS
     if (mode == 2 && HD == 80 && FAST) {
-      const char* e = getenv("HIPIE_VA_ABL");
+      const char* e = study_env("HIPIE_VA_ABL");
       if (e && atoi(e) == 8) return launch_sp<T, HD, 2, FAST, 8>(p, st);
       if (e && atoi(e) == 9) return launch_sp<T, HD, 2, FAST, 9>(p, st);
     }
@@ -920,7 +920,7 @@ static int dispatch_va(VAParams& p, hipStream_t st) {
   }
 #ifdef HIPIE_VA_ABLATIONS
   if (p.kw == 64 && HD == 80 && FAST && sizeof(T) == 2) {
-    const char* e = getenv("HIPIE_VA_ABL");
+    const char* e = study_env("HIPIE_VA_ABL");
     switch (e ? atoi(e) : 0) {
       case 1: return launch_va<T, HD, 2, 4, FAST, 1, 0, 1>(p, st);
       case 2: return launch_va<T, HD, 2, 4, FAST, 1, 0, 2>(p, st);

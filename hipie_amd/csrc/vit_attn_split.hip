@@ -703,7 +703,7 @@ extern "C" int hipie_vit_attn_split(const void* qkv, const void* tab_h, const vo
   {
     // grids wider than 96 tokens (eval yamls: MAX_SIZE_TEST 2048 -> up to 64 x 128): walk the grid column by column
     static int force_tr = -1;
-    if (force_tr < 0) { const char* e = getenv("HIPIE_VA_TRANSPOSE"); force_tr = e ? atoi(e) : 0; }      // 1: always (tests)
+    if (force_tr < 0) { const char* e = study_env("HIPIE_VA_TRANSPOSE"); force_tr = e ? atoi(e) : 0; }      // 1: always (tests)
     if ((gw > 96 && gh <= 96) || (force_tr == 1 && gw != 14)) {
       p.tr = 1; p.kh = gw; p.kw = gh; p.tab_h = (const f16_t*)tab_w; p.tab_w = (const f16_t*)tab_h;
       p.krs = (long)gw * p.st; p.kts = p.st;

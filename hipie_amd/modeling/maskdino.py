@@ -252,7 +252,7 @@ class MaskDINODecoder(nn.Module):
         # einsum #1 (:428): interm_outputs
         interm_cls, interm_mask = self.forward_prediction_heads(tgt, mask_features, pred_mask=self.initial_pred_masks)
         ref = ref_un.sigmoid()
-        sdt = torch.float32 if os.environ.get("HIPIE_DEC_F32", "1") == "1" else self.decoder.layers[0].linear1.out_dtype
+        sdt = torch.float32                                  # query stream dtype: fp32 in every policy
         wdt = self.decoder.ref_point_head.layers[0].weight.dtype
         refs, out, hs = [ref], tgt.to(sdt), []
         layers = self.decoder.layers

@@ -675,15 +675,10 @@ def ref_point_query(ref_point_head, sine):
 
 
 # The two small per-layer heads as ONE launch each (hipie_ref_point_mlp, hipie_box_head; exact fp32 FMAs): 75 launches fewer per step.
-# fast policy: slower than the fp16 library GEMMs it replaces (A/B on one box: 100.0 vs 99.2 ms per step) -> opt-in (HIPIE_FUSED_HEADS=1).
+# fast policy: slower than the fp16 library GEMMs it replaces (A/B on one box: 100.0 vs 99.2 ms per step) -> not used there.
 # split policy: the same speed as the 5 small split GEMMs + 2 glue launches per layer (224.5 vs 224.9 ms, same box, same 4.2e-4 parity
-# error) -> on by default there (HIPIE_FUSED_HEADS=0 turns it off).
-_FUSED_HEADS_ENV = os.environ.get("HIPIE_FUSED_HEADS")
-
-
+# error) -> used there.
 def _fused_heads(module):
-    if _FUSED_HEADS_ENV is not None:
-        return _FUSED_HEADS_ENV == "1"
     return bool(getattr(module, "split", False))
 
 
@@ -728,7 +723,7 @@ class DeformableTransformerDecoder(nn.Module):
         self.class_embed = None
 
     def forward(self, tgt, reference_points, src, spatial_shapes, level_start_index, valid_ratios, src_padding_mask=None):
-        sdt = torch.float32 if os.environ.get("HIPIE_DEC_F32", "1") == "1" else self.layers[0].linear1.out_dtype   # query stream dtype
+        sdt = torch.float32                                  # query stream dtype: fp32 in every policy (910 queries: the traffic is negligible)
         output, inter, inter_refs = tgt.to(sdt), [], []
         vr2 = torch.cat([valid_ratios, valid_ratios], -1)[:, None]
         wdt = self.ref_point_head.layers[0].weight.dtype

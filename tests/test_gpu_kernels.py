@@ -455,18 +455,14 @@ def test_bi_xattn(name, dt, tol):
 
 @pytest.mark.parametrize("hd,nq,nk", [(80, 200, 333), (64, 1500, 640), (32, 77, 64), (256, 130, 100)])
 def test_flash_attn_generic(hd, nq, nk):
-    """hipie_flash_attn without bias: ragged tails, every head dim, strided q/k/v views, both workgroup shapes."""
+    """hipie_flash_attn without bias: ragged tails, every head dim, strided q/k/v views against dense copies."""
     import os
     from hipie_amd import ops
     gen = torch.Generator().manual_seed(9)
     qkv = torch.randn(2, max(nq, nk), 3, 4, hd, generator=gen).half().to(DEV)
     q, k, v = qkv[:, :nq, 0], qkv[:, :nk, 1], qkv[:, :nk, 2]            # strided views, head_dim contiguous
     a = ops.flash_attn(q, k, v, hd ** -0.5)
-    os.environ["HIPIE_FA_WAVES"] = "4"
-    try:
-        b = ops.flash_attn(q, k, v, hd ** -0.5)
-    finally:
-        del os.environ["HIPIE_FA_WAVES"]
+    b = ops.flash_attn(q.contiguous(), k.contiguous(), v.contiguous(), hd ** -0.5)      # the same numbers from dense operands
     assert rel_err(a.float().cpu(), b.float().cpu()) < 1e-6
     ref = torch.nn.functional.scaled_dot_product_attention(q.float().cpu().transpose(1, 2), k.float().cpu().transpose(1, 2),
                                                            v.float().cpu().transpose(1, 2)).transpose(1, 2).reshape(2, nq, 4 * hd)
