@@ -343,7 +343,10 @@ def parity_error(policy, device, full_size=True):
                        "reference's own initialisation, tests/golden/refinit_stats.json; e2e_deep = the shipped depths on a narrow ViT; "
                        "e2e_full_c80 = the gate weights on the TIMED inputs: image 0 of this script's batch, the 80-class caption of 194 tokens, "
                        "and the grounding call)"
-                       % ",".join(fixtures)}
+                       % ",".join(fixtures),
+            "batch_note": "every fixture is a 1- or 2-image batch (the reference runs in minutes per image on the CPU); the timed batch is 8: the "
+                          "bridge is tests/test_gpu_e2e.py::test_e2e_batch_items_are_independent (an image's rows do not depend on its batch "
+                          "neighbours) and ::test_two_stream_step_repeats_bit_for_bit_at_full_size (the timed bs-8 step repeats within 7e-6)"}
 
 
 def main():
@@ -690,7 +693,7 @@ def main():
     if rank == 0:
         std = args.model == "vit_huge" and args.batch == 8 and args.size == 1024
         pmc = {}
-        for pmc_file in ("r03_pmc_kernels.json", "r04_pmc_kernels.json", "r05_pmc_kernels.json"):      # the newest round's rows win
+        for pmc_file in ("r03_pmc_kernels.json", "r04_pmc_kernels.json", "r05_pmc_kernels.json", "r06_pmc_kernels.json"):      # the newest round's rows win
             pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_file)
             if os.path.exists(pmc_path) and std:
                 pmc.update(json.load(open(pmc_path)))
@@ -729,7 +732,7 @@ def main():
                     "per_shape_ms": {t: round(gemm[t][0], 4) for t in shapes if gemm.get(t, (None, 0))[0]},
                     "traffic": pmc.get("gemm_qkv_split", {}).get("traffic_bytes_per_launch"),
                     "traffic_note": "bytes per launch of the qkv shape (0.81 ms; 691 MB algorithmic), rocprofv3 PMC FETCH_SIZE (x2, guide correction) + "
-                                    "WRITE_SIZE, separate passes: profiles/r05_pmc_kernels.json (r04_pmc_kernels.json when absent)"}
+                                    "WRITE_SIZE, separate passes: profiles/r06_pmc_kernels.json (the newest round present wins)"}
         else:
             roof = roof_attn
         line = {

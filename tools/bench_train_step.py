@@ -93,6 +93,15 @@ def main():
         if it:
             fw.append(t1 - t0)
             bw.append(t2 - t1)
+    if os.environ.get("TORCH_PROF") == "1":                  # top kernels of one steady-state step
+        from torch.profiler import ProfilerActivity, profile
+        model.zero_grad(set_to_none=True)
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            with torch.enable_grad():
+                total = sum(step.loss_dict(batch, targets).values())
+            total.backward()
+            torch.cuda.synchronize()
+        print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=28, max_name_column_width=90))
     if phases:
         print("forward phases (sum over %d steps, ms): %s" % (steps + 1, ", ".join("%s %.1f" % (k, v * 1e3) for k, v in phases.items())))
     gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
