@@ -307,6 +307,30 @@ class MaskCLIP(nn.Module):
         return torch.cat([torch.zeros(N, Q, 1, dtype=torch.bool, device=mask.device), (patch_mask < 0.5).reshape(N, Q, -1)], 2)
 
     @torch.no_grad()
+    def blocked_patches_upsampled(self, mask, scale, crop_hw):
+        """blocked_patches(F.interpolate(mask, scale_factor=scale, bilinear)[..., :crop_h, :crop_w]) without the up-sampled tensor (5 GB per
+        image at 1210 masks of 256 x 256 and scale 4): up-sampling, cropping and the resize to the CLIP input are LINEAR and separable, so
+        the (336 x h) row operator and the (336 x w) column operator are built by pushing identity matrices through the same three torch
+        operations, and the composite is two small matrix products per mask.  Same arithmetic up to fp32 summation order.
+        mask (N,Q,h,w) logits at 1 / scale resolution; crop_hw = the image size the up-sampled logits are cropped to (hipie_img.py:731-747)."""
+        N, Q, h, w = mask.shape
+        S = self.image_size[0]
+        key = (h, w, int(scale), int(crop_hw[0]), int(crop_hw[1]), str(mask.device))
+        ops_ = self.__dict__.setdefault("_resize_ops", {})
+        if key not in ops_:
+            def operator(n, crop):
+                eye = torch.eye(n, device=mask.device).view(1, 1, n, n)
+                up = F.interpolate(eye, size=(n * int(scale), n), mode="bilinear", align_corners=False)[:, :, :crop]
+                return F.interpolate(up, size=(S, n), mode="bilinear", align_corners=False)[0, 0]              # (S, n)
+            if len(ops_) > 8:
+                ops_.clear()
+            ops_[key] = (operator(h, int(crop_hw[0])), operator(w, int(crop_hw[1])))
+        A_h, A_w = ops_[key]
+        x = torch.matmul(A_h, torch.matmul(mask.float(), A_w.t()))                                            # (N, Q, S, S)
+        patch_mask = F.max_pool2d(x.sigmoid(), kernel_size=self.cfg["patch"], stride=self.cfg["patch"])
+        return torch.cat([torch.zeros(N, Q, 1, dtype=torch.bool, device=mask.device), (patch_mask < 0.5).reshape(N, Q, -1)], 2)
+
+    @torch.no_grad()
     def mask_rows(self, state, blocked):
         """state of N images (encode_images), blocked (N, Q, T) -> mask embeddings (N, Q, embed_dim)."""
         vis = self.clip.visual
@@ -380,13 +404,15 @@ def get_clip_logits(clip, image01, mask_logits, test_label_names, train_label_na
     return _fuse(lg, pred_open_prob, ov, alpha, beta, agg_mode)
 
 
-def get_clip_logits_batched(clip, state, mask_logits, test_label_names, train_label_names, pred_open_prob, alpha, beta, agg_mode="MUL"):
+def get_clip_logits_batched(clip, state, mask_logits, test_label_names, train_label_names, pred_open_prob, alpha, beta, agg_mode="MUL", blocked=None):
     """the same for the N images of a batched state in ONE pass of the mask tokens: mask_logits / pred_open_prob are lists of (Q_i,h_i,w_i) /
     (Q_i,C) tensors (ragged Q_i: rows are padded with mask tokens that see the class token only and dropped again) -> list of (Q_i,C).
-    Every row's result is what get_clip_logits gives for its image alone (rows of a GEMM do not interact; the softmax is per row)."""
+    Every row's result is what get_clip_logits gives for its image alone (rows of a GEMM do not interact; the softmax is per row).
+    blocked: the per-image patch-visibility maps when the caller has them already (blocked_patches_upsampled)."""
     dev = pred_open_prob[0].device
     labels, ov, text_embed = _vocab(clip, test_label_names, train_label_names, dev)
-    blocked = [clip.blocked_patches(m[None])[0] for m in mask_logits]          # per image: the (Q_i, 336, 336) resize is the big transient
+    if blocked is None:                                                        # per image: the (Q_i, 336, 336) resize is the big transient
+        blocked = [clip.blocked_patches(m[None])[0] for m in mask_logits]
     qs = [b.shape[0] for b in blocked]
     Qm = max(qs)
     pad = torch.ones(len(qs), Qm, blocked[0].shape[-1], dtype=torch.bool, device=dev)

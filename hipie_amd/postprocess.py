@@ -191,7 +191,7 @@ def _clip_states(model, batched_inputs, out):
     return st
 
 
-def _clip_logits_all(model, batched_inputs, out, mask_logits, pred_open_prob):
+def _clip_logits_all(model, batched_inputs, out, mask_logits, pred_open_prob, blocked=None):
     """HIPIE_IMG.get_clip_logits (hipie_img.py:811-868) for every image of the call: mask_logits / pred_open_prob = per-image lists of
     (Q_i, h, w) / (Q_i, C) -> list of fused (Q_i, C).  The test vocabulary is the inputs' `open_seg_labels` ([{"name": "a,b,..."}] per
     class, data/coco_dataset_mapper_uni.py; one vocabulary per call, as one task per call: hipie_img.py:285), the training vocabulary
@@ -201,7 +201,8 @@ def _clip_logits_all(model, batched_inputs, out, mask_logits, pred_open_prob):
     cfg = model.cfg
     kind, st = _clip_states(model, batched_inputs, out)
     if kind == "batched" and all(x.get("open_seg_labels") == batched_inputs[0].get("open_seg_labels") for x in batched_inputs):
-        return get_clip_logits_batched(model.clip, st, mask_logits, test, train, pred_open_prob, cfg.clip_alpha, cfg.clip_beta, cfg.clip_agg_mode)
+        return get_clip_logits_batched(model.clip, st, mask_logits, test, train, pred_open_prob, cfg.clip_alpha, cfg.clip_beta, cfg.clip_agg_mode,
+                                       blocked=blocked)
     res = []
     for i, x in enumerate(batched_inputs):
         test_i = [t["name"].split(",") for t in x["open_seg_labels"]]
@@ -377,12 +378,17 @@ def _inference(model, out, batched_inputs, do_postprocess=True, with_masks=True,
             masks_list.append(masks_all)
         if getattr(model, "enable_clip", False):
             # hipie_img.py:731-747: the masks the reference hands to CLIP are the x4 up-sampled logits cropped to the image
-            ups = []
-            for i in range(B):
-                up = F.interpolate(masks_list[i][:, None].float(), scale_factor=float(s), mode="bilinear", align_corners=False)
-                ups.append(up[:, 0, :image_sizes[i][0], :image_sizes[i][1]])
-            cls_list = [c.softmax(-1) for c in _clip_logits_all(model, batched_inputs, out, ups, cls_list)]
-            del ups
+            if _clip_states(model, batched_inputs, out)[0] == "batched":
+                # the x4 up-sampling, the crop and MaskCLIP's resize to its input size as ONE pair of small operators per image geometry
+                blocked = [model.clip.blocked_patches_upsampled(masks_list[i][None], s, image_sizes[i])[0] for i in range(B)]
+                cls_list = [c.softmax(-1) for c in _clip_logits_all(model, batched_inputs, out, masks_list, cls_list, blocked=blocked)]
+            else:
+                ups = []
+                for i in range(B):
+                    up = F.interpolate(masks_list[i][:, None].float(), scale_factor=float(s), mode="bilinear", align_corners=False)
+                    ups.append(up[:, 0, :image_sizes[i][0], :image_sizes[i][1]])
+                cls_list = [c.softmax(-1) for c in _clip_logits_all(model, batched_inputs, out, ups, cls_list)]
+                del ups
         for i in range(B):
             sem, tab = _sem_pan(cls_list[i], masks_list[i], s, image_sizes[i], out_sizes[i], thing_vector(is_thing[i], C, dev), cfg,
                                 0 if getattr(getattr(model, "precision", None), "einsum", 0) in (0, 1, 4) else 1)

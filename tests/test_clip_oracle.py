@@ -96,3 +96,22 @@ def test_product_maskclip_host_path_matches_reference():
     for mode in ("MUL", "ADD"):
         fused = get_clip_logits(m, g["image"][0], g["mask"][0], test, train, g["pred_open_prob"], 0.4, 0.45, mode)
         assert rel_err(fused, g["fused_" + mode]) < TOL
+
+
+def test_visibility_maps_without_the_upsampled_tensor():
+    """MaskCLIP.blocked_patches_upsampled (the x4 up-sampling of the semantic / panoptic mask logits, the crop to the image and MaskCLIP's
+    resize to its input size as one pair of small operators: hipie_img.py:731-747 + clip.py:299-321) gives the patch-visibility bits of the
+    three-step route, on blob-shaped masks with ~45 % of the patches visible, for a crop that cuts the up-sampled map and one that does not."""
+    import torch.nn.functional as F
+    from hipie_amd.open_vocab import MaskCLIP
+    cfg = dict(width=128, layers=2, heads=4, patch=14, image_size=112, embed_dim=64, text_width=64, text_layers=2, text_heads=4, context=16,
+               vocab=100, quick_gelu=True)
+    torch.manual_seed(0)
+    m = MaskCLIP("tiny", cfg=cfg, tokenize=lambda t: None)
+    mask = F.interpolate(torch.randn(2, 300, 6, 5) * 3 - 1.5, size=(50, 44), mode="bilinear", align_corners=False)
+    for crop in ((200, 176), (187, 150)):
+        up = F.interpolate(mask, scale_factor=4.0, mode="bilinear", align_corners=False)[:, :, :crop[0], :crop[1]]
+        want = m.blocked_patches(up)
+        got = m.blocked_patches_upsampled(mask, 4, crop)
+        assert 0.3 < float((~want).float().mean()) < 0.7
+        assert int((want != got).sum()) <= 2, int((want != got).sum())          # a logit within fp32 rounding of 0 may fall on the other side

@@ -621,3 +621,29 @@ def test_two_stream_step_repeats_bit_for_bit_at_full_size():
     for k in KEYS:
         assert dev_by_mode[True][k] < 5e-5, (k, dev_by_mode[True][k])
         assert dev_by_mode[True][k] <= 10 * dev_by_mode[False][k] + 1e-5, (k, dev_by_mode)
+
+
+def test_two_stream_forward_replays_in_a_hip_graph():
+    """the forward with its side stream (the MaskDINO head beside the deformable transformer) captured ONCE into a hipGraph -- the fork / join
+    of the branch become graph dependencies -- and replayed: the replays equal the eager forward (bench.py --graph does this at full size)."""
+    from hipie_amd.config import Precision
+    g, model = build(Precision.split3())
+    model.pin_topk(g["detection_topk_fg"], g["detection_topk_md"])
+    batch = inputs(g, "detection")
+    for b in batch:                                         # token ids on the device: nothing crosses the PCIe inside the capture
+        b["input_ids"], b["attention_mask"] = b["input_ids"].cuda(), b["attention_mask"].cuda()
+    eager = {k: v.float().clone() for k, v in model.forward_raw(batch).items() if torch.is_tensor(v)}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        model.forward_raw(batch)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = model.forward_raw(batch)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    for k in KEYS:
+        assert rel_err(out[k].float().cpu(), eager[k].cpu()) < 2e-5, (k, rel_err(out[k].float().cpu(), eager[k].cpu()))
