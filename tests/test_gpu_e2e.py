@@ -628,10 +628,10 @@ def test_two_stream_forward_replays_in_a_hip_graph():
     of the branch become graph dependencies -- and replayed: the replays equal the eager forward (bench.py --graph does this at full size)."""
     from hipie_amd.config import Precision
     g, model = build(Precision.split3())
-    model.pin_topk(g["detection_topk_fg"], g["detection_topk_md"])
+    model.pin_topk(g["detection_topk_fg"].cuda(), g["detection_topk_md"].cuda())
     batch = inputs(g, "detection")
-    for b in batch:                                         # token ids on the device: nothing crosses the PCIe inside the capture
-        b["input_ids"], b["attention_mask"] = b["input_ids"].cuda(), b["attention_mask"].cuda()
+    for b in batch:                                         # images and token ids on the device: nothing crosses the PCIe inside the capture
+        b["image"], b["input_ids"], b["attention_mask"] = b["image"].cuda(), b["input_ids"].cuda(), b["attention_mask"].cuda()
     eager = {k: v.float().clone() for k, v in model.forward_raw(batch).items() if torch.is_tensor(v)}
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
