@@ -659,3 +659,22 @@ def test_training_operator_functions_have_no_host_path():
     import inspect
     src = inspect.getsource(functions)
     assert "oracle" not in src.replace("oracle's", "")
+
+
+def test_bench_pins_each_rank_to_its_own_cores():
+    """bench.pin_host_threads (round 6, --gpus N readiness): rank r of N gets the r-th slice of the usable cores and sizes torch's intra-op
+    pool to it; one rank keeps everything.  Run in a child process (it changes the affinity)."""
+    import subprocess
+    import sys
+    code = ("import os, sys, json; sys.path.insert(0, %r); import bench, torch; "
+            "all_ = sorted(os.sched_getaffinity(0)); r = bench.pin_host_threads(1, 2); mine = sorted(os.sched_getaffinity(0)); "
+            "print(json.dumps([all_, mine, list(r), torch.get_num_threads()]))" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-400:]
+    import json
+    all_, mine, r, nthreads = json.loads(out.stdout.strip().splitlines()[-1])
+    if len(all_) >= 2:
+        per = len(all_) // 2
+        assert mine == all_[per:2 * per] and r[0] == per and nthreads == max(1, min(per, 8))
+    else:
+        assert mine == all_
