@@ -55,6 +55,8 @@ SIGNATURES = {
     "hipie_gemm_gather": [c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p] + [c_i] * 6 + [c_f, c_f, c_p],
     "hipie_vit_attn_split": [c_p, c_p, c_p, c_p] + [c_i] * 5 + [c_p],
     "hipie_msda_backward": [c_p] * 9 + [c_i] * 8 + [c_p],
+    "hipie_msda_backward_ws": [c_p] * 9 + [c_i] * 8 + [c_p, c_l, c_p],
+    "hipie_msda_backward_workspace": [c_i] * 6,
     "hipie_gemm_batched": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l] + [c_i] * 6 + [c_f, c_p],
     "hipie_gemm_batched_softmax": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l] + [c_i] * 5 + [c_p, c_i, c_f, c_f, c_p],
     "hipie_softmax_hl8": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_f, c_p],
@@ -98,7 +100,7 @@ def load():
             raise HipieLibraryError("%s does not export %s (stale build?)" % (LIB_PATH, name))
         fn.argtypes = argtypes
         fn.restype = (ctypes.c_char_p if name == "hipie_last_error" else
-                      ctypes.c_int64 if name in ("hipie_bi_xattn_workspace", "hipie_mask_einsum_workspace") else ctypes.c_int)
+                      ctypes.c_int64 if name in ("hipie_bi_xattn_workspace", "hipie_mask_einsum_workspace", "hipie_msda_backward_workspace") else ctypes.c_int)
     _lib = lib
     return lib
 

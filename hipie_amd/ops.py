@@ -136,7 +136,8 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
 
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step=64):
     """MSDA.ms_deform_attn_backward (ops/src/vision.cpp:13-16; ms_deform_attn_cuda.cu:83-153): the gradients of the op above with
-    respect to value, sampling_loc and attn_weight, all f32 or all f64 -> (grad_value, grad_sampling_loc, grad_attn_weight)."""
+    respect to value, sampling_loc and attn_weight, all f32 or all f64 -> (grad_value, grad_sampling_loc, grad_attn_weight).
+    Runs hipie_msda_backward_ws: the gather form for fp32 and D = 32, the atomic kernel of hipie_msda_backward otherwise."""
     lib = _lib.load()
     B, S, M, D = value.shape
     _check_im2col_step(B, im2col_step)
@@ -149,10 +150,13 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     gv = torch.empty_like(value, memory_format=torch.contiguous_format)
     gl = torch.empty(sampling_loc.shape, dtype=dt, device=value.device)
     ga = torch.empty(attn_weight.shape, dtype=dt, device=value.device)
-    rc = lib.hipie_msda_backward(_chk(value, "value", dt), _chk(spatial_shapes, "spatial_shapes", torch.int64),
-                                 _chk(level_start_index, "level_start_index", torch.int64), _chk(sampling_loc, "sampling_loc", dt),
-                                 _chk(attn_weight, "attn_weight", dt), _chk(grad_output.contiguous(), "grad_output", dt),
-                                 gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), B, S, M, D, L, Lq, P, 3 if dt == torch.float64 else F32, _stream())
+    need = int(lib.hipie_msda_backward_workspace(B, S, M, L, Lq, P)) if dt == torch.float32 and D == 32 and B * Lq > 0 else 0
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=value.device)      # the gather form's bins and corner records (fp32, D = 32)
+    rc = lib.hipie_msda_backward_ws(_chk(value, "value", dt), _chk(spatial_shapes, "spatial_shapes", torch.int64),
+                                    _chk(level_start_index, "level_start_index", torch.int64), _chk(sampling_loc, "sampling_loc", dt),
+                                    _chk(attn_weight, "attn_weight", dt), _chk(grad_output.contiguous(), "grad_output", dt),
+                                    gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), B, S, M, D, L, Lq, P, 3 if dt == torch.float64 else F32,
+                                    ws.data_ptr(), need, _stream())
     _lib.check(rc, "hipie_msda_backward")
     return gv, gl, ga
 

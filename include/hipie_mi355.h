@@ -90,6 +90,20 @@ int hipie_msda_backward(const void* value, const int64_t* spatial_shapes, const 
                         void* grad_attn_weight, int B, int S, int M, int D, int L, int Lq, int P, int dtype, void* stream);
 
 /*
+ * The same operator with a caller-provided workspace: for fp32 and D = 32 (every MSDA of the model) grad_value is computed from the
+ * destination side -- sampling corners are binned by (pixel, head) with integer atomics, then every destination sums its own list in
+ * registers and is written once -- instead of B*Lq*M*L*P*4*D floating-point atomics (which bound the form above: ~460 G adds/s).
+ * Other dtypes / widths run the kernel above (the workspace is ignored).  Same arguments and results; grad_value needs no zeroing and
+ * is summed in slot (arrival) order.  workspace: at least hipie_msda_backward_workspace(...) bytes, 16-byte aligned, contents
+ * irrelevant before and after.  Replaces the same reference entry as hipie_msda_backward (ms_deform_attn_cuda.cu:83-153).
+ */
+int64_t hipie_msda_backward_workspace(int B, int S, int M, int L, int Lq, int P);
+int hipie_msda_backward_ws(const void* value, const int64_t* spatial_shapes, const int64_t* level_start, const void* sampling_loc,
+                           const void* attn_weight, const void* grad_output, void* grad_value, void* grad_sampling_loc,
+                           void* grad_attn_weight, int B, int S, int M, int D, int L, int Lq, int P, int dtype, void* workspace,
+                           int64_t workspace_bytes, void* stream);
+
+/*
  * Fused form used by the product path: sampling locations and the 16-way softmax are computed in the kernel from
  * the raw projections, so neither (B,Lq,M,L,P,2) locations nor normalised weights ever reach HBM.
  * Replaces: MSDeformAttn.forward lines 99-114 (ops/modules/ms_deform_attn.py) + the op above.

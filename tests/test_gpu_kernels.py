@@ -1227,6 +1227,72 @@ def test_msda_backward_d32_geometries(geom):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["heads5", "heads16_batch3", "tall_image", "all_outside", "one_pixel_hot"])
+def test_msda_backward_gather_form_against_the_atomic_kernel_and_autograd(case):
+    """hipie_msda_backward_ws (round 6: corners binned by destination in LDS counters, every (pixel, head) row of grad_value summed in registers
+    and stored once) against hipie_msda_backward (floating-point atomics) on the same inputs, and against autograd through the oracle's
+    formulation in double.  Cases: head counts that do not / do follow the one-head-per-XCD group map (5; 16 with 3 images: 48 planes -> 5 query
+    slices), more pixel rows per image than the LDS of a CU holds (S = 41650 > 40960: the entry runs the atomic kernel and says nothing), every
+    sampling point outside the maps (all gradients zero, grad_value still fully written), every query sampling the same pixel (one
+    destination list of B*Lq*L*P... records per head)."""
+    from hipie_amd import _lib, ops
+    lib = _lib.load()
+    M, D, P = {"heads5": (5, 32, 4), "heads16_batch3": (16, 32, 2)}.get(case, (8, 32, 4))
+    shapes = {"tall_image": [(280, 112), (140, 56), (70, 28), (35, 14)]}.get(case, [(24, 32), (12, 16), (6, 8)])
+    B, Lq = {"heads16_batch3": (3, 517), "tall_image": (1, 700)}.get(case, (2, 1203))
+    L = len(shapes)
+    sh = torch.as_tensor(shapes, dtype=torch.long)
+    ls = _lsi(sh)
+    S = int(sh.prod(1).sum())
+    g = torch.Generator().manual_seed(len(case))
+    value = torch.randn(B, S, M, D, generator=g, dtype=torch.float64)
+    # sampling points from 1.5 pixels outside the maps to 1.5 pixels outside on the other side, kept 0.05 pixel away from the pixel
+    # boundaries (where grad_sampling_loc jumps and an fp32 rounding of the location would pick the other side)
+    wh = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float64)[None, None, None, :, None, :]
+    raw = torch.rand(B, Lq, M, L, P, 2, generator=g, dtype=torch.float64) * (wh + 3) - 2.0
+    if case == "all_outside":
+        raw = raw + 2 * wh
+    if case == "one_pixel_hot":
+        raw = torch.floor(wh / 2) + torch.rand(raw.shape, generator=g, dtype=torch.float64)
+    pix = torch.floor(raw) + 0.05 + 0.9 * (raw - torch.floor(raw))
+    loc = (pix + 0.5) / wh
+    attn = torch.softmax(torch.randn(B, Lq, M, L * P, generator=g, dtype=torch.float64), -1).view(B, Lq, M, L, P)
+    gout = torch.randn(B, Lq, M * D, generator=g, dtype=torch.float64)
+    with torch.enable_grad():
+        v, l_, a = value.clone().requires_grad_(True), loc.clone().requires_grad_(True), attn.clone().requires_grad_(True)
+        want = torch.autograd.grad(oo.ms_deform_attn_core(v, sh, l_, a), (v, l_, a), gout)
+    f = torch.float32
+    dv, dsh, dls, dloc, dattn, dgo = (value.to(f).to(DEV), sh.to(DEV), ls.to(DEV), loc.to(f).to(DEV), attn.to(f).to(DEV), gout.to(f).to(DEV))
+    need = int(lib.hipie_msda_backward_workspace(B, S, M, L, Lq, P))
+    assert need >= B * Lq * M * L * P * 4 * 8
+    got = ops.ms_deform_attn_backward(dv, dsh, dls, dloc, dattn, dgo, 64)
+    ref = [torch.full_like(dv, float("nan")), torch.empty_like(dloc), torch.empty_like(dattn)]
+    rc = lib.hipie_msda_backward(dv.data_ptr(), dsh.data_ptr(), dls.data_ptr(), dloc.data_ptr(), dattn.data_ptr(), dgo.data_ptr(), ref[0].data_ptr(),
+                                 ref[1].data_ptr(), ref[2].data_ptr(), B, S, M, D, L, Lq, P, 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    # fp32 locations on a 280-pixel axis carry 280 * 2^-24 = 1.7e-5 pixel of rounding into the bilinear weights
+    tols = (3e-5, 2e-4, 2e-4) if case == "tall_image" else (3e-6, 2e-5, 2e-5)
+    for w, x, r, tol in zip(want, got, ref, tols):
+        scale = float(w.abs().max())
+        if scale == 0.0:
+            assert float(x.abs().max()) == 0.0 and float(r.abs().max()) == 0.0
+        else:
+            assert rel_err(x.cpu(), w) < tol and rel_err(r.cpu(), w) < tol
+            assert float((x - r).abs().max()) <= 2e-5 * scale
+    # a workspace that is too small is refused with the size that is needed (the atomic-only forms ignore the workspace)
+    ws = torch.empty(1024, dtype=torch.uint8, device=DEV)
+    out = [torch.empty_like(dv), torch.empty_like(dloc), torch.empty_like(dattn)]
+    rc = lib.hipie_msda_backward_ws(dv.data_ptr(), dsh.data_ptr(), dls.data_ptr(), dloc.data_ptr(), dattn.data_ptr(), dgo.data_ptr(), out[0].data_ptr(),
+                                    out[1].data_ptr(), out[2].data_ptr(), B, S, M, D, L, Lq, P, 0, ws.data_ptr(), 1024, torch.cuda.current_stream().cuda_stream)
+    if case == "tall_image":
+        assert rc == 0 and S > 40960
+        torch.cuda.synchronize()
+        assert rel_err(out[0].cpu(), want[0]) < tols[0]
+    else:
+        assert rc != 0 and b"needed" in lib.hipie_last_error()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,Q,C,H,W,bias", [(2, 300, 256, 64, 64, True), (1, 37, 256, 25, 38, False), (2, 1100, 256, 32, 32, True), (1, 5, 64, 3, 7, False)])
 def test_mask_einsum_backward_vs_autograd(B, Q, C, H, W, bias):
     """row f-4: the backward of the mask contraction (hipie_amd.training.functions.MaskEinsumFunction: forward hipie_mask_einsum, backward
