@@ -67,6 +67,7 @@ SIGNATURES = {
     "hipie_topk": [c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p],
     "hipie_fill_rows": [c_p, c_l, c_p, c_l, c_p, c_l, c_p],
     "hipie_to_hl8": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_f, c_p],
+    "hipie_to_hl8_t": [c_p, c_l, c_p, c_l, c_l, c_i, c_l, c_f, c_p],
     "hipie_selftest": [c_i, c_p, c_p, c_p, c_p],
 }
 

@@ -710,6 +710,51 @@ __global__ __launch_bounds__(256) void to_hl8_kernel(const T* __restrict__ x, f1
   *reinterpret_cast<f16x8*>(dst + 8) = l;
 }
 
+
+// x (rows x C fp32, row stride ldx) -> out (C x 2 rows_p) HL8: the TRANSPOSE as a split operand, for products that contract over the rows
+// (the weight gradients of the training step: dW = dy^T . x needs dy^T and x^T with the token dimension as K).  One pass instead of a
+// strided transpose copy followed by hipie_to_hl8: a 128-row x 64-column tile goes through LDS; columns beyond `rows` (up to rows_p, a
+// multiple of 8) are written as zeros.
+constexpr int kTrRows = 128, kTrCols = 64;
+__global__ __launch_bounds__(256) void to_hl8_t_kernel(const float* __restrict__ x, f16_t* __restrict__ out, long rows, int C, long ldx,
+                                                       long ldo, long rows_p, float scale) {
+  __shared__ float tile[kTrRows][kTrCols + 1];
+  const long r0 = (long)blockIdx.x * kTrRows;
+  const int c0 = blockIdx.y * kTrCols;
+  const int tid = threadIdx.x;
+  for (int k = tid; k < kTrRows * (kTrCols / 4); k += 256) {           // coalesced along the columns
+    const int i = k / (kTrCols / 4), j = (k % (kTrCols / 4)) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r0 + i < rows) {
+      const float* src = x + (r0 + i) * ldx + c0 + j;
+      if (c0 + j + 3 < C && (((uintptr_t)src) & 15) == 0) {
+        const float4 q = *reinterpret_cast<const float4*>(src);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      } else {
+        for (int e = 0; e < 4; ++e) v[e] = c0 + j + e < C ? src[e] : 0.f;
+      }
+    }
+    for (int e = 0; e < 4; ++e) tile[i][j + e] = v[e];
+  }
+  __syncthreads();
+  for (int u = tid; u < kTrCols * (kTrRows / 8); u += 256) {           // unit = (output row c, group of 8 source rows)
+    const int c = u % kTrCols, g = u / kTrCols;
+    const long m = r0 + 8 * g;
+    if (c0 + c >= C || m >= rows_p) continue;
+    f16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      f16_t hh, ll;
+      hl_split(tile[8 * g + e][c] * scale, hh, ll);
+      h[e] = hh;
+      l[e] = ll;
+    }
+    f16_t* dst = out + (long)(c0 + c) * ldo + 2 * m;
+    *reinterpret_cast<f16x8*>(dst) = h;
+    *reinterpret_cast<f16x8*>(dst + 8) = l;
+  }
+}
+
 }  // namespace hipie
 
 using namespace hipie;
@@ -909,4 +954,16 @@ extern "C" int hipie_to_hl8(const void* x, int64_t ldx, void* out, int64_t ldo, 
     default: return set_err(HIPIE_EINVAL, "to_hl8: dtype %d", x_dtype);
   }
   return check_launch("to_hl8");
+}
+
+extern "C" int hipie_to_hl8_t(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int C, int64_t rows_p, float scale, void* stream) {
+  HIPIE_REQUIRE(x && out && rows > 0 && C > 0, "to_hl8_t: rows=%ld C=%d", (long)rows, C);
+  HIPIE_REQUIRE(rows_p >= rows && rows_p % 8 == 0 && ldx >= C && ldo >= 2 * rows_p && ldo % 8 == 0, "to_hl8_t: rows_p=%ld (>= rows, multiple of 8), strides %ld / %ld",
+                (long)rows_p, (long)ldx, (long)ldo);
+  HIPIE_REQUIRE(((uintptr_t)out % 16) == 0, "to_hl8_t: output must be 16-byte aligned");
+  const long tiles_r = (rows_p + kTrRows - 1) / kTrRows, tiles_c = (C + kTrCols - 1) / kTrCols;
+  HIPIE_REQUIRE(tiles_c <= 65535, "to_hl8_t: C=%d too wide", C);
+  hipLaunchKernelGGL(to_hl8_t_kernel, dim3((unsigned)tiles_r, (unsigned)tiles_c), dim3(256), 0, (hipStream_t)stream, (const float*)x, (f16_t*)out,
+                     (long)rows, C, (long)ldx, (long)ldo, (long)rows_p, scale);
+  return check_launch("to_hl8_t");
 }

@@ -931,6 +931,23 @@ def to_hl8(x, scale=1.0):
     return out
 
 
+@_timed("to_hl8_t")
+def to_hl8_t(x, pad_to=32, scale=1.0):
+    """(M, C) fp32 device tensor (last dim contiguous, any row stride) -> (C, 2 Mp) fp16 HL8 of x^T, Mp = M rounded up to `pad_to`, the padding
+    columns zero (hipie_to_hl8_t): a split operand whose K runs over the rows of x."""
+    lib = _lib.load()
+    if x.dim() != 2 or x.dtype != torch.float32 or not x.is_cuda:
+        raise RuntimeError("to_hl8_t: a 2-D fp32 device tensor")
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    M, C = x.shape
+    Mp = -(-M // pad_to) * pad_to
+    out = torch.empty(C, 2 * Mp, dtype=torch.float16, device=x.device)
+    rc = lib.hipie_to_hl8_t(x.data_ptr(), x.stride(0), out.data_ptr(), 2 * Mp, M, C, Mp, float(scale), _stream())
+    _lib.check(rc, "hipie_to_hl8_t")
+    return out
+
+
 @_timed("fill_rows")
 def fill_rows(dst, rows, src_row):
     """dst[rows[i]] = src_row for every i (hipie_fill_rows): dst (R, W) contiguous device tensor, rows int32 (n,), src_row (W,) of dst's
@@ -1037,6 +1054,27 @@ def vit_attn_split(qkv, tab_h, tab_w, grid_hw, heads):
     rc = lib.hipie_vit_attn_split(_chk(qkv, "qkv"), _chk(tab_h, "tab_h"), _chk(tab_w, "tab_w"), out.data_ptr(), B, gh, gw, heads, hd, _stream())
     _lib.check(rc, "hipie_vit_attn_split")
     return out
+
+
+@_timed("gemm_split_k")
+def gemm_split_k(a_hl8, w_hl8, nk):
+    """a . w^T for HL8 operands a (M, 2K), w (N, 2K) with the contraction cut into nk chunks (K / nk a multiple of 32): one problem per
+    chunk in ONE hipie_gemm_batched launch, partial products summed -> (M, N) fp32.  For products whose M x N is a few tiles and whose K is
+    long (the weight gradients of the training step)."""
+    lib = _lib.load()
+    M, K2 = a_hl8.shape
+    N = w_hl8.shape[0]
+    K = K2 // 2
+    if w_hl8.shape[1] != K2 or K % (32 * nk) or a_hl8.dtype != torch.float16 or w_hl8.dtype != torch.float16 or not a_hl8.is_cuda:
+        raise RuntimeError("gemm_split_k: HL8 device operands (M, 2K) / (N, 2K), K a multiple of 32 * nk")
+    if N % 8:
+        raise RuntimeError("gemm_split_k: N must be a multiple of 8")
+    Kc = K // nk
+    part = torch.empty(nk, M, N, dtype=torch.float32, device=a_hl8.device)
+    rc = lib.hipie_gemm_batched(a_hl8.data_ptr(), K2, 0, 2 * Kc, w_hl8.data_ptr(), K2, 0, 2 * Kc, part.data_ptr(), N, 0, M * N, 1, nk, M, N, Kc,
+                                F32, 1.0, _stream())
+    _lib.check(rc, "hipie_gemm_batched")
+    return part.sum(0)
 
 
 @_timed("gemm_batched")

@@ -52,13 +52,31 @@ def dynamic_mask(mask_feats, ref_points, params, num_queries, stride=8, up=2):
     return DynamicMaskFunction.apply(mask_feats, ref_points, params, num_queries, stride, up)
 
 
+def _weight_grad(g2, x2):
+    """dW = dy^T . x  (N x K, the contraction over the M token rows) on the split GEMM.  N x K is 25-100 tiles of 256 x 256 for the ViT-H
+    linears -- a fraction of the 256 CUs -- so the M rows are cut into nk chunks, one problem each in ONE hipie_gemm_batched launch, and
+    the partial products are summed (the 64 x 128-tile kernel the single problem fell to ran at 160 TFLOP/s: 0.51 ms per linear)."""
+    M, N = g2.shape
+    K = x2.shape[1]
+    Mp = -(-M // 32) * 32
+    tiles = -(-N // 256) * -(-K // 256)
+    nk = 1
+    while nk < 16 and tiles * nk < 256 and (Mp // 32) % (2 * nk) == 0:
+        nk *= 2
+    gt, xt = ops.to_hl8_t(g2, 32), ops.to_hl8_t(x2, 32)                                           # (N | K, 2 Mp) fp16 pairs, one pass each
+    if nk == 1:
+        return ops.gemm(gt, xt, None, split=True, out_fmt=ops.F32, tag="train_dw")
+    return ops.gemm_split_k(gt, xt, nk)
+
+
 class SplitLinearFunction(torch.autograd.Function):
     """F.linear(x, weight, bias) with forward AND backward on hipie_gemm's split-fp16 operands (three MFMA products, fp32 accumulation:
     fp32-class results at ~2.7x the rate of the fp32 matrix pipe): the linears of the training step that carry its flops (ViT qkv / proj /
     fc1 / fc2, the encoder FFNs).
         y  = x . W^T + b            hipie_gemm(A = x fp32 rows, W as HL8)
         dx = dy . W                 hipie_gemm(A = dy fp32 rows, W^T as HL8)
-        dW = dy^T . x               hipie_gemm(A = dy^T fp32 rows, (x^T) as HL8): the contraction runs over the M rows (padded to 32)
+        dW = dy^T . x               split operands dy^T and x^T, the contraction over the M rows (padded to 32) cut into chunks that run as
+                                    one hipie_gemm_batched launch (_weight_grad)
         db = sum_m dy
     The two transposed operands cost one pass each; the HL8 copies of W and W^T are cached per parameter version on `owner`."""
 
@@ -75,19 +93,16 @@ class SplitLinearFunction(torch.autograd.Function):
     def backward(ctx, gy):
         x2, weight = ctx.saved_tensors
         N, K = weight.shape
-        g2 = gy.reshape(-1, N).contiguous().float()
+        g2 = gy.reshape(-1, N).float()
+        if g2.stride(-1) != 1:
+            g2 = g2.contiguous()
         M = g2.shape[0]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wt_hl8, _, _ = ops.split_weight(ctx.owner, ctx.key + ".T", [weight], lambda: weight.t().contiguous())
             gx = ops.gemm(g2, wt_hl8, None, split=True, out_fmt=ops.F32, tag="train_dx").view(*ctx.lead, K)
         if ctx.needs_input_grad[1]:
-            Mp = -(-M // 32) * 32
-            gt = g2.new_zeros(N, Mp)
-            gt[:, :M] = g2.t()
-            xt = x2.new_zeros(K, Mp)
-            xt[:, :M] = x2.t()
-            gw = ops.gemm(gt, ops.to_hl8(xt), None, split=True, out_fmt=ops.F32, tag="train_dw")
+            gw = _weight_grad(g2, x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g2.sum(0)
         return gx, gw, gb, None, None

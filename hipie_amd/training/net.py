@@ -91,14 +91,31 @@ def inverse_sigmoid(x, eps=1e-5):
 
 
 # ------------------------------------------------------------------------------------------------ ViT backbone (backbone/vit.py, utils.py)
+_RESIZE_OPS = {}
+
+
+def _bicubic_operator(src, dst, device, dtype=torch.float32):
+    """(dst, src) matrix of F.interpolate(mode="bicubic", align_corners=False) along one axis, read off the library itself (the identity
+    pushed through it), so the border clamping and the A = -0.75 kernel are the library's own"""
+    key = (src, dst, str(device), dtype)
+    if key not in _RESIZE_OPS:
+        eye = torch.eye(src, device=device, dtype=dtype).view(1, src, src, 1)
+        _RESIZE_OPS[key] = F.interpolate(eye, size=(dst, 1), mode="bicubic", align_corners=False)[0, :, :, 0].t().contiguous()
+    return _RESIZE_OPS[key]
+
+
 def get_abs_pos(abs_pos, hw):
-    """utils.py:128-157 (has_cls_token)"""
+    """utils.py:128-157 (has_cls_token).  The bicubic resize is linear and separable: it is applied as two small matrix products
+    (rows, then columns) with the library's own weights -- the same map as F.interpolate, whose BACKWARD kernel
+    (upsample_bicubic2d_backward_out_frame) takes 92 ms per step for this one (1, 1280, 64, 64) tensor on gfx950; as products it is 0.1 ms."""
     h, w = hw
     abs_pos = abs_pos[:, 1:]
     size = int(math.sqrt(abs_pos.shape[1]))
     if size != h or size != w:
-        new = F.interpolate(abs_pos.reshape(1, size, size, -1).permute(0, 3, 1, 2), size=(h, w), mode="bicubic", align_corners=False)
-        return new.permute(0, 2, 3, 1)
+        grid = abs_pos.reshape(size, size, -1)
+        ah, aw = _bicubic_operator(size, h, abs_pos.device, abs_pos.dtype), _bicubic_operator(size, w, abs_pos.device, abs_pos.dtype)
+        rows = torch.matmul(ah, grid.reshape(size, -1)).reshape(h, size, -1)                  # (h, size, C)
+        return torch.matmul(aw, rows.permute(1, 0, 2).reshape(size, -1)).reshape(w, h, -1).permute(1, 0, 2)[None]
     return abs_pos.reshape(1, h, w, -1)
 
 
@@ -143,18 +160,44 @@ def _blin(x, sd, p, be):
     return f(x, sd, p) if f is not None else lin(x, sd, p)
 
 
+_KEY_AXES = {}
+FOLD_REL_POS = True
+
+
+def _key_axis_indicators(H, W, device, dtype):
+    """(H*W, H + W) constant: row n = key (n // W, n % W) has a one in column n // W and a one in column H + n % W"""
+    key = (H, W, str(device), dtype)
+    if key not in _KEY_AXES:
+        n = torch.arange(H * W, device=device)
+        ind = torch.zeros(H * W, H + W, device=device, dtype=dtype)
+        ind[n, torch.div(n, W, rounding_mode="floor")] = 1
+        ind[n, H + n % W] = 1
+        _KEY_AXES[key] = ind
+    return _KEY_AXES[key]
+
+
 def vit_attention(x, sd, p, heads, be=None):
-    """Attention.forward (vit.py:67-83) + add_decomposed_rel_pos (utils.py:96-125): the bias is computed from the UNSCALED q"""
+    """Attention.forward (vit.py:67-83) + add_decomposed_rel_pos (utils.py:96-125): the bias is computed from the UNSCALED q.
+    The decomposed bias rel_h[q, kh] + rel_w[q, kw] is a product as well -- [rel_h(q, :), rel_w(q, :)] . [onehot(kh), onehot(kw)] -- so it
+    rides in the logits' GEMM as H + W extra columns of the operands (q' = [scale q, rel_h, rel_w], k' = [k, indicators]) instead of two
+    broadcast additions over the (heads, HW, HW) logits forward and two reductions over their gradient backward (at 64 x 64 tokens: four
+    passes over 2 GB per block)."""
     B, H, W, C = x.shape
     hd = C // heads
     qkv = _blin(x, sd, p + "qkv.", be).reshape(B, H * W, 3, heads, -1).permute(2, 0, 3, 1, 4)
     q, k, v = qkv.reshape(3, B * heads, H * W, -1).unbind(0)
-    attn = (q * hd ** -0.5) @ k.transpose(-2, -1)
     Rh, Rw = get_rel_pos(H, H, sd[p + "rel_pos_h"]), get_rel_pos(W, W, sd[p + "rel_pos_w"])
     rq = q.reshape(B * heads, H, W, hd)
-    rel_h = torch.einsum("bhwc,hkc->bhwk", rq, Rh)
-    rel_w = torch.einsum("bhwc,wkc->bhwk", rq, Rw)
-    attn = (attn.view(B * heads, H, W, H, W) + rel_h[:, :, :, :, None] + rel_w[:, :, :, None, :]).view(B * heads, H * W, H * W)
+    rel_h = torch.einsum("bhwc,hkc->bhwk", rq, Rh).reshape(B * heads, H * W, H)
+    rel_w = torch.einsum("bhwc,wkc->bhwk", rq, Rw).reshape(B * heads, H * W, W)
+    if FOLD_REL_POS:
+        qa = torch.cat((q * hd ** -0.5, rel_h, rel_w), -1)
+        ka = torch.cat((k, _key_axis_indicators(H, W, k.device, k.dtype).expand(B * heads, -1, -1)), -1)
+        attn = qa @ ka.transpose(-2, -1)
+    else:
+        attn = (q * hd ** -0.5) @ k.transpose(-2, -1)
+        attn = (attn.view(B * heads, H, W, H, W) + rel_h.view(B * heads, H, W, H)[:, :, :, :, None]
+                + rel_w.view(B * heads, H, W, W)[:, :, :, None, :]).view(B * heads, H * W, H * W)
     o = attn.softmax(dim=-1) @ v
     o = o.view(B, heads, H, W, -1).permute(0, 2, 3, 1, 4).reshape(B, H, W, -1)
     return _blin(o, sd, p + "proj.", be)

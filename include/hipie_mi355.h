@@ -474,6 +474,12 @@ int hipie_fill_rows(void* dst, int64_t ld_bytes, const int32_t* rows, int64_t n_
  * fp16 elements >= 2K): the generic producer of split operands (the LayerNorm / GEMM epilogues emit HL8 directly). */
 int hipie_to_hl8(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int K, int x_dtype, float scale, void* stream);
 
+/* x (rows x C fp32 values, row stride ldx elements) -> out (C x 2 rows_p) HIPIE_HL8 rows of scale * x^T: the transpose as a split operand in ONE
+ * pass (a strided transpose copy + hipie_to_hl8 otherwise), columns rows <= m < rows_p zero (rows_p a multiple of 8; 32 for a GEMM operand).
+ * The producer of both operands of the weight gradient dW = dy^T . x of a Linear (torch.nn.functional.linear's backward in the reference's
+ * training step, hipie/backbone/vit.py:67-83 and every other Linear): the contraction runs over the token rows. */
+int hipie_to_hl8_t(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t rows, int C, int64_t rows_p, float scale, void* stream);
+
 /*
  * hipie_gemm on n_outer x n_inner independent problems in ONE launch (split-fp16 HL8 operands only, no bias / residual / activation):
  * problem (o, i) reads A + o * a_outer + i * a_inner (fp16 elements), W + o * w_outer + i * w_inner, writes out + o * o_outer +

@@ -58,6 +58,23 @@ def test_to_hl8_kernel_matches_torch_pack():
     assert torch.equal(ops.to_hl8(xh), ops.hl8_pack(xh))
 
 
+@gpu
+@pytest.mark.parametrize("M,C,stride", [(8192, 1280, None), (333, 64, None), (1000, 320, 512), (7, 5, None), (130, 70, 72)])
+def test_to_hl8_t_is_the_pack_of_the_transpose(M, C, stride):
+    """hipie_to_hl8_t (round 6: both operands of the weight gradients) == hl8_pack(x^T) with the rows padded to 32, bit for bit: full tiles,
+    ragged rows and columns, a row-strided input, columns that are not a multiple of 4 (the unaligned load path)"""
+    from hipie_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + C)
+    base = torch.randn(M, stride or C, device="cuda", generator=g) * 3
+    x = base[:, :C]
+    Mp = -(-M // 32) * 32
+    want = torch.zeros(C, Mp, device="cuda")
+    want[:, :M] = x.t()
+    got = ops.to_hl8_t(x, 32)
+    assert got.shape == (C, 2 * Mp) and torch.equal(got, ops.hl8_pack(want))
+    assert torch.equal(ops.to_hl8_t(x, 32, 0.25), ops.hl8_pack(want, 0.25))
+
+
 SHAPES = [  # M, N, K
     (300, 256, 256),          # M tail, one N tile of 256
     (512, 1280, 1280),        # the 320-wide tile (ViT-H proj), two full M tiles
@@ -358,10 +375,11 @@ def test_gemm_thin_k256_kernel(M, N, f32):
 
 
 @gpu
-@pytest.mark.parametrize("M,N,K,bias", [(1000, 320, 256, True), (4096, 1280, 1280, True), (333, 64, 2048, False)])
+@pytest.mark.parametrize("M,N,K,bias", [(1000, 320, 256, True), (4096, 1280, 1280, True), (333, 64, 2048, False), (8192, 3840, 1280, True), (2080, 512, 5120, False)])
 def test_split_linear_function_forward_and_backward(M, N, K, bias):
     """row f-4 (3a): hipie_gemm as an autograd Function -- y = x W^T + b, dx = dy W, dW = dy^T x, db = sum dy, all three products on the
-    split-fp16 GEMM (training/functions.SplitLinearFunction) -- against torch.autograd of F.linear in double."""
+    split-fp16 GEMM (training/functions.SplitLinearFunction) -- against torch.autograd of F.linear in double.  dW cuts the token rows into
+    up to 16 chunks that run as one hipie_gemm_batched launch (16 / 16 / 1 / 4 / 1 chunks in these cases; 2080 = 65 x 32 rows do not halve)."""
     from hipie_amd.training.functions import SplitLinearFunction
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g, dtype=torch.float64)

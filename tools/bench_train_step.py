@@ -2,7 +2,8 @@
 """forward + backward time of ONE TRAINING STEP (hipie_amd/training/step.py) at the reference's training batch: ViT-H, 1024 x 1024, 2 images per
 GPU (configs/training/vit_huge_32g.yaml:1 -- 32 GPUs x 2), the 80-class caption, 8 synthetic targets per image (6 things, 2 stuff), DN_NUMBER 100,
 12544 mask points, random-init weights.  Prints ms for the forward (loss dictionary), the backward, and the peak memory.
-    python tools/bench_train_step.py [batch] [steps]"""
+    python tools/bench_train_step.py [batch] [steps]
+env: LIB_LINEAR=1 (library fp32 linears), PHASES=1 (synchronised forward phases), TORCH_PROF=1 (top kernels), HOSTPROF=1 (cProfile of a forward)"""
 import os
 import sys
 import time
@@ -78,7 +79,7 @@ def main():
         wrap(step.criterion, "forward")
     n_par = sum(p.numel() for p in model.parameters() if p.requires_grad)
     fw, bw = [], []
-    for it in range(steps + 1):
+    for it in range(steps + 2):                              # two untimed steps: the second still grows the allocator's pools (2.1 s forward)
         model.zero_grad(set_to_none=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -90,7 +91,7 @@ def main():
         total.backward()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        if it:
+        if it >= 2:
             fw.append(t1 - t0)
             bw.append(t2 - t1)
     if os.environ.get("TORCH_PROF") == "1":                  # top kernels of one steady-state step
@@ -102,8 +103,26 @@ def main():
             total.backward()
             torch.cuda.synchronize()
         print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=28, max_name_column_width=90))
+    if os.environ.get("HOSTPROF") == "1":                    # where the HOST time goes (the step is launch-bound on a slow host)
+        import cProfile
+        import io
+        import pstats
+        model.zero_grad(set_to_none=True)
+        pr = cProfile.Profile()
+        pr.enable()
+        with torch.enable_grad():
+            total = sum(step.loss_dict(batch, targets).values())
+        pr.disable()
+        torch.cuda.synchronize()
+        for key in ("cumulative", "tottime"):
+            out = io.StringIO()
+            pstats.Stats(pr, stream=out).sort_stats(key).print_stats(28)
+            print("\n".join(l[:190] for l in out.getvalue().splitlines() if l.strip()))
+        total.backward()
+        torch.cuda.synchronize()
     if phases:
         print("forward phases (sum over %d steps, ms): %s" % (steps + 1, ", ".join("%s %.1f" % (k, v * 1e3) for k, v in phases.items())))
+    print("per step (ms) forward: %s | backward: %s" % (" ".join("%.0f" % (1e3 * t) for t in fw), " ".join("%.0f" % (1e3 * t) for t in bw)))
     gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
     print("training step, ViT-H 1024^2, %d images / GPU, %.0f M trainable parameters, %d loss entries: forward %.1f ms, backward %.1f ms, total %.1f ms "
           "(%.2f images/s per GPU); loss %.3f, gradient norm %.3e, finite %s; peak memory %.1f GB"
