@@ -78,12 +78,12 @@ def _perm(indices, which):
 
 
 def _target_count(targets, device):
-    n = torch.as_tensor([float(sum(len(t["labels"]) for t in targets))], device=device)
-    world = 1
-    if torch.distributed.is_available() and torch.distributed.is_initialized():
-        torch.distributed.all_reduce(n)
-        world = torch.distributed.get_world_size()
-    return torch.clamp(n / world, min=1).item()
+    count = float(sum(len(t["labels"]) for t in targets))
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return max(count, 1.0)                      # one process: no device round trip (a host wait for the whole queue)
+    n = torch.as_tensor([count], device=device)
+    torch.distributed.all_reduce(n)
+    return torch.clamp(n / torch.distributed.get_world_size(), min=1).item()
 
 
 def _positive_onehot(logits, targets, indices):

@@ -18,6 +18,22 @@ import torch
 import torch.nn.functional as F
 
 
+_LEVELS = {}
+
+
+def level_tensors(shapes, device, which="int"):
+    """the pyramid's [(H, W)] as device tensors, built once per geometry: (spatial_shapes int64, level_start_index) or, which="wh", the
+    (L, 2) float (W, H) normaliser.  A host list -> device tensor is a pageable copy, i.e. a host wait for everything queued on the stream:
+    two of them per MSDeformAttn call kept the host from ever running ahead of the GPU (127 ms per forward of it sitting there, sampled)."""
+    key = (tuple((int(h), int(w)) for h, w in (shapes.tolist() if torch.is_tensor(shapes) else shapes)), str(device))
+    if key not in _LEVELS:
+        ss = torch.as_tensor(key[0], dtype=torch.int64, device=device)
+        ls = torch.cat((ss.new_zeros(1), ss.prod(1).cumsum(0)[:-1]))
+        _LEVELS[key] = (ss, ls, torch.stack((ss[:, 1], ss[:, 0]), -1).float())
+    ss, ls, wh = _LEVELS[key]
+    return wh if which == "wh" else (ss, ls)
+
+
 class HipBackend:
     """the operator kernels with a hand-written backward (libhipie_mi355.so); no host path"""
 
@@ -35,8 +51,7 @@ class HipBackend:
     def msda(value, shapes, loc, aw):
         """value (B,S,M,D), shapes [(H,W)], loc (B,Lq,M,L,P,2), aw (B,Lq,M,L,P) -> (B,Lq,M*D)"""
         from ..msda_shim import MSDeformAttnFunction
-        ss = torch.as_tensor(shapes, dtype=torch.int64, device=value.device)
-        ls = torch.cat((ss.new_zeros(1), ss.prod(1).cumsum(0)[:-1]))
+        ss, ls = level_tensors(shapes, value.device)
         return MSDeformAttnFunction.apply(value.contiguous(), ss, ls, loc.contiguous(), aw.contiguous(), 64)
 
     @staticmethod
@@ -301,9 +316,8 @@ def msda_module(query, ref_points, src, shapes, pad_mask, sd, p, be, heads=8, le
     value = value.view(N, S, heads, C // heads)
     off = lin(query, sd, p + "sampling_offsets.").view(N, Lq, heads, levels, points, 2)
     aw = F.softmax(lin(query, sd, p + "attention_weights.").view(N, Lq, heads, levels * points), -1).view(N, Lq, heads, levels, points)
-    shp = torch.as_tensor(shapes, dtype=torch.float32, device=query.device)
     if ref_points.shape[-1] == 2:
-        loc = ref_points[:, :, None, :, None, :] + off / torch.stack([shp[:, 1], shp[:, 0]], -1)[None, None, None, :, None, :]
+        loc = ref_points[:, :, None, :, None, :] + off / level_tensors(shapes, query.device, "wh")[None, None, None, :, None, :]
     else:
         loc = ref_points[:, :, None, :, None, :2] + off / points * ref_points[:, :, None, :, None, 2:] * 0.5
     return lin(be.msda(value, shapes, loc, aw), sd, p + "output_proj.")

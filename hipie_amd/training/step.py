@@ -122,8 +122,8 @@ class TrainStep:
         sd, cfg, be, d = self.params(), self.cfg, self.be, self.draws
         dev = x.device
         gt_fg, gt_bg = split_things_stuff(targets)
-        feats, srcs, masks, poses = net.backbone_and_projections(x, pad, sd, cfg, be)
         nbg, nq = cfg["num_bg_queries"], cfg["num_queries"]
+        scale = torch.tensor([[float(w), float(h)] for (h, w) in sizes], device=dev)    # host -> device copies wait for the queue: made while it is empty
         # ---- contrastive de-noising queries; the label side is the image's (un-fused) text embedding (DYNAMIC_LABEL_ENC) (:324-360)
         pool0 = net.agg_lang_feat(lang["hidden"], lang["masks"])
         label_enc = net.ln(net.lin(pool0, sd, "detr.resizer.fc."), sd, "detr.resizer.layer_norm.", 1e-12)
@@ -138,6 +138,11 @@ class TrainStep:
             noise = {"sign": sign, "part": d.rand((2 * G * n_all, 4), dev)}
         q_label, q_box, attn_mask, dn_meta = cdn_queries(targets, self.dn_number, self.box_noise_scale, nq + nbg, label_enc, noise=noise,
                                                          label_noise_ratio=self.label_noise_ratio, num_classes=None)
+        # The backbone is launched AFTER the de-noising queries, which need the text embedding and the targets only: cdn_queries ends in a
+        # data-dependent torch.nonzero -- a host wait for everything queued so far.  Behind the backbone that wait is the backbone's whole GPU
+        # time (114 ms per step of the host sitting there, sampled), and the host-bound matcher / criterion code that follows then runs with an
+        # empty queue instead of behind it.
+        feats, srcs, masks, poses = net.backbone_and_projections(x, pad, sd, cfg, be)
         tr = net.hipie_transformer(srcs, masks, poses, lang, sd, "detr.detr.transformer.", cfg, be, q_label, q_box, attn_mask, self.fusion_dropout)
         hs, memory, shapes = tr["hs"], tr["memory"], tr["shapes"]
         fused = {"hidden": tr["lang_hidden"], "masks": lang["masks"]}
@@ -151,7 +156,6 @@ class TrainStep:
         start_bg, start_fg = padding, padding + nbg
         mask_feats = self.mask_branch(memory, shapes, sd)
         B = x.shape[0]
-        scale = torch.tensor([[float(w), float(h)] for (h, w) in sizes], device=dev)
         groups = {k: dict(cls=[], box=[], msk=[], idx=[]) for k in ("fg", "bg", "gt")}
         ious = []
         for lvl in range(hs.shape[0]):

@@ -120,8 +120,63 @@ def main():
             print("\n".join(l[:190] for l in out.getvalue().splitlines() if l.strip()))
         total.backward()
         torch.cuda.synchronize()
+    if os.environ.get("HOSTPROF") == "2":                    # wall-clock stack sampling of the main thread (1 ms) over 3 forwards: where the host IS
+        import collections
+        import threading
+        main_id = threading.get_ident()
+        hits, leaf, stop = collections.Counter(), collections.Counter(), threading.Event()
+
+        def sampler():
+            while not stop.is_set():
+                f = sys._current_frames().get(main_id)
+                chain, lines = [], []
+                while f is not None:
+                    fn = f.f_code.co_filename
+                    if "/hipie_amd/" in fn:
+                        chain.append("%s:%s" % (os.path.basename(fn), f.f_code.co_name))
+                        lines.append(f.f_lineno)
+                    f = f.f_back
+                if chain:
+                    leaf[chain[0] + ":%d" % lines[0]] += 1
+                    for c in set(chain):
+                        hits[c] += 1
+                time.sleep(0.001)
+        import scipy.optimize as _m
+        lsa, lsa_t = _m.linear_sum_assignment, []
+
+        def timed_lsa(c):
+            t0_ = time.perf_counter()
+            r = lsa(c)
+            lsa_t.append((time.perf_counter() - t0_, c.shape))
+            return r
+        _m.linear_sum_assignment = timed_lsa
+        for _ in range(3):
+            model.zero_grad(set_to_none=True)
+            torch.cuda.synchronize()
+            th = threading.Thread(target=sampler)
+            stop.clear()
+            th.start()
+            with torch.enable_grad():
+                total = sum(step.loss_dict(batch, targets).values())
+            stop.set()
+            th.join()
+            total.backward()
+            torch.cuda.synchronize()
+        _m.linear_sum_assignment = lsa
+        print("scipy linear_sum_assignment: %d calls, %.1f ms in total over 3 forwards; slowest %s" % (
+            len(lsa_t), 1e3 * sum(t for t, _ in lsa_t), ["%.1f ms %s" % (1e3 * t, sh) for t, sh in sorted(lsa_t, reverse=True)[:4]]))
+        n = sum(leaf.values())
+        print("host samples over 3 forwards: %d (~ms); innermost hipie_amd frame:" % n)
+        for k, v in leaf.most_common(22):
+            print("   %5d  %s" % (v, k))
+        print("inclusive:")
+        for k, v in hits.most_common(30):
+            print("   %5d  %s" % (v, k))
     if phases:
         print("forward phases (sum over %d steps, ms): %s" % (steps + 1, ", ".join("%s %.1f" % (k, v * 1e3) for k, v in phases.items())))
+    ms_ = torch.cuda.memory_stats()
+    print("allocator: %d device allocations, %d device frees, %d retries over %d steps; reserved %.1f GB" % (
+        ms_.get("num_device_alloc", -1), ms_.get("num_device_free", -1), ms_.get("num_alloc_retries", -1), steps + 2, torch.cuda.memory_reserved() / 2 ** 30))
     print("per step (ms) forward: %s | backward: %s" % (" ".join("%.0f" % (1e3 * t) for t in fw), " ".join("%.0f" % (1e3 * t) for t in bw)))
     gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
     print("training step, ViT-H 1024^2, %d images / GPU, %.0f M trainable parameters, %d loss entries: forward %.1f ms, backward %.1f ms, total %.1f ms "

@@ -7,11 +7,14 @@ import csv
 import sys
 
 path = sys.argv[1]
-frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
+seconds = float(sys.argv[2][:-1]) if len(sys.argv) > 2 and sys.argv[2].endswith("s") else None      # "0.86s": the last 0.86 seconds
+frac = 0.5 if seconds is not None else (float(sys.argv[2]) if len(sys.argv) > 2 else 0.5)
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 t0, t1 = int(rows[0]["Start_Timestamp"]), int(rows[-1]["End_Timestamp"])
-if frac >= 1.0:
+if seconds is not None:
+    cut = t1 - int(seconds * 1e9)
+elif frac >= 1.0:
     # frac = K >= 1: the window is the last K forwards, located by the 24 global-attention launches each one issues
     marks = [int(r["Start_Timestamp"]) for r in rows if ("vit_attn_sp_kernel" in r["Kernel_Name"]) or
              ("vit_attn_split_kernel" in r["Kernel_Name"] and ("Li2ELi8E" in r["Kernel_Name"] or "2, 8," in r["Kernel_Name"])) or
@@ -49,16 +52,21 @@ prev_end, prev_name = None, None
 for r in rows:
     st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     if prev_end is not None and st > prev_end:
-        gaps.append((st - prev_end, prev_name, r["Kernel_Name"][:70]))
+        gaps.append((st - prev_end, prev_name, r["Kernel_Name"][:70], (prev_end - cut) / 1e6))
     if prev_end is None or en > prev_end:
         prev_end, prev_name = en, r["Kernel_Name"][:70]
 tot_gap = sum(g[0] for g in gaps)
+# idle time per 50 ms slice of the window: where in the step the GPU starves
+slices = collections.defaultdict(float)
+for d, _, _, at in gaps:
+    slices[int(at // 50)] += d / 1e6
+print("\nidle ms per 50 ms slice of the window: " + " ".join("%d:%.0f" % (k * 50, v) for k, v in sorted(slices.items())))
 print("\nidle gaps: total %.2f ms in %d gaps; > 20 us: %.2f ms in %d gaps" % (
     tot_gap / 1e6, len(gaps), sum(g[0] for g in gaps if g[0] > 20000) / 1e6, sum(1 for g in gaps if g[0] > 20000)))
-for d, a, b in sorted(gaps, key=lambda x: -x[0])[:25]:
-    print("%9.1f us  after %-70s before %s" % (d / 1e3, a, b))
+for d, a, b, at in sorted(gaps, key=lambda x: -x[0])[:25]:
+    print("%9.1f us  at +%7.1f ms  after %-70s before %s" % (d / 1e3, at, a, b))
 by_next = collections.defaultdict(lambda: [0, 0])
-for d, a, b in gaps:
+for d, a, b, _ in gaps:
     by_next[b][0] += d
     by_next[b][1] += 1
 print("\ngap time by the kernel that follows the gap:")
