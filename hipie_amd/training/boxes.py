@@ -23,7 +23,7 @@ def _pairwise_inter_union(a, b):
 def generalized_box_iou(a, b):
     """pairwise GIoU of xyxy boxes, (N, 4) x (M, 4) -> (N, M); the enclosing-box term carries the reference's 1e-7
     (util/box_ops.py:64-86).  Degenerate boxes are a caller error there (assert) and here (ValueError)."""
-    if not bool((a[:, 2:] >= a[:, :2]).all()) or not bool((b[:, 2:] >= b[:, :2]).all()):
+    if not bool((a[:, 2:] >= a[:, :2]).all() & (b[:, 2:] >= b[:, :2]).all()):          # one host wait for both checks
         raise ValueError("generalized_box_iou: boxes with x1 < x0 or y1 < y0")
     inter, union = _pairwise_inter_union(a, b)
     lo = torch.minimum(a[:, None, :2], b[None, :, :2])
