@@ -446,10 +446,11 @@ def test_abs_pos_resize_as_matrix_products_is_the_library_bicubic():
     g = torch.Generator().manual_seed(3)
     for size, (h, w) in ((14, (64, 64)), (14, (16, 24)), (32, (20, 7)), (8, (8, 8))):
         p = torch.randn(1, 1 + size * size, 24, generator=g, dtype=torch.float64, requires_grad=True)
-        got = net.get_abs_pos(p, (h, w))
-        a = p[:, 1:].reshape(1, size, size, -1)
-        ref = F.interpolate(a.permute(0, 3, 1, 2), size=(h, w), mode="bicubic", align_corners=False).permute(0, 2, 3, 1) if (size, size) != (h, w) else a
-        go = torch.randn(ref.shape, generator=g, dtype=torch.float64)
-        g1, = torch.autograd.grad(got, p, go, retain_graph=True)
-        g2, = torch.autograd.grad(ref, p, go)
+        with torch.enable_grad():                      # other test modules switch autograd off at import
+            got = net.get_abs_pos(p, (h, w))
+            a = p[:, 1:].reshape(1, size, size, -1)
+            ref = F.interpolate(a.permute(0, 3, 1, 2), size=(h, w), mode="bicubic", align_corners=False).permute(0, 2, 3, 1) if (size, size) != (h, w) else a
+            go = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+            g1, = torch.autograd.grad(got, p, go, retain_graph=True)
+            g2, = torch.autograd.grad(ref, p, go)
         assert got.shape == ref.shape and float((got - ref).abs().max()) < 1e-13 and float((g1 - g2).abs().max()) < 1e-12
