@@ -68,6 +68,9 @@ SIGNATURES = {
     "hipie_fill_rows": [c_p, c_l, c_p, c_l, c_p, c_l, c_p],
     "hipie_to_hl8": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_f, c_p],
     "hipie_to_hl8_t": [c_p, c_l, c_p, c_l, c_l, c_i, c_l, c_f, c_p],
+    "hipie_attn_train_forward": [c_p] * 8 + [c_i, c_i, c_p],
+    "hipie_to_f16_pair": [c_p, c_l, c_p, c_p, c_l, c_i, c_i, c_p, c_p],
+    "hipie_attn_train_backward": [c_p] * 13 + [c_i, c_i, c_p],
     "hipie_selftest": [c_i, c_p, c_p, c_p, c_p],
 }
 

@@ -948,6 +948,78 @@ def to_hl8_t(x, pad_to=32, scale=1.0):
     return out
 
 
+def f16_pair(x, cols=None, scale=None):
+    """fp32 (.., C) -> the two contiguous fp16 planes (hi = fp16(s x), lo = fp16(s x - hi)) of the fused training attention's operands, the
+    last dimension zero-padded to `cols` (a multiple of 8); s = `scale`, a one-element DEVICE tensor (no host wait), or 1; values beyond the
+    fp16 range saturate (hl_split).  One pass on the device (hipie_to_f16_pair); the torch formulation on the host."""
+    C = x.shape[-1]
+    Cp = C if cols is None else max(cols, C)
+    if x.is_cuda and x.dtype == torch.float32 and Cp % 8 == 0:
+        lib = _lib.load()
+        x2 = x.reshape(-1, C)
+        if x2.stride(1) != 1 or (x2.shape[0] > 1 and x2.stride(0) < C):
+            x2 = x2.contiguous()
+        hi = torch.empty(*x.shape[:-1], Cp, dtype=torch.float16, device=x.device)
+        lo = torch.empty_like(hi)
+        sc = 0 if scale is None else scale.float().reshape(1).data_ptr()
+        rc = lib.hipie_to_f16_pair(x2.data_ptr(), x2.stride(0) if x2.shape[0] > 1 else C, hi.data_ptr(), lo.data_ptr(), x2.shape[0], C, Cp, sc, _stream())
+        _lib.check(rc, "hipie_to_f16_pair")
+        return hi, lo
+    if Cp > C:
+        x = torch.nn.functional.pad(x, (0, Cp - C))
+    x = x.float() * (1.0 if scale is None else scale)
+    x = x.clamp(-65504.0, 65504.0)
+    hi = x.half()
+    return hi.contiguous(), (x - hi.float()).half().contiguous()
+
+
+@_timed("attn_train_fwd")
+def attn_train_forward(q_pair, k_pair, v_pair):
+    """hipie_attn_train_forward: q', k' (BH, N, 224) and v (BH, N, 80) as fp16 pairs (f16_pair) -> (out (BH, N, 80) f32, lse (BH, N) f32)"""
+    lib = _lib.load()
+    qh, ql = q_pair
+    kh, kl = k_pair
+    vh, vl = v_pair
+    BH, N, DQ = qh.shape
+    if DQ != 224 or kh.shape != qh.shape or tuple(vh.shape) != (BH, N, 80) or N % 128 or not qh.is_cuda:
+        raise RuntimeError("attn_train_forward: q', k' (BH, N, 224), v (BH, N, 80) device pairs with N %% 128 == 0, got %s / %s / %s"
+                           % (tuple(qh.shape), tuple(kh.shape), tuple(vh.shape)))
+    for t in (qh, ql, kh, kl, vh, vl):
+        if t.dtype != torch.float16 or not t.is_contiguous():
+            raise RuntimeError("attn_train_forward: contiguous fp16 planes")
+    out = torch.empty(BH, N, 80, dtype=torch.float32, device=qh.device)
+    lse = torch.empty(BH, N, dtype=torch.float32, device=qh.device)
+    rc = lib.hipie_attn_train_forward(qh.data_ptr(), ql.data_ptr(), kh.data_ptr(), kl.data_ptr(), vh.data_ptr(), vl.data_ptr(), out.data_ptr(),
+                                      lse.data_ptr(), BH, N, _stream())
+    _lib.check(rc, "hipie_attn_train_forward")
+    return out, lse
+
+
+@_timed("attn_train_bwd")
+def attn_train_backward(q_pair, k_pair, v96_pair, do96_pair, lse, delta):
+    """hipie_attn_train_backward: the forward's q', k' pairs, v and dO as (BH, N, 96) pairs (f16_pair(.., 96); dO scaled into fp16's range by the
+    caller), lse, delta = rowsum(dO * out) -> (dq' (BH, N, 224), dk (BH, N, 80), dv (BH, N, 80)) fp32, in the scale of the dO given"""
+    lib = _lib.load()
+    qh, ql = q_pair
+    kh, kl = k_pair
+    vh, vl = v96_pair
+    dh, dl = do96_pair
+    BH, N, _ = qh.shape
+    if tuple(vh.shape) != (BH, N, 96) or tuple(dh.shape) != (BH, N, 96) or tuple(lse.shape) != (BH, N) or tuple(delta.shape) != (BH, N):
+        raise RuntimeError("attn_train_backward: v / dO as (BH, N, 96) pairs, lse / delta (BH, N)")
+    for t in (qh, ql, kh, kl, vh, vl, dh, dl):
+        if t.dtype != torch.float16 or not t.is_contiguous() or not t.is_cuda:
+            raise RuntimeError("attn_train_backward: contiguous fp16 device planes")
+    lse, delta = lse.float().contiguous(), delta.float().contiguous()
+    dq = torch.empty(BH, N, 224, dtype=torch.float32, device=qh.device)
+    dk = torch.empty(BH, N, 80, dtype=torch.float32, device=qh.device)
+    dv = torch.empty(BH, N, 80, dtype=torch.float32, device=qh.device)
+    rc = lib.hipie_attn_train_backward(qh.data_ptr(), ql.data_ptr(), kh.data_ptr(), kl.data_ptr(), vh.data_ptr(), vl.data_ptr(), dh.data_ptr(),
+                                       dl.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), BH, N, _stream())
+    _lib.check(rc, "hipie_attn_train_backward")
+    return dq, dk, dv
+
+
 @_timed("fill_rows")
 def fill_rows(dst, rows, src_row):
     """dst[rows[i]] = src_row for every i (hipie_fill_rows): dst (R, W) contiguous device tensor, rows int32 (n,), src_row (W,) of dst's

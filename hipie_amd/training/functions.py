@@ -114,3 +114,37 @@ def split_linear(x, weight, bias, owner, key):
     if x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and K % 32 == 0 and N % 32 == 0 and x.numel() // K >= 256:
         return SplitLinearFunction.apply(x, weight, bias, owner, key)
     return torch.nn.functional.linear(x, weight, bias)
+
+
+class FusedAttentionFunction(torch.autograd.Function):
+    """softmax(q' k'^T) v with the decomposed rel-pos bias folded into q' / k' (net.vit_attention), forward and backward on
+    hipie_attn_train_forward / _backward (csrc/attn_train.hip): no (heads, N, N) tensor in HBM.  q' (BH, N, <= 224), k' (BH, N, <= 224) whose
+    columns from 80 on are CONSTANT (the key-axis indicators: they get a zero gradient), v (BH, N, 80), N a multiple of 128.
+    Saved for the backward: the fp16 pairs of q' and k' (the bytes of the fp32 operands), v, the output and the log-sum-exp row."""
+
+    @staticmethod
+    def forward(ctx, qa, ka, v):
+        qp, kp = ops.f16_pair(qa, 224), ops.f16_pair(ka, 224)
+        out, lse = ops.attn_train_forward(qp, kp, ops.f16_pair(v))
+        ctx.save_for_backward(qp[0], qp[1], kp[0], kp[1], v, out, lse)
+        ctx.cols = (qa.shape[-1], ka.shape[-1])
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        qh, ql, kh, kl, v, out, lse = ctx.saved_tensors
+        go = go.float().contiguous()
+        # dO enters the kernels as fp16 pairs: scaled by a power of two so that its largest entry sits in [8, 16) (a device scalar: no host
+        # wait) -- high enough for the pairs of dO and dS = P (dP - delta) to be normal fp16 numbers, low enough for |dP| <= 16 * 80 * max|v|
+        scale = torch.exp2(torch.floor(torch.log2(16.0 / go.abs().amax().clamp_min(1e-30))))
+        delta = (go * out).sum(-1) * scale
+        dq, dk, dv = ops.attn_train_backward((qh, ql), (kh, kl), ops.f16_pair(v, 96), ops.f16_pair(go, 96, scale), lse, delta)
+        inv = 1.0 / scale
+        cq, ck = ctx.cols
+        return dq[..., :cq] * inv, torch.nn.functional.pad(dk * inv, (0, ck - 80)), dv * inv
+
+
+def fused_attention_ok(qa, ka, v):
+    """shapes FusedAttentionFunction covers (the global blocks of the ViT at grids whose token count is a multiple of 128)"""
+    return (qa.is_cuda and qa.dtype == torch.float32 and v.shape[-1] == 80 and qa.shape[-1] <= 224 and ka.shape[-1] == qa.shape[-1]
+            and qa.shape[1] % 128 == 0 and qa.shape[0] <= 65535)

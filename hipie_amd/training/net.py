@@ -55,6 +55,13 @@ class HipBackend:
         return MSDeformAttnFunction.apply(value.contiguous(), ss, ls, loc.contiguous(), aw.contiguous(), 64)
 
     @staticmethod
+    def fused_attention(qa, ka, v):
+        """softmax(q' k'^T) v of a global ViT block on the fused split-fp16 kernels when the shape is covered (token count a multiple of 128,
+        head width 80, <= 224 operand columns), else None: the caller's materialised formulation runs (the 14 x 14 windows)"""
+        from .functions import FusedAttentionFunction, fused_attention_ok
+        return FusedAttentionFunction.apply(qa, ka, v) if fused_attention_ok(qa, ka, v) else None
+
+    @staticmethod
     def mask_einsum(mask_embed, mask_features):
         from .functions import mask_einsum
         return mask_einsum(mask_embed, mask_features)
@@ -208,6 +215,12 @@ def vit_attention(x, sd, p, heads, be=None):
     if FOLD_REL_POS:
         qa = torch.cat((q * hd ** -0.5, rel_h, rel_w), -1)
         ka = torch.cat((k, _key_axis_indicators(H, W, k.device, k.dtype).expand(B * heads, -1, -1)), -1)
+        fused = getattr(be, "fused_attention", None)
+        if fused is not None:
+            o = fused(qa, ka, v)                      # HipBackend: forward + backward without the (heads, HW, HW) tensors (csrc/attn_train.hip)
+            if o is not None:
+                o = o.view(B, heads, H, W, -1).permute(0, 2, 3, 1, 4).reshape(B, H, W, -1)
+                return _blin(o, sd, p + "proj.", be)
         attn = qa @ ka.transpose(-2, -1)
     else:
         attn = (q * hd ** -0.5) @ k.transpose(-2, -1)

@@ -465,6 +465,26 @@ int hipie_gemm_gather(const void* A, int64_t lda, int64_t a_rows, const int32_t*
 int hipie_vit_attn_split(const void* qkv, const void* tab_h, const void* tab_w, void* out, int B, int gh, int gw, int heads,
                          int hd, void* stream);
 
+/*
+ * Fused attention for the TRAINING step's global ViT blocks: O = softmax(q' k'^T) v and its gradients, no (heads, N, N) tensor
+ * in HBM.  Replaces Attention.forward between the qkv and proj Linears (hipie/backbone/vit.py:69-80) and its autograd, with
+ * add_decomposed_rel_pos (hipie/backbone/utils.py:96-125) folded into the operands by the caller:
+ *   q' = [scale q, rel_h(q, :), rel_w(q, :), 0..], k' = [k, onehot(key row), onehot(key column), 0..]   -- 224 columns; v, O: 80 columns
+ * Every operand is an fp16 pair given as two planes (hi = fp16(x), lo = fp16(x - hi), row-major, contiguous); products are three fp16 MFMAs
+ * accumulated in fp32 (the library's split form).  N a multiple of 128; BH = batch x heads <= 65535.
+ *   forward:   q', k' (BH, N, 224) pairs, v (BH, N, 80) pair -> out (BH, N, 80) f32, lse (BH, N) f32 (log of the softmax denominator + row max)
+ *   backward:  the same operands, v and dO (scaled by the caller into fp16's range) as (BH, N, 96) pairs (columns 80.. zero), lse, delta (BH, N)
+ *              f32 = rowsum(dO * out) -> dq' (BH, N, 224) f32 (columns 80.. are d rel_h | d rel_w), dk (BH, N, 80) f32, dv (BH, N, 80) f32
+ */
+int hipie_attn_train_forward(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* v_hi, const void* v_lo,
+                             void* out, void* lse, int BH, int N, void* stream);
+/* fp32 rows (row stride ldx elements) -> the two fp16 planes (rows x Cp, contiguous) of an operand of the two entries below: hi = fp16(s x),
+ * lo = fp16(s x - hi), columns C.. zero; s = *scale (a DEVICE float, e.g. the power of two that lifts dO into fp16's range) or 1 when NULL. */
+int hipie_to_f16_pair(const void* x, int64_t ldx, void* hi, void* lo, int64_t rows, int C, int Cp, const void* scale, void* stream);
+int hipie_attn_train_backward(const void* q_hi, const void* q_lo, const void* k_hi, const void* k_lo, const void* v_hi, const void* v_lo,
+                              const void* do_hi, const void* do_lo, const void* lse, const void* delta, void* dq, void* dk, void* dv,
+                              int BH, int N, void* stream);
+
 /* dst + rows[i] * ld_bytes <- the row_bytes bytes at src_row, for i < n_rows (negative entries are skipped): one constant row into a
  * listed set of rows.  Used to write the HL8 qkv BIAS row into the padding rows of a window-layout qkv buffer -- the qkv of a padding token
  * of window_partition is the bias, its LayerNorm output being zero (hipie/backbone/utils.py:29-37, vit.py:67-71).  16-byte units. */
