@@ -43,6 +43,8 @@ constexpr float kAtShift = 8.317766166719343f;     // 12 ln 2: probabilities ent
 #endif
 constexpr int AT_THREADS = 64 * AT_WAVES, AT_WG_ROWS = 16 * AT_WAVES, AT_NT = AT_TR / 16;
 
+constexpr float kAtDsScale = 16.f;                 // dS = P (dP - delta) is split as 16 dS: with max |dO| in [8, 16) a row of 4096 keys has
+                                                    // |dS| ~ 5e-3, whose lo half would be a subnormal; |dS| <= P (1 - P) range(dP) keeps 16 dS in range
 typedef f16x8 at_frag;
 
 __device__ __forceinline__ f32x4 at_mma3(at_frag ah, at_frag al, at_frag bh, at_frag bl, f32x4 c) {
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_bwd_kv_kernel(const f16
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         p[t][i] = __expf(acc[i] - lq[i]);
-        ds[t][i] = p[t][i] * (dp[i] - dq_[i]);
+        ds[t][i] = p[t][i] * (dp[i] - dq_[i]) * kAtDsScale;
       }
     }
 #pragma unroll
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_bwd_kv_kernel(const f16
     for (int i = 0; i < 4; ++i) {
       const long at = (bh * N + k0 + 4 * g + i) * AT_DV + 16 * j + c;
       dV[at] = dv[j][i] * (1.f / 4096.f);
-      dK[at] = dk[j][i];
+      dK[at] = dk[j][i] * (1.f / kAtDsScale);
     }
 }
 
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_bwd_q_kernel(const f16_
         dp = at_mma3(ah, al, dh[s], dl[s], dp);                           // dP^T = v dO^T, same layout
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ds[t][i] = __expf(acc[i] - lse) * (dp[i] - delta);
+      for (int i = 0; i < 4; ++i) ds[t][i] = __expf(acc[i] - lse) * (dp[i] - delta) * kAtDsScale;
     }
 #pragma unroll
     for (int tp = 0; tp < AT_NT; tp += 2) {
@@ -409,7 +411,9 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_bwd_q_kernel(const f16_
   }
   float* out = dQ + (bh * N + q0 + c) * AT_DQ + 4 * g;
 #pragma unroll
-  for (int j = 0; j < 14; ++j) *reinterpret_cast<float4*>(out + 16 * j) = make_float4(dq[j][0], dq[j][1], dq[j][2], dq[j][3]);
+  for (int j = 0; j < 14; ++j)
+    *reinterpret_cast<float4*>(out + 16 * j) = make_float4(dq[j][0] * (1.f / kAtDsScale), dq[j][1] * (1.f / kAtDsScale), dq[j][2] * (1.f / kAtDsScale),
+                                                           dq[j][3] * (1.f / kAtDsScale));
 }
 
 // fp32 rows -> the two fp16 planes of the operands above, zero-padded to Cp columns and optionally scaled by a DEVICE scalar (dO's power of

@@ -429,6 +429,69 @@ def test_train_step_losses_and_gradients_match_the_reference(dev):
     assert border[0][0] < (1e-3 if dev == "cpu" else 8e-2), border[:5]
 
 
+@pytest.mark.gpu
+def test_vit_backbone_full_token_grid_fused_attention_against_float64_attention():
+    """The fused attention of the global ViT blocks (csrc/attn_train.hip) INSIDE the training step's backbone at the full 64 x 64 token grid --
+    1024 x 1024 image, ViT-H width (16 heads x 80), 128 rel-pos columns, two windowed + two global blocks, weights as bench.py draws them
+    (the reference-generated fixture of the whole step, train_step_tiny.npz, has 16 x 16 token grids).  Forward features and the gradient of
+    every backbone parameter under a fixed cotangent, three ways: global blocks fused, materialised in fp32 (library GEMMs + softmax), and
+    materialised in float64 -- the yardstick.  The fused step has to be as close to it as the fp32 one is.  (The whole step's LOSSES are not
+    the right observable here: top-k point sampling and the matchers turn 1e-6 feature differences into discrete changes.)"""
+    import sys
+    import bench
+    from hipie_amd.config import HipieConfig, Precision
+    from hipie_amd.hipie_img import HIPIE_IMG
+    from hipie_amd.training import net
+    from hipie_amd.training.step import TrainStep
+    dev = torch.device("cuda", 0)
+    cfg = HipieConfig(vit_depth=4, vit_window_blocks=[0, 2])
+    torch.manual_seed(0)
+    model = HIPIE_IMG(cfg, Precision.parity(), device=dev)
+    bench.randomize_degenerate_inits(model)
+    model.finalize()
+    step = TrainStep(model)
+    sd, c = step.params(), step.cfg
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, 3, 1024, 1024, generator=g).to(dev)
+    results, calls = {}, []
+    fused = net.HipBackend.fused_attention
+
+    def counting(qa, ka, v):
+        o = fused(qa, ka, v)
+        calls.append((tuple(qa.shape), o is not None))
+        return o
+
+    def in_double(qa, ka, v):
+        if qa.shape[1] != 4096:
+            return None
+        return (torch.softmax(qa.double() @ ka.double().transpose(-2, -1), -1) @ v.double()).float()
+    cot = None
+    for mode, fn in (("fused", counting), ("fp32", lambda qa, ka, v: None), ("float64", in_double)):
+        net.HipBackend.fused_attention = staticmethod(fn)
+        try:
+            model.zero_grad(set_to_none=True)
+            with torch.enable_grad():
+                feats = net.vit_backbone(x, sd, "detr.detr.backbone.0.backbone.", c, step.be)
+                if cot is None:
+                    cot = {k: torch.randn(v.shape, generator=g).to(dev) for k, v in feats.items()}
+                sum((feats[k] * cot[k]).sum() for k in feats).backward()
+            results[mode] = ({k: v.detach().clone() for k, v in feats.items()},
+                             {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+        finally:
+            net.HipBackend.fused_attention = fused
+    # the two global blocks ran fused on (16 heads, 4096 tokens, 80 + 64 + 64 columns); the windowed ones (196-token windows) did not
+    assert [c_ for c_ in calls if c_[1]] == [((16, 4096, 208), True)] * 2 and len(calls) == 4
+
+    def worst(a, b):
+        return max(float((a[k] - b[k]).abs().max() / (b[k].abs().max() + 1e-30)) for k in b)
+    (ff, gf), (f32, g32), (fd, gd) = results["fused"], results["fp32"], results["float64"]
+    assert len(gd) > 40 and gf.keys() == gd.keys()
+    ef, e32, egf, eg32 = worst(ff, fd), worst(f32, fd), worst(gf, gd), worst(g32, gd)
+    print("ViT at the full token grid, against float64 attention: features fused %.1e / fp32 %.1e; worst of %d parameter gradients fused %.1e / fp32 %.1e"
+          % (ef, e32, len(gd), egf, eg32))
+    assert ef < max(2 * e32, 3e-6) and egf < max(4 * eg32, 1e-5), (ef, e32, egf, eg32)        # measured 9.0e-7 / 1.0e-6 and 2.5e-6 / 1.0e-6
+
+
 def test_train_step_has_no_host_path_by_default():
     """the default backend is the HIP library: on host tensors the step fails loudly instead of computing something else"""
     z, meta, model, step, batch, targets = _train_step_case("cpu")
