@@ -62,6 +62,8 @@ SIGNATURES = {
     "hipie_softmax_hl8": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_f, c_p],
     "hipie_attn_f32": [c_p] * 5 + [c_i] * 5 + [c_l] * 6 + [c_f, c_p],
     "hipie_attn_split": [c_p] * 5 + [c_i] * 5 + [c_l] * 6 + [c_f, c_p],
+    "hipie_attn_f32_rows": [c_p] * 5 + [c_i] * 5 + [c_l] * 6 + [c_f, c_p],
+    "hipie_attn_split_rows": [c_p] * 5 + [c_i] * 5 + [c_l] * 6 + [c_f, c_p],
     "hipie_conv3x3_split": [c_p, c_l, c_p, c_p, c_p, c_l, c_l] + [c_i] * 6 + [c_p],
     "hipie_ffn_fused": [c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p],
     "hipie_topk": [c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p],

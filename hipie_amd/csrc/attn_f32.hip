@@ -18,6 +18,7 @@ namespace hipie {
 struct AFParams {
   const float *q, *k, *v;
   const unsigned char* key_mask;      // (B, Nk), 1 = attend; or null
+  const unsigned char* query_mask;    // (B, Nq, Nk), 1 = attend: a mask per QUERY row (MaskCLIP's mask tokens); or null
   float* out;                         // (B, Nq, H * HD)
   int B, H, Nq, Nk;
   long q_sb, q_st, k_sb, k_st, v_sb, v_st;      // batch / token strides in elements; a head is HD contiguous elements at h * HD
@@ -37,6 +38,7 @@ __global__ __launch_bounds__(128) void attn_f32_kernel(const AFParams p) {
   const int qi = qt * 128 + tid;
   const bool live = qi < p.Nq;
   const float* qrow = p.q + b * p.q_sb + (long)min(qi, p.Nq - 1) * p.q_st + h * HD;
+  const unsigned char* qm = p.query_mask ? p.query_mask + ((long)b * p.Nq + min(qi, p.Nq - 1)) * p.Nk : nullptr;
   float q[HD], o[HD];
 #pragma unroll
   for (int d = 0; d < HD; d += 4) {
@@ -69,6 +71,7 @@ __global__ __launch_bounds__(128) void attn_f32_kernel(const AFParams p) {
         a1 = fmaf(q[d + 4], k5.x, a1); a1 = fmaf(q[d + 5], k5.y, a1); a1 = fmaf(q[d + 6], k5.z, a1); a1 = fmaf(q[d + 7], k5.w, a1);
       }
       s[j] = (a0 + a1) + km[j];
+      if (qm && k0 + j < p.Nk && qm[k0 + j] == 0) s[j] = -INFINITY;             // this row may not see key k0 + j
       mx = fmaxf(mx, s[j]);
     }
     if (mx > m_run) {                                  // per-lane branch: the rescale is rare after the first tiles
@@ -100,9 +103,9 @@ __global__ __launch_bounds__(128) void attn_f32_kernel(const AFParams p) {
 
 }  // namespace hipie
 
-extern "C" int hipie_attn_f32(const float* q, const float* k, const float* v, const unsigned char* key_mask, float* out, int B, int H, int Nq,
-                              int Nk, int head_dim, int64_t q_sb, int64_t q_st, int64_t k_sb, int64_t k_st, int64_t v_sb, int64_t v_st,
-                              float scale, void* stream) {
+static int attn_f32_launch(const float* q, const float* k, const float* v, const unsigned char* key_mask, const unsigned char* query_mask,
+                           float* out, int B, int H, int Nq, int Nk, int head_dim, int64_t q_sb, int64_t q_st, int64_t k_sb, int64_t k_st,
+                           int64_t v_sb, int64_t v_st, float scale, void* stream) {
   using namespace hipie;
   HIPIE_REQUIRE(q && k && v && out, "attn_f32: null pointer");
   HIPIE_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0, "attn_f32: bad shape B=%d H=%d Nq=%d Nk=%d", B, H, Nq, Nk);
@@ -110,7 +113,7 @@ extern "C" int hipie_attn_f32(const float* q, const float* k, const float* v, co
   HIPIE_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0 && ((q_sb | q_st | k_sb | k_st | v_sb | v_st) & 3) == 0,
                 "attn_f32: pointers must be 16-byte aligned and strides multiples of 4 elements");
   AFParams p;
-  p.q = q; p.k = k; p.v = v; p.key_mask = key_mask; p.out = out;
+  p.q = q; p.k = k; p.v = v; p.key_mask = key_mask; p.query_mask = query_mask; p.out = out;
   p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk;
   p.q_sb = q_sb; p.q_st = q_st; p.k_sb = k_sb; p.k_st = k_st; p.v_sb = v_sb; p.v_st = v_st;
   p.scale_log2e = scale * 1.4426950408889634f;
@@ -118,4 +121,16 @@ extern "C" int hipie_attn_f32(const float* q, const float* k, const float* v, co
   if (head_dim == 32) hipLaunchKernelGGL(attn_f32_kernel<32>, dim3(grid), dim3(128), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(attn_f32_kernel<64>, dim3(grid), dim3(128), 0, (hipStream_t)stream, p);
   return check_launch("attn_f32");
+}
+
+extern "C" int hipie_attn_f32(const float* q, const float* k, const float* v, const unsigned char* key_mask, float* out, int B, int H, int Nq,
+                              int Nk, int head_dim, int64_t q_sb, int64_t q_st, int64_t k_sb, int64_t k_st, int64_t v_sb, int64_t v_st,
+                              float scale, void* stream) {
+  return attn_f32_launch(q, k, v, key_mask, nullptr, out, B, H, Nq, Nk, head_dim, q_sb, q_st, k_sb, k_st, v_sb, v_st, scale, stream);
+}
+
+extern "C" int hipie_attn_f32_rows(const float* q, const float* k, const float* v, const unsigned char* query_mask, float* out, int B, int H,
+                                   int Nq, int Nk, int head_dim, int64_t q_sb, int64_t q_st, int64_t k_sb, int64_t k_st, int64_t v_sb,
+                                   int64_t v_st, float scale, void* stream) {
+  return attn_f32_launch(q, k, v, nullptr, query_mask, out, B, H, Nq, Nk, head_dim, q_sb, q_st, k_sb, k_st, v_sb, v_st, scale, stream);
 }

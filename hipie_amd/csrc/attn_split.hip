@@ -22,6 +22,7 @@ namespace hipie {
 struct ASParams {
   const float *q, *k, *v;
   const unsigned char* key_mask;      // (B, Nk), 1 = attend; or null
+  const unsigned char* query_mask;    // (B, Nq, Nk), 1 = attend: a mask per QUERY row (MaskCLIP's mask tokens); or null
   float* out;                         // (B, Nq, H * HD)
   int B, H, Nq, Nk;
   long q_sb, q_st, k_sb, k_st, v_sb, v_st;
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const ASParams p) {
   const int b = bh / p.H, h = bh % p.H;
   const int qi = qt * 128 + wave * 32 + li;
   const float* qrow = p.q + b * p.q_sb + (long)min(qi, p.Nq - 1) * p.q_st + h * HD;
+  const unsigned char* qm = p.query_mask ? p.query_mask + ((long)b * p.Nq + min(qi, p.Nq - 1)) * p.Nk : nullptr;     // this lane's query row
 
   // ---- Q fragments (B operand): lane (query li, half hi) holds head-dim group 2 ks + hi, pre-scaled into the exp2 domain, as an fp16 pair ----
   frag qh[KS], ql[KS];
@@ -130,7 +132,9 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const ASParams p) {
     for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        S[blk][r] += km[32 * blk + crow(r, hi)];
+        const int kk = 32 * blk + crow(r, hi);
+        S[blk][r] += km[kk];
+        if (qm && k0 + kk < p.Nk && qm[k0 + kk] == 0) S[blk][r] = -INFINITY;                 // this row may not see key k0 + kk
         mx = fmaxf(mx, S[blk][r]);
       }
     mx = as_xhalf_max(mx);
@@ -191,7 +195,8 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const ASParams p) {
 
 }  // namespace hipie
 
-extern "C" int hipie_attn_split(const float* q, const float* k, const float* v, const unsigned char* key_mask, float* out, int B, int H, int Nq,
+static int attn_split_launch(const float* q, const float* k, const float* v, const unsigned char* key_mask, const unsigned char* query_mask,
+                             float* out, int B, int H, int Nq,
                                 int Nk, int head_dim, int64_t q_sb, int64_t q_st, int64_t k_sb, int64_t k_st, int64_t v_sb, int64_t v_st,
                                 float scale, void* stream) {
   using namespace hipie;
@@ -201,7 +206,7 @@ extern "C" int hipie_attn_split(const float* q, const float* k, const float* v, 
   HIPIE_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0 && ((q_sb | q_st | k_sb | k_st | v_sb | v_st) & 3) == 0,
                 "attn_split: pointers must be 16-byte aligned and strides multiples of 4 elements");
   ASParams p;
-  p.q = q; p.k = k; p.v = v; p.key_mask = key_mask; p.out = out;
+  p.q = q; p.k = k; p.v = v; p.key_mask = key_mask; p.query_mask = query_mask; p.out = out;
   p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk;
   p.q_sb = q_sb; p.q_st = q_st; p.k_sb = k_sb; p.k_st = k_st; p.v_sb = v_sb; p.v_st = v_st;
   p.scale_log2e = scale * 1.4426950408889634f;
@@ -209,4 +214,16 @@ extern "C" int hipie_attn_split(const float* q, const float* k, const float* v, 
   if (head_dim == 32) hipLaunchKernelGGL(attn_split_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(attn_split_kernel<64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("attn_split");
+}
+
+extern "C" int hipie_attn_split(const float* q, const float* k, const float* v, const unsigned char* key_mask, float* out, int B, int H, int Nq,
+                                int Nk, int head_dim, int64_t q_sb, int64_t q_st, int64_t k_sb, int64_t k_st, int64_t v_sb, int64_t v_st,
+                                float scale, void* stream) {
+  return attn_split_launch(q, k, v, key_mask, nullptr, out, B, H, Nq, Nk, head_dim, q_sb, q_st, k_sb, k_st, v_sb, v_st, scale, stream);
+}
+
+extern "C" int hipie_attn_split_rows(const float* q, const float* k, const float* v, const unsigned char* query_mask, float* out, int B, int H,
+                                     int Nq, int Nk, int head_dim, int64_t q_sb, int64_t q_st, int64_t k_sb, int64_t k_st, int64_t v_sb,
+                                     int64_t v_st, float scale, void* stream) {
+  return attn_split_launch(q, k, v, nullptr, query_mask, out, B, H, Nq, Nk, head_dim, q_sb, q_st, k_sb, k_st, v_sb, v_st, scale, stream);
 }

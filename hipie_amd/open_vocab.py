@@ -121,6 +121,11 @@ class ResidualAttentionBlock(nn.Module):
         N, Q, D = xm.shape
         H, hd = self.heads, D // self.heads
         q = self._q_only(self.ln_1(xm)).view(N, Q, H, hd)
+        if xm.is_cuda and hd in (32, 64) and q.dtype == torch.float32 and k.dtype == torch.float32 and v.dtype == torch.float32:
+            # one launch per layer (hipie_attn_split_rows: the mask read per query row) instead of two batched GEMMs, a masked_fill, a softmax
+            # and their transposes over the (N, H, Q, T) logits
+            om = ops.attn_f32_rows(q, k, v, hd ** -0.5, ~blocked, split=True)
+            return self._mlp(xm + self.attn.out_proj(om))
         sc = (q.transpose(1, 2).float() * hd ** -0.5) @ k.permute(0, 2, 3, 1).float()   # (N, H, Q, T)
         sc = sc.masked_fill(blocked[:, None], float("-inf"))
         om = (sc.softmax(-1) @ v.transpose(1, 2).float()).transpose(1, 2).reshape(N, Q, D)

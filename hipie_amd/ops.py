@@ -309,6 +309,27 @@ def attn_f32(q, k, v, scale, key_mask=None):
     return _small_attn("hipie_attn_f32", q, k, v, scale, key_mask)
 
 
+@_timed("attn_rows")
+def attn_f32_rows(q, k, v, scale, query_mask, split=False):
+    """hipie_attn_f32_rows (exact fp32 FMA) / hipie_attn_split_rows (split=True: matrix pipe, fp32-class): attention with a mask per query row --
+    query_mask (B, Nq, Nk) bool / uint8, True = may attend"""
+    lib = _lib.load()
+    B, Nq, H, hd = q.shape
+    Nk = k.shape[1]
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        if not t.is_cuda or t.dtype != torch.float32 or t.stride(-1) != 1 or (H > 1 and t.stride(2) != hd):
+            raise RuntimeError("attn_f32_rows: %s must be an fp32 device (B, N, H, hd) with hd contiguous and heads hd apart" % n)
+    if tuple(query_mask.shape) != (B, Nq, Nk):
+        raise RuntimeError("attn_f32_rows: query_mask (B, Nq, Nk), got %s" % (tuple(query_mask.shape),))
+    qm = query_mask.to(torch.uint8).contiguous()
+    out = torch.empty(B, Nq, H * hd, dtype=torch.float32, device=q.device)
+    fn = lib.hipie_attn_split_rows if split else lib.hipie_attn_f32_rows
+    rc = fn(q.data_ptr(), k.data_ptr(), v.data_ptr(), qm.data_ptr(), out.data_ptr(), B, H, Nq, Nk, hd, q.stride(0), q.stride(1),
+            k.stride(0), k.stride(1), v.stride(0), v.stride(1), float(scale), _stream())
+    _lib.check(rc, "hipie_attn_split_rows" if split else "hipie_attn_f32_rows")
+    return out
+
+
 @_timed("attn_split")
 def attn_split(q, k, v, scale, key_mask=None):
     """hipie_attn_split: the same attention on the matrix pipe at fp32-class accuracy (operands split into fp16 pairs in the kernel, three

@@ -355,3 +355,23 @@ def test_post_maskclip_mixed_sizes_match_single_image_runs():
         assert torch.equal(got.pred_classes[:n], alone.pred_classes[:n])
         assert rel_err(got.scores.cpu(), alone.scores.cpu()) < 1e-4
         assert rel_err(got.pred_boxes.tensor[:n].cpu(), alone.pred_boxes.tensor[:n].cpu()) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,Nq,Nk,hd", [(2, 16, 150, 577, 64), (1, 3, 5, 33, 32), (3, 2, 130, 64, 64)])
+def test_attn_f32_rows_mask_per_query_row(B, H, Nq, Nk, hd):
+    """hipie_attn_f32_rows / hipie_attn_split_rows (the mask tokens' attention of MaskCLIP: every query row has its own set of visible keys) against
+    softmax(masked_fill(q k^T, -inf)) v in double; q / k / v as column blocks of one projection output (strided views); key 0 always visible."""
+    from hipie_amd import ops
+    g = torch.Generator().manual_seed(B * 7 + Nq)
+    qkv = torch.randn(B, max(Nq, Nk), 3, H, hd, generator=g, dtype=torch.float64)
+    q, k, v = qkv[:, :Nq, 0], qkv[:, :Nk, 1], qkv[:, :Nk, 2]
+    vis = torch.rand(B, Nq, Nk, generator=g) < 0.3
+    vis[:, :, 0] = True
+    sc = (q.transpose(1, 2) * hd ** -0.5) @ k.permute(0, 2, 3, 1)
+    want = (sc.masked_fill(~vis[:, None], float("-inf")).softmax(-1) @ v.transpose(1, 2)).transpose(1, 2).reshape(B, Nq, H * hd)
+    dq = qkv.float().cuda()
+    for split, tol in ((False, 2e-6), (True, 4e-6)):
+        got = ops.attn_f32_rows(dq[:, :Nq, 0], dq[:, :Nk, 1], dq[:, :Nk, 2], hd ** -0.5, vis.cuda(), split=split)
+        err = float((got.cpu().double() - want).abs().max() / want.abs().max())
+        assert err < tol, (split, err)
