@@ -114,6 +114,58 @@ def synthetic_clip_tokenizer(context=77, vocab=49408):
     return tok
 
 
+def train_step_leg(dev, steps=3):
+    """SURVEY row f-4, reported beside the headline: ONE TRAINING STEP (hipie_amd/training/step.py: the reference's coco_forward + three DINO
+    criterion calls + the MaskDINO criterion + backward) at the reference's training batch -- ViT-H, 1024 x 1024, 2 images per GPU
+    (configs/training/vit_huge_32g.yaml), the 80-class caption, 8 synthetic targets per image, DN_NUMBER 100, random-init weights.  Two
+    untimed steps (allocator pools), then `steps` timed ones.  Never the headline; tools/bench_train_step.py is the same measurement."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    from bench_train_step import targets_for
+    from hipie_amd.config import HipieConfig, Precision
+    from hipie_amd.hipie_img import HIPIE_IMG
+    from hipie_amd.training.step import TrainStep
+    cfg = HipieConfig.vit_huge()
+    torch.manual_seed(0)
+    model = HIPIE_IMG(cfg, Precision.parity(), device=dev)
+    randomize_degenerate_inits(model)
+    model.finalize()
+    find = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = False        # MIOpen's exhaustive search over the step's forward AND backward convolutions takes ~2 min
+    for p in model.text_encoder.parameters():
+        p.requires_grad_(False)
+    B, size, L = 2, 1024, 194
+    batch = synth_batch(cfg, B, size, 80, L, dev)
+    targets = targets_for(B, 6, 2, size, L, dev)
+    step = TrainStep(model)
+    torch.cuda.reset_peak_memory_stats()
+    fw, bw = [], []
+    for it in range(steps + 2):
+        model.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.enable_grad():
+            losses = step.loss_dict(batch, targets)
+            total = sum(losses.values())
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        total.backward()
+        torch.cuda.synchronize()
+        if it >= 2:
+            fw.append(t1 - t0)
+            bw.append(time.perf_counter() - t1)
+    f, b = sum(fw) / len(fw), sum(bw) / len(bw)
+    res = {"value": round(B / (f + b), 3), "unit": "images/sec per GPU", "ms_per_step": round((f + b) * 1e3, 1), "forward_ms": round(f * 1e3, 1),
+           "backward_ms": round(b * 1e3, 1), "steps": steps, "images_per_step": B, "loss_entries": len(losses), "finite": bool(torch.isfinite(total)),
+           "peak_memory_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+           "what": "forward (loss dictionary) + backward of one training step, ViT-H, 1024^2, 2 images per GPU, random-init weights, synthetic targets; "
+                   "no optimizer step (hipie_amd/training/step.py::train_iteration adds clipping + AdamW); pinned against the reference's own "
+                   "coco_forward + criteria + backward by tests/golden/train_step_tiny.npz"}
+    del model, step, losses, total
+    torch.cuda.empty_cache()
+    torch.backends.cudnn.benchmark = find
+    return res
+
+
 def e2e_leg(model, batch, steps, dev):
     """`model(batched_inputs)` as the reference's evaluation timer sees it (detectron2/evaluation/evaluator.py:157-161): the images arrive
     as HOST tensors (uint8, what the dataset mapper produces), go to the device, and the call returns the FULL post-processed results
@@ -370,6 +422,7 @@ def main():
                          "shipped depths; fast: single-fp16 operands (out of tolerance); parity: fp32 library GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-leg", action="store_true", help="skip parity_err and the fast-policy timing (rank 0, N = 1)")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the training-step figure (`train_step`: SURVEY f-4; rank 0, N = 1, ~25 s)")
     ap.add_argument("--graph", action="store_true", help="capture the forward once into a hipGraph and replay it (same rate as "
                     "eager: the step is GPU-bound; the round-2 replay fault was torch.topk, replaced by hipie_topk -- DESIGN.md "
                     "section 9)")
@@ -690,6 +743,15 @@ def main():
         except Exception as e:          # never lose the measured line to the side legs
             print("bench: parity leg failed: %r" % (e,), file=sys.stderr)
 
+    train_leg = None
+    if rank == 0 and world == 1 and not args.no_train_leg and not args.timed_only and args.model == "vit_huge" and graph is None:
+        try:
+            model = None
+            torch.cuda.empty_cache()
+            train_leg = train_step_leg(dev)
+        except Exception as e:          # never lose the measured line to the side legs
+            print("bench: training-step leg failed: %r" % (e,), file=sys.stderr)
+
     if rank == 0:
         std = args.model == "vit_huge" and args.batch == 8 and args.size == 1024
         pmc = {}
@@ -764,6 +826,7 @@ def main():
             "postprocess_clip_ms": None if post_clip_ms is None else round(post_clip_ms, 2),
             "value_e2e": e2e,
             "value_e2e_clip": e2e_clip,
+            "train_step": train_leg,
             "parity_err": parity_err,
             "pad_max_4096": pad_max,
             "fast_policy": other,
