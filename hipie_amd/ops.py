@@ -972,7 +972,7 @@ def to_hl8_t(x, pad_to=32, scale=1.0):
 def f16_pair(x, cols=None, scale=None):
     """fp32 (.., C) -> the two contiguous fp16 planes (hi = fp16(s x), lo = fp16(s x - hi)) of the fused training attention's operands, the
     last dimension zero-padded to `cols` (a multiple of 8); s = `scale`, a one-element DEVICE tensor (no host wait), or 1; values beyond the
-    fp16 range saturate (hl_split).  One pass on the device (hipie_to_f16_pair); the torch formulation on the host."""
+    fp16 range saturate (hl_split).  One pass on the device (hipie_to_f16_pair)."""
     C = x.shape[-1]
     Cp = C if cols is None else max(cols, C)
     if x.is_cuda and x.dtype == torch.float32 and Cp % 8 == 0:
@@ -986,12 +986,8 @@ def f16_pair(x, cols=None, scale=None):
         rc = lib.hipie_to_f16_pair(x2.data_ptr(), x2.stride(0) if x2.shape[0] > 1 else C, hi.data_ptr(), lo.data_ptr(), x2.shape[0], C, Cp, sc, _stream())
         _lib.check(rc, "hipie_to_f16_pair")
         return hi, lo
-    if Cp > C:
-        x = torch.nn.functional.pad(x, (0, Cp - C))
-    x = x.float() * (1.0 if scale is None else scale)
-    x = x.clamp(-65504.0, 65504.0)
-    hi = x.half()
-    return hi.contiguous(), (x - hi.float()).half().contiguous()
+    raise RuntimeError("f16_pair: an fp32 device tensor and a column count that is a multiple of 8 (got %s %s on %s, %d columns)"
+                       % (x.dtype, tuple(x.shape), x.device, Cp))
 
 
 @_timed("attn_train_fwd")

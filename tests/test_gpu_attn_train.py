@@ -67,18 +67,26 @@ def test_attn_train_function_gradients_vs_autograd_in_double(BH, H, W, gscale):
 
 @gpu
 def test_f16_pair_kernel_matches_the_torch_formulation():
-    """hipie_to_f16_pair (pad + optional device scale + hi / lo split in one pass) == the host formulation of ops.f16_pair, bit for bit; values
+    """hipie_to_f16_pair (pad + optional device scale + hi / lo split in one pass) == the same arithmetic in torch on the host, bit for bit; values
     beyond fp16's range saturate; a row-strided input view"""
     from hipie_amd import ops
+
+    def host_pair(x, cols, scale=None):
+        x = torch.nn.functional.pad(x, (0, cols - x.shape[-1])).float() * (1.0 if scale is None else scale)
+        x = x.clamp(-65504.0, 65504.0)
+        hi = x.half()
+        return hi, (x - hi.float()).half()
     g = torch.Generator().manual_seed(2)
     x = torch.randn(3, 50, 208, generator=g) * torch.logspace(-6, 3, 208)
     x[0, 0, 0], x[0, 0, 1] = 1e6, -1e6
     for cols, scale in ((224, None), (208, None), (224, torch.tensor([2.0 ** -7]))):
-        want = ops.f16_pair(x, cols, scale)
+        want = host_pair(x, cols, scale)
         got = ops.f16_pair(x.cuda(), cols, None if scale is None else scale.cuda())
         assert got[0].shape[-1] == cols and torch.equal(got[0].cpu(), want[0]) and torch.equal(got[1].cpu(), want[1])
+    with pytest.raises(RuntimeError):
+        ops.f16_pair(x, 224)                                   # no host path
     wide = torch.randn(40, 96, generator=g)
-    want = ops.f16_pair(wide[:, :80], 96)
+    want = host_pair(wide[:, :80], 96)
     got = ops.f16_pair(wide.cuda()[:, :80], 96)
     assert torch.equal(got[0].cpu(), want[0]) and torch.equal(got[1].cpu(), want[1])
     assert float(got[0][:, 80:].abs().max()) == 0.0
