@@ -17,10 +17,12 @@
 // slot (g, j).  Two C tiles of the logits therefore ARE one operand of the next product over keys / queries (slots j = 0..3 from tile t,
 // 4..7 from tile t + 1: keys 16 t + 4 g + j), and the other operand reads the same 2 x 4 ROWS of a row-major LDS tile with ds_read_b64_tr_b16.
 //
-//   forward  (grid N/128 x BH, 8 waves x 16 queries):  S^T = K' Q'^T per 64-key tile, online softmax per query column, O^T += V^T P^T
-//   backward 1 (grid N/128 x BH, 8 waves x 16 keys):   per 64-query tile  S = Q' K'^T, P = exp(S - lse), dP = dO V^T, dS = P (dP - delta),
+//   forward  (grid N/128 x BH, 8 waves x 16 queries):  S^T = K' Q'^T per 32-key tile, online softmax per query column, O^T += V^T P^T
+//   backward 1 (grid N/128 x BH, 8 waves x 16 keys):   per 32-query tile  S = Q' K'^T, P = exp(S - lse), dP = dO V^T, dS = P (dP - delta),
 //                                                      dV += P^T dO, dK += dS^T Q'[:, :80]
-//   backward 2 (grid N/128 x BH, 8 waves x 16 queries): per 64-key tile    S^T, P^T, dP^T = V dO^T, dS^T, dQ'^T += K'^T dS^T
+//   backward 2 (grid N/128 x BH, 8 waves x 16 queries): per 32-key tile    S^T, P^T, dP^T = V dO^T, dS^T, dQ'^T += K'^T dS^T
+// All three are software-pipelined: the next tile travels global -> registers while the current one is computed on, then into the other LDS
+// buffer; one barrier per tile.
 #include "common.h"
 #include "mfma.h"
 
@@ -89,33 +91,28 @@ __device__ __forceinline__ void at_block(int BH, int per_head, long& bh, int& bl
   }
 }
 
-// rows [r0, r0 + 64) x `cols` halfs of a (.., ld)-strided global matrix -> row-major LDS tile with row stride `ls` (16-byte chunks)
-__device__ __forceinline__ void at_stage_rows(f16_t* dst, int ls, const f16_t* src, long ld, int cols, int tid, int nthreads) {
-  const int cpr = cols / 8;
-  for (int idx = tid; idx < AT_TR * cpr; idx += nthreads) {
-    const int r = idx / cpr, ch = idx % cpr;
-    *reinterpret_cast<at_frag*>(dst + r * ls + ch * 8) = *reinterpret_cast<const at_frag*>(src + r * ld + ch * 8);
-  }
-}
-
-// the same staging in two halves, for the software pipeline of the backward kernels: global -> registers (in flight while the current tile is
+// Staging of a streamed tile (AT_TR rows x COLS halfs of a row-major global matrix -> row-major LDS tile with a padded row stride) in two halves,
+// for the software pipeline of all three kernels: global -> registers (in flight while the current tile is
 // computed on), registers -> the OTHER LDS buffer, one barrier per tile.  (Keeping each thread's LDS offsets in registers instead of
 // recomputing idx / chunks-per-row every tile removes 130 VALU instructions per tile and is 15 % SLOWER -- measured on one box; not kept.)
 template <int COLS> struct AtStage {
   static constexpr int kChunks = AT_TR * (COLS / 8), kPer = (kChunks + AT_THREADS - 1) / AT_THREADS;
   at_frag r[kPer];
+  // Branch-free on purpose: threads beyond the tile's last chunk re-load and re-store that chunk (same value, same address).  With the
+  // loads under `if (idx < kChunks)` the compiler put an s_waitcnt vmcnt(0) between them -- six serialised L2 round trips at the top of
+  // every tile instead of six loads in flight behind the compute.
   __device__ __forceinline__ void fetch(const f16_t* src, long ld, int tid) {
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
-      const int idx = tid + k * AT_THREADS;
-      if (idx < kChunks) r[k] = *reinterpret_cast<const at_frag*>(src + (idx / (COLS / 8)) * ld + (idx % (COLS / 8)) * 8);
+      const int idx = min(tid + k * AT_THREADS, kChunks - 1);
+      r[k] = *reinterpret_cast<const at_frag*>(src + (idx / (COLS / 8)) * ld + (idx % (COLS / 8)) * 8);
     }
   }
   __device__ __forceinline__ void commit(f16_t* dst, int ls, int tid) const {
 #pragma unroll
     for (int k = 0; k < kPer; ++k) {
-      const int idx = tid + k * AT_THREADS;
-      if (idx < kChunks) *reinterpret_cast<at_frag*>(dst + (idx / (COLS / 8)) * ls + (idx % (COLS / 8)) * 8) = r[k];
+      const int idx = min(tid + k * AT_THREADS, kChunks - 1);
+      *reinterpret_cast<at_frag*>(dst + (idx / (COLS / 8)) * ls + (idx % (COLS / 8)) * 8) = r[k];
     }
   }
 };
@@ -125,10 +122,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_fwd_kernel(const f16_t*
                                                              const f16_t* __restrict__ Vh, const f16_t* __restrict__ Vl,
                                                              float* __restrict__ O, float* __restrict__ LSE, int N, int BH) {
   extern __shared__ __attribute__((aligned(16))) char at_smem[];
-  f16_t* sKh = reinterpret_cast<f16_t*>(at_smem);              // [AT_TR][AT_KS]
-  f16_t* sKl = sKh + AT_TR * AT_KS;
-  f16_t* sVh = sKl + AT_TR * AT_KS;                                // [AT_TR][AT_VS]
-  f16_t* sVl = sVh + AT_TR * AT_VS;
+  constexpr int kBuf = 2 * AT_TR * AT_KS + 2 * AT_TR * AT_VS;                   // halfs per buffer: k' pair, v pair
+  f16_t* sbase = reinterpret_cast<f16_t*>(at_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, g = lane >> 4;
   long bh;
   int blk;
@@ -147,13 +142,31 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_fwd_kernel(const f16_t*
 #pragma unroll
   for (int j = 0; j < 5; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, lsum = 0.f;
-  for (int kb = 0; kb < N; kb += AT_TR) {
-    __syncthreads();
-    at_stage_rows(sKh, AT_KS, Kh + (bh * N + kb) * AT_DQ, AT_DQ, AT_DQ, tid, AT_THREADS);
-    at_stage_rows(sKl, AT_KS, Kl + (bh * N + kb) * AT_DQ, AT_DQ, AT_DQ, tid, AT_THREADS);
-    at_stage_rows(sVh, AT_VS, Vh + (bh * N + kb) * AT_DV, AT_DV, AT_DV, tid, AT_THREADS);
-    at_stage_rows(sVl, AT_VS, Vl + (bh * N + kb) * AT_DV, AT_DV, AT_DV, tid, AT_THREADS);
-    __syncthreads();
+  AtStage<AT_DQ> fkh, fkl;
+  AtStage<AT_DV> fvh, fvl;
+  auto fetch = [&](int kb) {
+    fkh.fetch(Kh + (bh * N + kb) * AT_DQ, AT_DQ, tid);
+    fkl.fetch(Kl + (bh * N + kb) * AT_DQ, AT_DQ, tid);
+    fvh.fetch(Vh + (bh * N + kb) * AT_DV, AT_DV, tid);
+    fvl.fetch(Vl + (bh * N + kb) * AT_DV, AT_DV, tid);
+  };
+  auto commit = [&](int buf) {
+    f16_t* b = sbase + buf * kBuf;
+    fkh.commit(b, AT_KS, tid);
+    fkl.commit(b + AT_TR * AT_KS, AT_KS, tid);
+    fvh.commit(b + 2 * AT_TR * AT_KS, AT_VS, tid);
+    fvl.commit(b + 2 * AT_TR * AT_KS + AT_TR * AT_VS, AT_VS, tid);
+  };
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (int kb = 0, it = 0; kb < N; kb += AT_TR, ++it) {
+    const bool more = kb + AT_TR < N;
+    if (more) fetch(kb + AT_TR);
+    const f16_t* sKh = sbase + (it & 1) * kBuf;
+    const f16_t* sKl = sKh + AT_TR * AT_KS;
+    const f16_t* sVh = sKl + AT_TR * AT_KS;
+    const f16_t* sVl = sVh + AT_TR * AT_VS;
     f32x4 acc[AT_NT];
 #pragma unroll
     for (int t = 0; t < AT_NT; ++t) {
@@ -195,6 +208,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_fwd_kernel(const f16_t*
         o[j] = at_mma3(vh, vl, ph, pl, o[j]);                             // O^T: rows = d 16 j + 4 g + i, column = query c
       }
     }
+    if (more) commit((it & 1) ^ 1);
+    __syncthreads();
   }
   float ltot = lsum;
   ltot += __shfl_xor(ltot, 16);
@@ -248,8 +263,10 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_bwd_kv_kernel(const f16
     fql.fetch(Ql + qrow, AT_DQ, tid);
     fdh.fetch(Dh + drow, AT_DVP, tid);
     fdl.fetch(Dl + drow, AT_DVP, tid);
-    if (tid < AT_TR) fstat = LSE[bh * N + qb + tid];
-    else if (tid < 2 * AT_TR) fstat = DELTA[bh * N + qb + tid - AT_TR];
+    {
+      const int i = min(tid, 2 * AT_TR - 1);                                // branch-free: threads beyond 2 AT_TR repeat the last entry
+      fstat = (i < AT_TR ? LSE : DELTA)[bh * N + qb + (i < AT_TR ? i : i - AT_TR)];
+    }
   };
   auto commit = [&](int buf) {
     f16_t* b = sbase + buf * kBuf;
@@ -257,7 +274,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_bwd_kv_kernel(const f16
     fql.commit(b + AT_TR * AT_KS, AT_KS, tid);
     fdh.commit(b + 2 * AT_TR * AT_KS, AT_DS, tid);
     fdl.commit(b + 2 * AT_TR * AT_KS + AT_TR * AT_DS, AT_DS, tid);
-    if (tid < 2 * AT_TR) reinterpret_cast<float*>(b + 2 * AT_TR * AT_KS + 2 * AT_TR * AT_DS)[tid] = fstat;
+    reinterpret_cast<float*>(b + 2 * AT_TR * AT_KS + 2 * AT_TR * AT_DS)[min(tid, 2 * AT_TR - 1)] = fstat;
   };
   fetch(0);
   commit(0);
@@ -441,7 +458,7 @@ __global__ __launch_bounds__(256) void to_f16_pair_kernel(const float* __restric
 
 constexpr size_t kAtBwdKvLds = 2 * ((size_t)(2 * AT_TR * AT_KS + 2 * AT_TR * AT_DS) * sizeof(f16_t) + 2 * AT_TR * sizeof(float));   // two buffers
 constexpr size_t kAtBwdQLds = 2 * (size_t)(2 * AT_TR * AT_KS + 2 * AT_TR * AT_DS) * sizeof(f16_t);
-constexpr size_t kAtFwdLds = (size_t)(2 * AT_TR * AT_KS + 2 * AT_TR * AT_VS) * sizeof(f16_t);
+constexpr size_t kAtFwdLds = 2 * (size_t)(2 * AT_TR * AT_KS + 2 * AT_TR * AT_VS) * sizeof(f16_t);                                          // two buffers
 
 }  // namespace hipie
 
