@@ -738,7 +738,7 @@ __global__ __launch_bounds__(256) void to_hl8_t_kernel(const float* __restrict__
   }
   __syncthreads();
   for (int u = tid; u < kTrCols * (kTrRows / 8); u += 256) {           // unit = (output row c, group of 8 source rows)
-    const int c = u % kTrCols, g = u / kTrCols;
+    const int g = u % (kTrRows / 8), c = u / (kTrRows / 8);      // lanes along the 16 row groups: 512 contiguous bytes of one output row
     const long m = r0 + 8 * g;
     if (c0 + c >= C || m >= rows_p) continue;
     f16x8 h, l;
