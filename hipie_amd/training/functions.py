@@ -145,6 +145,29 @@ class FusedAttentionFunction(torch.autograd.Function):
 
 
 def fused_attention_ok(qa, ka, v):
-    """shapes FusedAttentionFunction covers (the global blocks of the ViT at grids whose token count is a multiple of 128)"""
+    """operands FusedAttentionFunction takes as they are (the global blocks of the ViT at grids whose token count is a multiple of 128)"""
     return (qa.is_cuda and qa.dtype == torch.float32 and v.shape[-1] == 80 and qa.shape[-1] <= 224 and ka.shape[-1] == qa.shape[-1]
-            and qa.shape[1] % 128 == 0 and qa.shape[0] <= 65535)
+            and qa.shape[1] % 128 == 0)
+
+
+def fused_attention(qa, ka, v):
+    """softmax(q' k'^T) v on the fused kernels, or None when the operands are not covered.  Token counts that are not a multiple of 128 (a
+    50 x 76 grid: 3800) are padded: the padding KEYS get a bias of -30000 through one more operand column (q' column 1, k' column -30000
+    on the padding rows) so they receive probability 0; the padding QUERY rows are zeros and their outputs are dropped (no gradient
+    reaches them)."""
+    BH, N, C = qa.shape
+    if N % 128 == 0:
+        return FusedAttentionFunction.apply(qa, ka, v) if fused_attention_ok(qa, ka, v) else None
+    if N < 1024:
+        # the 196-token windows: correct on this path (tests) but SLOWER than the materialised formulation -- the kernels always run 224
+        # operand columns (a window has 108) and 256 rows: 752 against 720 ms per training step
+        return None
+    Np = -(-N // 128) * 128
+    pad = torch.nn.functional.pad
+    if not fused_attention_ok(pad(qa[:, :0], (0, 1, 0, Np)), pad(ka[:, :0], (0, 1, 0, Np)), pad(v[:, :0], (0, 0, 0, Np))):
+        return None
+    bias = ka.new_zeros(BH, Np, 1)
+    bias[:, N:] = -30000.0
+    qa_p = pad(torch.cat((qa, qa.new_ones(BH, N, 1)), -1), (0, 0, 0, Np - N))
+    ka_p = torch.cat((pad(ka, (0, 0, 0, Np - N)), bias), -1)
+    return FusedAttentionFunction.apply(qa_p, ka_p, pad(v, (0, 0, 0, Np - N)))[:, :N]

@@ -56,10 +56,11 @@ class HipBackend:
 
     @staticmethod
     def fused_attention(qa, ka, v):
-        """softmax(q' k'^T) v of a global ViT block on the fused split-fp16 kernels when the shape is covered (token count a multiple of 128,
-        head width 80, <= 224 operand columns), else None: the caller's materialised formulation runs (the 14 x 14 windows)"""
-        from .functions import FusedAttentionFunction, fused_attention_ok
-        return FusedAttentionFunction.apply(qa, ka, v) if fused_attention_ok(qa, ka, v) else None
+        """softmax(q' k'^T) v of a ViT block on the fused split-fp16 kernels when the shape is covered (head width 80, <= 224 operand columns;
+        large token counts that are not a multiple of 128 are padded with masked keys), else None: the caller's materialised formulation
+        runs (the 196-token windows, where it is the faster one)"""
+        from .functions import fused_attention
+        return fused_attention(qa, ka, v)
 
     @staticmethod
     def mask_einsum(mask_embed, mask_features):

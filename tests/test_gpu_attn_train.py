@@ -90,3 +90,28 @@ def test_f16_pair_kernel_matches_the_torch_formulation():
     got = ops.f16_pair(wide.cuda()[:, :80], 96)
     assert torch.equal(got[0].cpu(), want[0]) and torch.equal(got[1].cpu(), want[1])
     assert float(got[0][:, 80:].abs().max()) == 0.0
+
+
+@gpu
+@pytest.mark.parametrize("BH,H,W", [(2, 50, 76), (3, 33, 35)])
+def test_fused_attention_pads_token_counts_that_are_not_a_multiple_of_128(BH, H, W):
+    """functions.fused_attention on token grids that are not a multiple of 128 (50 x 76: an 800 x 1216 image; 33 x 35): padding keys masked
+    through one more operand column, padding query rows dropped -- output and gradients against the materialised formulation in double on
+    the UNPADDED operands.  The 196-token windows are left to the materialised formulation (None)."""
+    from hipie_amd.training.functions import fused_attention
+    w = _operands(4, 14, 14, 1)
+    assert fused_attention(*(t.float().cuda() for t in w)) is None
+    qa, ka, v = _operands(BH, H, W, BH + H)
+    g = torch.Generator().manual_seed(9)
+    go = torch.randn(v.shape, generator=g, dtype=torch.float64) * 0.1
+    with torch.enable_grad():
+        ql, kl, vl = (t.clone().requires_grad_(True) for t in (qa, ka, v))
+        want_o = torch.softmax(ql @ kl.transpose(1, 2), -1) @ vl
+        want = torch.autograd.grad(want_o, (ql, kl, vl), go)
+        dq, dk, dv = (t.float().cuda().requires_grad_(True) for t in (qa, ka, v))
+        out = fused_attention(dq, dk, dv)
+        assert out is not None and out.shape == (BH, H * W, 80)
+        got = torch.autograd.grad(out, (dq, dk, dv), go.float().cuda())
+    assert rel_err(out.detach().cpu(), want_o.detach()) < 3e-6
+    assert rel_err(got[0].cpu(), want[0]) < 1e-5 and rel_err(got[1][..., :80].cpu(), want[1][..., :80]) < 1e-5 and rel_err(got[2].cpu(), want[2]) < 1e-5
+    assert float(got[1][..., 80:].abs().max()) == 0.0
