@@ -5,8 +5,9 @@
                dictionary over the product model's parameters -- loss entries, total and every parameter gradient pinned against the
                reference's own step (tests/golden/train_step_tiny.npz, tests/test_training.py::test_train_step_*);
   net.py       the differentiable network under it: hand-written HIP forward AND backward for multi-scale deformable attention, the mask
-               contraction and the CondInst dynamic mask head (functions.py, ../msda_shim.py); the dense layers on the library kernels
-               with torch.autograd (the inference path's fused split-fp16 kernels have no backward);
+               contraction, the CondInst dynamic mask head, the large linears (split-fp16 GEMM: y, dx, dW) and the attention of the
+               global ViT blocks (csrc/attn_train.hip: no (heads, N, N) tensor in HBM) -- functions.py, ../msda_shim.py; everything
+               else on the library kernels with torch.autograd;
   matcher.py, criterion.py, dn.py, targets.py, weights.py, boxes.py
                the host logic: matching costs + assignment (Hungarian, SimOTA), the set-prediction losses of both heads, contrastive
                de-noising queries, target preparation, loss weighting -- each pinned against the reference's classes;
