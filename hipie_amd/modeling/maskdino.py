@@ -17,7 +17,7 @@ from .. import ops
 from .transformer import (MLP, _select_topk, DeformableTransformerDecoderLayer, DeformableTransformerEncoderLayer, FeatureResizer, geo_cached,
                           PConv2d, PGroupNorm, PLayerNorm, PLinear, PositionEmbeddingSine, _get_clones, encoder_reference_points,
                           gen_encoder_output_proposals, level_tensors,
-                          batched_decoder_values, decoder_box_refine, decoder_fast_path, decoder_query_pos)
+                          batched_decoder_values, decoder_box_refine, decoder_split_values, decoder_fast_path, decoder_query_pos)
 
 
 class NormConv2d(PConv2d):
@@ -268,10 +268,11 @@ class MaskDINODecoder(nn.Module):
                 refs.append(ref)
             hs.append(self.decoder.norm(t32).float())
             layers = []
+        values = batched_decoder_values(self.decoder, layers, src, None) if layers and decoder_split_values(self.decoder, src) else None
         for lid, layer in enumerate(layers):
             ref_in = ref[:, :, None] * vr2
             query_pos = self.decoder.ref_point_head(ops.sine_embed(ref_in[:, :, 0, :], out_dtype=wdt))
-            out = layer(out, query_pos, ref_in, src, spatial_shapes, level_start_index, None)
+            out = layer(out, query_pos, ref_in, src, spatial_shapes, level_start_index, None, value=None if values is None else values[lid])
             new_ref = ops.box_refine(self.decoder.bbox_embed[lid](out), ref)
             ref = new_ref
             refs.append(new_ref)

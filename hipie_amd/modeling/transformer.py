@@ -333,16 +333,17 @@ class MSDeformAttn(nn.Module):
                              reference_points.float().contiguous(), off, logits)
         return self.output_proj(out)
 
-    def forward_projected(self, query, reference_points, value, input_spatial_shapes, input_level_start_index, x_hl8=False):
+    def forward_projected(self, query, reference_points, value, input_spatial_shapes, input_level_start_index, x_hl8=False, project=True):
         """forward with the value projection done by the caller (one GEMM for all decoder layers): `value` (N, S, heads, hd),
-        dense or a column block of the batched projection (sampled in place through its row stride)."""
+        dense or a column block of the batched projection (sampled in place through its row stride).  project=False: the sampled
+        values before output_proj (the caller fuses the projection with what follows it)."""
         w, b = self._fused_proj()
         no = self.n_heads * self.n_levels * self.n_points * 2
         proj = _lin(self, "offlog", query, w, b, x_hl8=x_hl8)
         off = proj[..., :no].unflatten(-1, (self.n_heads, self.n_levels, self.n_points, 2))
         logits = proj[..., no:].unflatten(-1, (self.n_heads, self.n_levels * self.n_points))
         out = ops.msda_fused(value, input_spatial_shapes, input_level_start_index, reference_points.float().contiguous(), off, logits)
-        return self.output_proj(out)
+        return self.output_proj(out) if project else out
 
     def _fused_proj(self):
         so, aw = self.sampling_offsets, self.attention_weights
@@ -513,9 +514,14 @@ def _enc_layer_forward_split(self, src, pos, reference_points, spatial_shapes, l
     else:
         src_h, q_h = ops.to_hl8(src), ops.to_hl8(src + pos if carry is None else carry)
     value = attn.project_value(src_h, padding_mask, x_hl8=True)
-    src2 = attn.forward_projected(q_h, reference_points, value.contiguous(), spatial_shapes, level_start_index, x_hl8=True)
-    n = self.norm1
-    src, s_h, _ = ops.add_layernorm_dec(src, src2.contiguous(), n.weight, n.bias, n.eps, "hl8", want16=True)
+    n, op = self.norm1, attn.output_proj
+    if ops.split_linear_ln_ok(src, op.weight, n.weight):
+        # output_proj + residual + norm1 as ONE launch (hipie_gemm_ln: 256 features = one column tile, the rows are whole in the epilogue)
+        sampled = attn.forward_projected(q_h, reference_points, value.contiguous(), spatial_shapes, level_start_index, x_hl8=True, project=False)
+        src, s_h = ops.split_linear_ln(sampled, op, "w", op.weight, op.bias, src, n.weight, n.bias, n.eps)
+    else:
+        src2 = attn.forward_projected(q_h, reference_points, value.contiguous(), spatial_shapes, level_start_index, x_hl8=True)
+        src, s_h, _ = ops.add_layernorm_dec(src, src2.contiguous(), n.weight, n.bias, n.eps, "hl8", want16=True)
     if ops.ffn_fused_ok(s_h, self.linear1, self.linear2):
         src2 = ops.ffn_fused(s_h, self.linear1, self.linear2)          # one launch, the (tokens x 2048) hidden tensor never exists
     else:
@@ -615,11 +621,15 @@ class DeformableTransformerDecoderLayer(nn.Module):
         self.linear1, self.linear2 = PLinear(d_model, d_ffn), PLinear(d_ffn, d_model)
         self.norm3 = PLayerNorm(d_model)
 
-    def forward(self, tgt, query_pos, reference_points, src, spatial_shapes, level_start_index, src_padding_mask=None):
-        """every residual add + LayerNorm is one hipie_add_layernorm launch; the stream keeps the dtype it arrives in."""
+    def forward(self, tgt, query_pos, reference_points, src, spatial_shapes, level_start_index, src_padding_mask=None, value=None):
+        """every residual add + LayerNorm is one hipie_add_layernorm launch; the stream keeps the dtype it arrives in.
+        value: this layer's pre-projected (N, S, heads, hd) block of batched_decoder_values (src is then not read)."""
         qk = tgt + query_pos
         tgt = _add_norm(tgt, self.self_attn(qk, tgt), self.norm2)
-        tgt2 = self.cross_attn(tgt + query_pos, reference_points, src, spatial_shapes, level_start_index, src_padding_mask)
+        if value is not None:
+            tgt2 = self.cross_attn.forward_projected(tgt + query_pos, reference_points, value, spatial_shapes, level_start_index)
+        else:
+            tgt2 = self.cross_attn(tgt + query_pos, reference_points, src, spatial_shapes, level_start_index, src_padding_mask)
         tgt = _add_norm(tgt, tgt2, self.norm1)
         tgt2 = self.linear2(self.linear1.forward_relu(tgt))
         return _add_norm(tgt, tgt2, self.norm3)
@@ -650,6 +660,13 @@ def decoder_fast_path(layers, stream_dtype):
             and l0.linear1.out_dtype == wd and l0.linear1.weight.is_cuda)
 
 
+def decoder_split_values(decoder, src):
+    """split policy, inference: the value projections of all decoder layers read the same fp32 memory -> one batched GEMM."""
+    l0 = decoder.layers[0].cross_attn
+    return (bool(getattr(decoder, "split", False)) and src.is_cuda and src.dtype == torch.float32 and not torch.is_grad_enabled()
+            and l0.value_proj.weight.dtype == torch.float32 and l0.value_dtype == torch.float32)
+
+
 def batched_decoder_values(owner, layers, src, padding_mask=None):
     """value projections of ALL decoder layers as one GEMM on the concatenated weights (they read the same memory); returns
     the per-layer (N, S, heads, hd) column blocks (views: hipie_msda samples them in place)."""
@@ -659,7 +676,7 @@ def batched_decoder_values(owner, layers, src, padding_mask=None):
         owner._bv = (torch.cat([p.weight for p in ps], 0).contiguous(), torch.cat([p.bias for p in ps], 0).contiguous())
         owner._bv_key = key
     w, b = owner._bv
-    v = F.linear(src.to(w.dtype), w, b)
+    v = _lin(owner, "bv", src, w, b)           # split policy: ONE thin-K split GEMM (N = layers x 256) instead of one 256-column GEMM per layer
     if padding_mask is not None:
         v.masked_fill_(padding_mask[..., None], 0.0)
     N, S, _ = v.shape
@@ -739,10 +756,12 @@ class DeformableTransformerDecoder(nn.Module):
                 inter.append(t32)
                 inter_refs.append(reference_points)
             return torch.stack(inter), torch.stack(inter_refs)
+        values = batched_decoder_values(self, self.layers, src, src_padding_mask) if decoder_split_values(self, src) else None
         for lid, layer in enumerate(self.layers):
             ref_in = reference_points[:, :, None] * vr2
             query_pos = self.ref_point_head(ops.sine_embed(ref_in[:, :, 0, :], out_dtype=wdt))      # one launch (was ~21)
-            output = layer(output, query_pos, ref_in, src, spatial_shapes, level_start_index, src_padding_mask)
+            output = layer(output, query_pos, ref_in, src, spatial_shapes, level_start_index, src_padding_mask,
+                           value=None if values is None else values[lid])
             new_ref = ops.box_refine(self.bbox_embed[lid](output), reference_points)               # one launch (was ~8)
             reference_points = new_ref
             inter.append(output)

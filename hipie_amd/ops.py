@@ -1324,6 +1324,40 @@ def split_linear(x, owner, key, weight, bias=None, act=ACT_NONE, out_fmt=F32, re
     return out
 
 
+def split_linear_ln_ok(x, weight, norm_weight):
+    """the fused projection + residual LayerNorm (hipie_gemm_ln) applies: 256 output features = one column tile, split-able K."""
+    return (x.is_cuda and weight.dtype == torch.float32 and weight.shape[0] == 256 and norm_weight.numel() == 256 and weight.shape[1] % 32 == 0
+            and not torch.is_grad_enabled())
+
+
+@_timed("gemm_ln")
+def split_linear_ln(x, owner, key, weight, bias, resid, norm_weight, norm_bias, eps, x_hl8=False, want_hl8=True):
+    """LayerNorm(resid + F.linear(x, weight, bias)) over 256 features as ONE launch (hipie_gemm_ln): returns (n fp32, n as HL8 or None).
+    x (..., K) fp32 rows or HL8 (x_hl8); resid (..., 256) fp32; the HL8 copy of `weight` is cached on `owner` under `key` (split_weight)."""
+    lib = _lib.load()
+    w, b, N = split_weight(owner, key, [weight] + ([bias] if bias is not None else []), lambda: weight, (lambda: bias) if bias is not None else None)
+    if N != 256 or w.shape[0] != 256:
+        raise RuntimeError("split_linear_ln: 256 output features expected")
+    K = w.shape[1] // 2
+    a_f32 = not x_hl8
+    if a_f32 and (x.dtype != torch.float32 or x.stride(-1) != 1):
+        raise RuntimeError("split_linear_ln: x must be fp32 rows or HL8")
+    a2 = x.reshape(-1, x.shape[-1])
+    if a2.shape[-1] != (K if a_f32 else 2 * K) or (a_f32 and (a2.stride(0) % 4 or a2.data_ptr() % 16)):
+        raise RuntimeError("split_linear_ln: operand rows %s against weight %s" % (tuple(x.shape), tuple(weight.shape)))
+    r2 = resid.reshape(-1, 256)
+    M = a2.shape[0]
+    if r2.dtype != torch.float32 or r2.stride(-1) != 1 or r2.shape[0] != M or not r2.is_cuda:
+        raise RuntimeError("split_linear_ln: resid must be (rows, 256) fp32 on the device")
+    out = torch.empty(*resid.shape[:-1], 256, dtype=torch.float32, device=x.device)
+    o16 = torch.empty(*resid.shape[:-1], 512, dtype=torch.float16, device=x.device) if want_hl8 else None
+    rc = lib.hipie_gemm_ln(a2.data_ptr(), a2.stride(0), _chk(w, "w"), w.shape[1], None if b is None else b.data_ptr(), r2.data_ptr(), r2.stride(0),
+                           _chk(norm_weight, "norm_weight", torch.float32), _chk(norm_bias, "norm_bias", torch.float32), float(eps),
+                           out.data_ptr(), 256, None if o16 is None else o16.data_ptr(), 512, M, K, F32 if a_f32 else HL8, 1.0, _stream())
+    _lib.check(rc, "hipie_gemm_ln")
+    return out, o16
+
+
 _SHUFFLE_MAPS = {}
 
 

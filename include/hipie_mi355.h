@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HIPIE_ABI_VERSION 12
+#define HIPIE_ABI_VERSION 13
 
 /* element types of activations */
 #define HIPIE_F32 0
@@ -443,6 +443,20 @@ int hipie_box_refine(const void* delta, const float* ref, float* out, int64_t n,
 int hipie_gemm(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* resid, int64_t ldr,
                void* out, int64_t ldo, const int32_t* out_row, int M, int N, int K, int in_fmt, int out_fmt, int act, float alpha,
                float oscale, void* stream);
+
+/*
+ * hipie_gemm (split operands, N = 256) with the post-norm residual LayerNorm of the deformable encoder layer in its epilogue:
+ *     y = LayerNorm_256( resid + alpha * A . W^T + bias ) * gamma + beta;   out = y as fp32 rows;  out_hl8 (or NULL) = y as HIPIE_HL8 rows
+ * Replaces `src = norm1(src + dropout1(output_proj(msda)))` (models/deformable_detr/deformable_transformer_dino.py:387-389 with
+ * ops/modules/ms_deform_attn.py:114) as ONE launch: N = 256 is one column tile, so the workgroup that owns 256 rows holds them whole and the
+ * row statistics (two passes, fp32, as hipie_add_layernorm_dec) are two LDS exchanges away; the projection never exists in memory.
+ * A in_fmt HIPIE_HL8 | HIPIE_F32 (lda as in hipie_gemm); W (256, 2K) HL8; bias (256) or NULL; resid (M, 256) fp32, required, may alias out
+ * (every residual value of a row is read before any value of that row is stored); gamma, beta (256); ldo >= 256 (fp32 elements),
+ * ldo_hl8 >= 512 (fp16 elements).  K a multiple of 32.  All pointers 16-byte aligned.
+ */
+int hipie_gemm_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* resid, int64_t ldr,
+                  const float* gamma, const float* beta, float eps, float* out, int64_t ldo, void* out_hl8, int64_t ldo_hl8, int M, int K,
+                  int in_fmt, float alpha, void* stream);
 
 /*
  * hipie_gemm whose product row m READS operand row a_row[m] (0 <= a_row[m] < a_rows; A is a_rows x K; split formats only; the whole operand

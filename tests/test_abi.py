@@ -22,7 +22,7 @@ def test_library_loads_and_exports_all():
     lib = _lib.load()
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.hipie_version() == 12
+    assert lib.hipie_version() == 13
     assert lib.hipie_last_error() == b""
 
 
@@ -61,6 +61,11 @@ def test_new_entry_points_validate_on_the_host():
     st = [64 * 128, 128, 64] * 4
     assert lib.hipie_flash_attn(p, p, p, p, 1, 2, 64, 64, 64, *st, None, None, 0, 0, None, 1.0, 0.0, 2 | 0x200, None) == -22
     assert b"HL8_HI" in lib.hipie_last_error()
+    # hipie_gemm_ln: residual required, K % 32, split operands only, fp32 output rows of at least 256
+    assert lib.hipie_gemm_ln(p, 256, p, 512, p, None, 256, p, p, 1e-5, p, 256, p, 512, 10, 256, 0, 1.0, None) == -22 and b"null" in lib.hipie_last_error()
+    assert lib.hipie_gemm_ln(p, 256, p, 512, p, p, 256, p, p, 1e-5, p, 256, p, 512, 10, 250, 0, 1.0, None) == -22 and b"K=250" in lib.hipie_last_error()
+    assert lib.hipie_gemm_ln(p, 256, p, 512, p, p, 256, p, p, 1e-5, p, 256, p, 512, 10, 256, 1, 1.0, None) == -22 and b"format" in lib.hipie_last_error()
+    assert lib.hipie_gemm_ln(p, 256, p, 512, p, p, 256, p, p, 1e-5, p, 200, p, 512, 10, 256, 0, 1.0, None) == -22 and b"stride" in lib.hipie_last_error()
     # empty work is a no-op even with null data pointers
     assert lib.hipie_batched_nms(None, None, None, None, None, 0, 0, 0.7, 1, None) == 0
     assert lib.hipie_mask_finalize(None, 0, None, 0, 8, 8, 4, 32, 32, 32, 32, 0.5, None, None) == 0

@@ -397,3 +397,73 @@ def test_split_linear_function_forward_and_backward(M, N, K, bias):
     assert rel_err(y.detach().cpu(), want_y.detach()) < 3e-6
     for a, c, name in zip(got, want, ("dx", "dW", "db")):
         assert a.shape == c.shape and rel_err(a.cpu(), c) < 5e-6, (name, rel_err(a.cpu(), c))
+
+
+class _Owner:
+    pass
+
+
+@gpu
+@pytest.mark.parametrize("M,K,hl8_in", [(1, 256, False), (255, 256, True), (1000, 256, False), (21760, 256, False), (4100, 2048, True)])
+def test_gemm_ln_matches_projection_then_layernorm(M, K, hl8_in):
+    """hipie_gemm_ln (output_proj + residual + norm1 of the deformable encoder layer in ONE launch: deformable_transformer_dino.py:387-389)
+    against the two launches it replaces (hipie_gemm, then hipie_add_layernorm_dec) and against fp64; the HL8 output is the split of the fp32
+    output bit for bit; in place on the residual stream."""
+    from hipie_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    x = torch.randn(M, K, device="cuda", generator=g) * 2.0
+    w = torch.randn(256, K, device="cuda", generator=g) * (K ** -0.5)
+    b = torch.randn(256, device="cuda", generator=g)
+    resid = torch.randn(M, 256, device="cuda", generator=g) * 3.0 + 0.7
+    gamma = torch.randn(256, device="cuda", generator=g)
+    beta = torch.randn(256, device="cuda", generator=g)
+    eps = 1e-5
+    a = ops.to_hl8(x) if hl8_in else x
+    own = _Owner()
+    assert ops.split_linear_ln_ok(x, w, gamma)
+    n32, n16 = ops.split_linear_ln(a, own, "w", w, b, resid, gamma, beta, eps, x_hl8=hl8_in)
+    proj = ops.gemm(a, ops.hl8_pack(w), b, split=True)
+    want32, want16, _ = ops.add_layernorm_dec(resid, proj, gamma, beta, eps, "hl8", want16=True)
+    assert rel_err(n32.cpu(), want32.cpu()) < 2e-6
+    assert torch.equal(n16, ops.to_hl8(n32))
+    ref = torch.nn.functional.layer_norm(resid.double() + x.double() @ w.double().t() + b.double(), (256,), gamma.double(), beta.double(), eps)
+    assert rel_err(n32.cpu(), ref.float().cpu()) < 5e-6
+    only32, none16 = ops.split_linear_ln(a, own, "w", w, b, resid, gamma, beta, eps, x_hl8=hl8_in, want_hl8=False)
+    assert none16 is None and torch.equal(only32, n32)
+
+
+@gpu
+def test_decoder_values_batched_in_the_split_policy():
+    """split policy: the value projections of all decoder layers as ONE thin-K split GEMM over the shared memory (transformer.
+    batched_decoder_values) equal the per-layer projections (ms_deform_attn.py:95-99 once per layer), and the decoder output does not move."""
+    import hipie_amd.modeling.transformer as T
+    torch.manual_seed(3)
+    dec = T.DeformableTransformerDecoder(256, T.DeformableTransformerDecoderLayer(256, 512, 4, 8, 4, torch.float32), 3).cuda()
+    for p in dec.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    dec.bbox_embed = torch.nn.ModuleList([T.MLP(256, 256, 4, 3).cuda() for _ in range(3)])
+    T.set_split(dec)
+    shapes = [(32, 40), (16, 20), (8, 10), (4, 5)]
+    S = sum(h * w for h, w in shapes)
+    ss = torch.tensor(shapes, device="cuda")
+    ls = torch.cat([ss.new_zeros(1), (ss[:, 0] * ss[:, 1]).cumsum(0)[:-1]])
+    B, Q = 6, 50                                        # 6 x 1700 rows: the thin-K kernel (M >= 8192)
+    src = torch.randn(B, S, 256, device="cuda")
+    mask = torch.zeros(B, S, dtype=torch.bool, device="cuda")
+    mask[1, -37:] = True
+    assert T.decoder_split_values(dec, src)
+    vals = T.batched_decoder_values(dec, dec.layers, src, mask)
+    for lid, layer in enumerate(dec.layers):
+        want = layer.cross_attn.project_value(src, mask)
+        assert vals[lid].shape == want.shape and rel_err(vals[lid].cpu(), want.cpu()) < 1e-6
+    tgt = torch.randn(B, Q, 256, device="cuda")
+    ref = torch.rand(B, Q, 4, device="cuda") * 0.5 + 0.25
+    vr = torch.ones(B, 4, 2, device="cuda")
+    got, got_refs = dec(tgt, ref, src, ss, ls, vr, mask)
+    keep = T.decoder_split_values
+    T.decoder_split_values = lambda *a: False
+    try:
+        want, want_refs = dec(tgt, ref, src, ss, ls, vr, mask)
+    finally:
+        T.decoder_split_values = keep
+    assert rel_err(got.cpu(), want.cpu()) < 2e-6 and rel_err(got_refs.cpu(), want_refs.cpu()) < 2e-6
