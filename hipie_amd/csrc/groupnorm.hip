@@ -100,6 +100,60 @@ __global__ __launch_bounds__(256) void gn_apply_nhwc_kernel(const T* __restrict_
   }
 }
 
+// ---- NHWC in, NCHW out (channels_last = 2): the normalised map leaves pixel-fastest -- the operand layout of the mask contraction
+// (hipie_mask_einsum) -- without the 2 x (B, C, HW) transposing copy that followed the channels-last pass.  A workgroup owns 64 pixels of
+// one image: the channels-last rows are read as the plain kernel reads them, the normalised values cross an LDS tile [channel][pixel]
+// and leave as 256-byte runs of one channel.  HW % 64 == 0.
+constexpr int GN_TP = 64;             // pixels per tile
+template <typename T, typename OutT>
+__global__ __launch_bounds__(256) void gn_apply_nhwc_to_nchw_kernel(const T* __restrict__ x, const float* __restrict__ prebias,
+                                                                    const float* __restrict__ part, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, OutT* __restrict__ out, int HW, int G,
+                                                                    int nchunk, float eps, int relu) {
+  extern __shared__ __attribute__((aligned(16))) float gn_tile[];      // [C][GN_TP + 1]
+  __shared__ float stat[2][64];
+  const int b = blockIdx.y, p0 = blockIdx.x * GN_TP;
+  const int g = threadIdx.x % G, pl = threadIdx.x / G, npl = 256 / G;
+  const int C = G * GN_CPG;
+  if (threadIdx.x < G) {
+    float s = 0.f, ss = 0.f;
+    const float* pp = part + ((long)b * G + threadIdx.x) * nchunk * 2;
+    for (int k = 0; k < nchunk; ++k) { s += pp[2 * k]; ss += pp[2 * k + 1]; }
+    const float n = (float)HW * GN_CPG;
+    const float ms = s / n;
+    const float K = (float)x[(long)b * HW * C + threadIdx.x * 8] + (prebias ? prebias[threadIdx.x * 8] : 0.f);
+    stat[0][threadIdx.x] = K + ms;
+    stat[1][threadIdx.x] = rsqrtf(fmaxf(ss / n - ms * ms, 0.f) + eps);
+  }
+  __syncthreads();
+  const float mean = stat[0][g], rstd = stat[1][g];
+  float sc[8], sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    sc[i] = rstd * gamma[g * 8 + i];
+    sh[i] = beta[g * 8 + i] + ((prebias ? prebias[g * 8 + i] : 0.f) - mean) * sc[i];
+  }
+  for (int p = pl; p < GN_TP; p += npl) {
+    float v[8];
+    V8<T>::ld(x + ((long)b * HW + p0 + p) * C + g * 8, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v[i] = fmaf(v[i], sc[i], sh[i]);
+      if (relu) v[i] = fmaxf(v[i], 0.f);
+      gn_tile[(g * 8 + i) * (GN_TP + 1) + p] = v[i];
+    }
+  }
+  __syncthreads();
+  struct alignas(sizeof(OutT) * 4) Pack { OutT v[4]; };
+  const int q = threadIdx.x & 15, cr = threadIdx.x >> 4;                 // 16 threads x 4 pixels = one channel's 64 pixels; 16 channels per pass
+  for (int c = cr; c < C; c += 16) {
+    Pack o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o.v[i] = elem<OutT>::from_f32(gn_tile[c * (GN_TP + 1) + 4 * q + i]);
+    *reinterpret_cast<Pack*>(out + ((long)b * C + c) * HW + p0 + 4 * q) = o;
+  }
+}
+
 // ---- NCHW: x (B, C, HW).  one block per (chunk, image * channel); 8 elements per thread per step ----
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_nchw_kernel(const T* __restrict__ x, const float* __restrict__ prebias,
@@ -180,6 +234,14 @@ static int launch_gn(const void* x, const float* prebias, const float* gamma, co
     const int per = (HW + nchunk - 1) / nchunk;
     nchunk = (HW + per - 1) / per;
     hipLaunchKernelGGL((gn_stats_nhwc_kernel<T>), dim3(nchunk, B), dim3(256), 0, st, (const T*)x, prebias, part, HW, G, nchunk, per);
+    if (nhwc == 2) {                         // channels-last in, NCHW out
+      const size_t lds = (size_t)C * (GN_TP + 1) * sizeof(float);
+      auto kern = gn_apply_nhwc_to_nchw_kernel<T, OutT>;
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kern, dim3(HW / GN_TP, B), dim3(256), lds, st, (const T*)x, prebias, part, gamma, beta, (OutT*)out, HW, G, nchunk,
+                         eps, relu);
+      return check_launch("group_norm");
+    }
     hipLaunchKernelGGL((gn_apply_nhwc_kernel<T, OutT>), dim3(nchunk, B), dim3(256), 0, st, (const T*)x, prebias, part, gamma, beta,
                        (OutT*)out, HW, G, nchunk, per, eps, relu);
   } else {
@@ -216,6 +278,8 @@ extern "C" int hipie_group_norm(const void* x, const float* prebias, const float
   HIPIE_REQUIRE(groups > 0 && C == groups * GN_CPG && groups <= 64 && 256 % groups == 0,
                 "group_norm: %d channels in %d groups unsupported (8 channels per group, 256 %% groups == 0)", C, groups);
   HIPIE_REQUIRE(channels_last || HW % 8 == 0, "group_norm: NCHW needs H*W %% 8 == 0 (got %d)", HW);
+  HIPIE_REQUIRE(channels_last >= 0 && channels_last <= 2 && (channels_last != 2 || HW % 64 == 0),
+                "group_norm: channels_last %d (0 NCHW, 1 channels-last, 2 channels-last in / NCHW out: H*W %% 64 == 0, got %d)", channels_last, HW);
   if (B == 0) return HIPIE_OK;
   hipStream_t st = (hipStream_t)stream;
   switch (x_dtype) {

@@ -125,7 +125,7 @@ class MaskDINOEncoder(nn.Module):
             y = F.conv_transpose2d(z.contiguous().to(ct.weight.dtype), ct.weight, None, ct.stride, ct.padding, ct.output_padding, ct.groups, ct.dilation)
         if out_dtype is not None:
             y = y.to(out_dtype)
-        return gn(y, relu=True, prebias=ct.bias.float())
+        return gn(y, relu=True, prebias=ct.bias.float(), out_nchw=True)   # pixel-fastest: the mask contraction's operand layout (callers `.contiguous()` it)
 
     def forward_features(self, features, masks=None):
         f3, f4, f5 = features["res3"], features["res4"], features["res5"]      # the projections cast / lay out their input

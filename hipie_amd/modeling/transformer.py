@@ -100,9 +100,10 @@ class PGroupNorm(nn.GroupNorm):
     """GroupNorm on whatever activation dtype / memory format arrives (fp32 parameters and statistics): hipie_group_norm for
     GroupNorm(32, 256) on the GPU, optionally with the ReLU that follows and a per-channel bias that precedes it."""
 
-    def forward(self, x, relu=False, prebias=None):
+    def forward(self, x, relu=False, prebias=None, out_nchw=False):
+        """out_nchw: the caller wants a dense NCHW result whatever layout x has (a hint: other paths return x's layout)."""
         if self.weight.dtype == torch.float32 and ops.group_norm_ok(x, self.num_groups):
-            return ops.group_norm(x, self.num_groups, self.weight, self.bias, self.eps, relu=relu, prebias=prebias)
+            return ops.group_norm(x, self.num_groups, self.weight, self.bias, self.eps, relu=relu, prebias=prebias, out_nchw=out_nchw)
         if prebias is not None:
             x = x + prebias.view(1, -1, 1, 1).to(x.dtype)
         y = F.group_norm(x, self.num_groups, self.weight.to(x.dtype), self.bias.to(x.dtype), self.eps)
@@ -511,8 +512,10 @@ def _enc_layer_forward_split(self, src, pos, reference_points, spatial_shapes, l
     src = src.contiguous()
     if isinstance(carry, dict):
         src_h, q_h = carry["src_h"], carry["q_h"]
+    elif carry is None:                     # first layer: the query src + pos as ONE pass over the cached HL8 position embedding
+        src_h, q_h = ops.to_hl8(src), ops.add_to_hl8(src, _pos_hl8(self, pos))
     else:
-        src_h, q_h = ops.to_hl8(src), ops.to_hl8(src + pos if carry is None else carry)
+        src_h, q_h = ops.to_hl8(src), ops.to_hl8(carry)
     value = attn.project_value(src_h, padding_mask, x_hl8=True)
     n, op = self.norm1, attn.output_proj
     if ops.split_linear_ln_ok(src, op.weight, n.weight):
@@ -529,11 +532,16 @@ def _enc_layer_forward_split(self, src, pos, reference_points, spatial_shapes, l
     n = self.norm2
     if not want_query:
         return ops.add_layernorm_dec(src, src2, n.weight, n.bias, n.eps, "hl8")[0]
-    key = (pos.data_ptr(), pos._version, tuple(pos.shape))
-    if getattr(self, "_pos_h_key", None) != key:            # the position embedding is a per-geometry constant
-        self._pos_h, self._pos_h_key = ops.to_hl8(pos.contiguous()), key
-    out, o_h, q_h = ops.add_layernorm_dec(src, src2, n.weight, n.bias, n.eps, "hl8", want16=True, addend=self._pos_h)
+    out, o_h, q_h = ops.add_layernorm_dec(src, src2, n.weight, n.bias, n.eps, "hl8", want16=True, addend=_pos_hl8(self, pos))
     return out, {"src_h": o_h, "q_h": q_h}
+
+
+def _pos_hl8(layer, pos):
+    """HL8 copy of the position embedding, cached on the layer: a per-geometry constant"""
+    key = (pos.data_ptr(), pos._version, tuple(pos.shape))
+    if getattr(layer, "_pos_h_key", None) != key:
+        layer._pos_h, layer._pos_h_key = ops.to_hl8(pos.contiguous()), key
+    return layer._pos_h
 
 
 DeformableTransformerEncoderLayer._forward_split = _enc_layer_forward_split
@@ -774,7 +782,7 @@ def gen_encoder_output_proposals(memory, memory_padding_mask, shapes_list, geo_k
     The proposals and the keep mask depend only on the geometry (cached); the memory masking is one masked_fill."""
     keep, prop = geo_cached(geo_key, ("proposals", tuple(shapes_list)),
                             lambda: _proposal_geometry(memory_padding_mask, shapes_list, memory.shape[0], memory.device))
-    return memory.masked_fill(~keep, 0.0), prop
+    return torch.where(keep, memory, memory.new_zeros(())), prop          # one pass (masked_fill on a copy was two)
 
 
 def _proposal_geometry(memory_padding_mask, shapes_list, N_, device):

@@ -687,23 +687,28 @@ def group_norm_ok(x, groups):
 
 
 @_timed("group_norm")
-def group_norm(x, groups, weight, bias, eps, relu=False, prebias=None, out_dtype=None):
+def group_norm(x, groups, weight, bias, eps, relu=False, prebias=None, out_dtype=None, out_nchw=False):
     """GroupNorm(groups, C = 8 * groups)(x + prebias[c]) (+ ReLU) on a (B,C,H,W) tensor in the memory format it arrives in
-    (channels-last stays channels-last: no NHWC -> NCHW copy); fp32 statistics."""
+    (channels-last stays channels-last: no NHWC -> NCHW copy); fp32 statistics.  out_nchw: a channels-last input leaves as a dense
+    NCHW tensor (transposed inside the kernel; H*W % 64 == 0) -- what `.contiguous()` would make of the result, without that pass."""
     lib = _lib.load()
     B, C, H, W = x.shape
     nhwc = x.is_contiguous(memory_format=torch.channels_last) and not (x.is_contiguous() and C > 1 and H * W > 1)
     if not nhwc and not x.is_contiguous():
         raise RuntimeError("group_norm: x must be NCHW- or channels-last-contiguous")
     out_dtype = out_dtype or x.dtype
-    out = torch.empty_like(x, dtype=out_dtype)            # preserves the memory format
+    if out_nchw and nhwc and (H * W) % 64 == 0:
+        nhwc = 2
+        out = torch.empty(B, C, H, W, dtype=out_dtype, device=x.device)
+    else:
+        out = torch.empty_like(x, dtype=out_dtype)            # preserves the memory format
     key = (str(x.device), B * groups, torch.cuda.current_stream(x.device).cuda_stream)      # per stream: the two branches of the head overlap
     ws = _GN_WS.get(key)
     if ws is None:
         ws = _GN_WS[key] = torch.empty(2 * B * groups * 512, dtype=torch.float32, device=x.device)
     rc = lib.hipie_group_norm(x.data_ptr(), None if prebias is None else _chk(prebias, "prebias", torch.float32),
                               _chk(weight, "weight", torch.float32), _chk(bias, "bias", torch.float32), out.data_ptr(),
-                              ws.data_ptr(), B, C, H * W, groups, 1 if nhwc else 0, float(eps), 1 if relu else 0,
+                              ws.data_ptr(), B, C, H * W, groups, int(nhwc), float(eps), 1 if relu else 0,
                               _DT[x.dtype], _DT[out_dtype], _stream())
     _lib.check(rc, "hipie_group_norm")
     return out
@@ -717,6 +722,18 @@ def add_cast(a, b):
         raise RuntimeError("add_cast: shapes differ")
     out = torch.empty_like(b)
     rc = lib.hipie_add_cast(_chk(a, "a", torch.float32), _chk(b, "b"), out.data_ptr(), a.numel(), _DT[b.dtype], _stream())
+    _lib.check(rc, "hipie_add_cast")
+    return out
+
+
+@_timed("add_cast")
+def add_to_hl8(a, b_hl8):
+    """HL8 of (a + b): a (..., C) fp32, b_hl8 (..., 2C) fp16 HL8 of the same rows -> (..., 2C) HL8, one pass (hipie_add_cast, HL8 form)."""
+    lib = _lib.load()
+    if b_hl8.dtype != torch.float16 or b_hl8.numel() != 2 * a.numel() or a.shape[-1] % 8 or not a.is_cuda:
+        raise RuntimeError("add_to_hl8: a (.., C) fp32 and b (.., 2C) HL8 device tensors, C %% 8 == 0")
+    out = torch.empty_like(b_hl8)
+    rc = lib.hipie_add_cast(_chk(a, "a", torch.float32), _chk(b_hl8, "b"), out.data_ptr(), a.numel(), HL8, _stream())
     _lib.check(rc, "hipie_add_cast")
     return out
 

@@ -349,7 +349,9 @@ int hipie_box_head(const float* x, const float* ref, const float* w1t, const flo
  * GroupNorm with 8 channels per group (GroupNorm(32, 256) of every conv + GN block after the backbone: input_proj of both heads,
  * deformable_detr.py:139-160; the pixel decoder's lateral / output convs and mask_features head, maskdino_encoder.py:262-300),
  * on the layout the tensor arrives in, with an optional per-channel pre-bias (y = GN(x + prebias[c])) and an optional ReLU.
- *   x, out (B, C, H*W) when channels_last == 0, (B, H*W, C) when 1;  workspace: 2 * B * groups * 512 floats (partial sums);
+ *   x, out (B, C, H*W) when channels_last == 0, (B, H*W, C) when 1;  channels_last == 2: x (B, H*W, C), out (B, C, H*W) -- the map
+ *   leaves pixel-fastest (the mask_features operand of hipie_mask_einsum) through an LDS tile, no transposing copy; H*W % 64 == 0;
+ *   workspace: 2 * B * groups * 512 floats (partial sums);
  *   gamma, beta (C) f32;  statistics fp32 (sum / sum of squares per group, biased variance, eps inside the sqrt).
  *   C == 8 * groups, 256 % groups == 0;  NCHW: H*W % 8 == 0.  Two launches, no atomics (deterministic).
  */

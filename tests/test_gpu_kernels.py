@@ -984,6 +984,24 @@ def test_group_norm_large_mean(nhwc):
     assert rel_err(got.float().cpu(), want) < 2e-4
 
 
+@pytest.mark.parametrize("shape,odt", [((2, 256, 32, 40), torch.float32), ((1, 256, 64, 64), torch.float16), ((3, 64, 8, 8), torch.float32)])
+def test_group_norm_channels_last_in_nchw_out(shape, odt):
+    """channels_last = 2 (the mask_features head: maskdino_encoder.py:289-292 feeds the mask contraction pixel-fastest): the same values as
+    the channels-last pass followed by `.contiguous()`, bit for bit, as a dense NCHW tensor; H*W % 64 != 0 keeps the input's layout."""
+    from hipie_amd import ops
+    gen = torch.Generator().manual_seed(sum(shape))
+    C = shape[1]
+    x = (torch.randn(shape, generator=gen) * 2 + 0.5).to(DEV).contiguous(memory_format=torch.channels_last)
+    w, b = (1 + 0.2 * torch.randn(C, generator=gen)).to(DEV), (0.2 * torch.randn(C, generator=gen)).to(DEV)
+    pb = torch.randn(C, generator=gen).to(DEV)
+    want = ops.group_norm(x, C // 8, w, b, 1e-5, relu=True, prebias=pb, out_dtype=odt)
+    got = ops.group_norm(x, C // 8, w, b, 1e-5, relu=True, prebias=pb, out_dtype=odt, out_nchw=True)
+    assert got.is_contiguous() and want.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, want.contiguous())
+    odd = x[:, :, :5, :7].contiguous(memory_format=torch.channels_last)            # 35 pixels: not a multiple of 64
+    assert ops.group_norm(odd, C // 8, w, b, 1e-5, out_nchw=True).is_contiguous(memory_format=torch.channels_last)
+
+
 def test_msda_fused_tiny_dense_heads():
     """dense value with M * D not a multiple of 8 (the reference's own unit shapes, ops/test.py: M = 2, D = 2) through the fused op."""
     from hipie_amd import ops
