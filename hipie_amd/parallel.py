@@ -101,9 +101,21 @@ def all_gather_predictions(block):
     world = dist.get_world_size()
     block = block.contiguous()
     raw = block if block.dtype == torch.float32 else block.view(torch.uint8)      # bytes: every backend gathers uint8
-    out = torch.empty((world * raw.shape[0],) + tuple(raw.shape[1:]), dtype=raw.dtype, device=raw.device)
-    dist.all_gather_into_tensor(out, raw)
+    if raw.is_cuda and dist.get_backend() == "gloo":
+        # gloo is the CPU backend of the tests (and of N processes sharing fewer GPUs, tests/test_gpu_rccl.py): device blocks cross
+        # through the host there; the N-GPU job's backend is "nccl" (RCCL), which gathers device memory directly
+        host = torch.empty((world * raw.shape[0],) + tuple(raw.shape[1:]), dtype=raw.dtype)
+        dist.all_gather_into_tensor(host, raw.cpu())
+        out = host.to(raw.device)
+    else:
+        out = torch.empty((world * raw.shape[0],) + tuple(raw.shape[1:]), dtype=raw.dtype, device=raw.device)
+        dist.all_gather_into_tensor(out, raw)
     return out if block.dtype == torch.float32 else out.view(block.dtype)
+
+
+def _collective_device(device):
+    """where the small bookkeeping collectives (rank count, max-over-ranks) put their operand: the device for "nccl", the host for "gloo"."""
+    return torch.device("cpu") if dist.is_initialized() and dist.get_backend() == "gloo" else device
 
 
 def live_ranks(device):
@@ -111,7 +123,7 @@ def live_ranks(device):
     in use (RCCL for "nccl").  1 without a process group.  bench.py reports it next to the gathered block's shape."""
     if not dist.is_initialized():
         return 1
-    t = torch.ones(1, dtype=torch.float32, device=device)
+    t = torch.ones(1, dtype=torch.float32, device=_collective_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(round(float(t.item())))
 
@@ -138,7 +150,7 @@ def barrier():
 
 
 def max_over_ranks(value, device):
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_collective_device(device))
     if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -75,3 +75,85 @@ def test_collectives_run_through_rccl_on_one_rank():
     res = json.loads(tag[-1][len("RCCL_OK "):])
     assert res["ranks"] == 1 and res["t"] == 1.25
     assert res["dp"]["backend"] == "nccl" and res["dp"]["rccl_ranks"] == 1 and res["dp"]["gathered_block_shape"] == [8, 100, 7]
+
+
+SHARD_CHILD = r"""
+import json, os, sys, torch
+sys.path.insert(0, %r)
+sys.path.insert(0, os.path.join(%r, "tests"))
+sys.path.insert(0, os.path.join(sys.path[0], "golden"))
+import _synth
+from util import Golden
+from hipie_amd import parallel
+from hipie_amd.config import HipieConfig, Precision
+from hipie_amd.hipie_img import HIPIE_IMG
+from hipie_amd.postprocess import inference_compact
+torch.set_grad_enabled(False)
+rank, world, _ = parallel.init_from_env(backend="gloo")          # two processes, ONE GPU: the group runs on gloo, the compute on cuda:0
+dev = torch.device("cuda", 0)
+g = Golden("e2e_tiny")
+model = HIPIE_IMG(HipieConfig.from_dict(g.meta["cfg"]), Precision.split3(), device=dev)
+model.load_state_dict(_synth.synth_full_state_dict({k: tuple(v) for k, v in g.meta["manifest"].items()}, dist=g.meta.get("dist")), strict=True)
+model.finalize()
+total = 4
+imgs = _synth.synth_images([(192, 256)] * total, seed=99)
+ids, mask, pmap = _synth.synth_token_ids(total, 9, 64, seed=74)
+def batch(idx):
+    return [{"image": imgs[i], "task": "detection", "input_ids": ids[0], "attention_mask": mask[0], "positive_map_label_to_token": pmap,
+             "height": 192, "width": 256} for i in idx]
+everything = batch(range(total))
+full_out = model.forward_raw(everything)                         # the whole global batch in this process: the yardstick, and the top-k rows to pin
+fg, md = model.last_topk()
+full = inference_compact(model, full_out, everything, topk=20)
+shard = parallel.shard_range(total, rank, world)                 # InferenceSampler ranges: rank 0 -> images 0, 1; rank 1 -> images 2, 3
+model.pin_topk(fg[shard.start:shard.stop].cpu(), md[shard.start:shard.stop].cpu())
+mine = batch(shard)
+local = inference_compact(model, model.forward_raw(mine), mine, topk=20)
+gathered = parallel.all_gather_predictions(local)
+t = parallel.max_over_ranks(1.0 + rank, dev)
+dp = parallel.dp_evidence(gathered, len(shard), rank, world, dev)
+parallel.barrier()
+same = (gathered[..., 5:] == full[..., 5:]).all(-1)             # rows whose (class, query index) agree: a near-tie of two scores may swap a pair
+boxes_err = float(((gathered[..., :5] - full[..., :5]).abs() * same[..., None]).max() / full[..., :5].abs().max())
+same_ids = float(same.float().mean())
+print("SHARD_OK " + json.dumps({"rank": rank, "shape": list(gathered.shape), "boxes_err": boxes_err, "same_ids": same_ids, "t": t, "dp": dp,
+                                "device": str(gathered.device), "n_inst": int((full[..., 4] > 0).sum())}))
+parallel.shutdown()
+"""
+
+
+def test_two_processes_shard_the_batch_on_device_tensors():
+    """N > 1 on DEVICE tensors with the hardware a gpurun box has: two processes share cuda:0 (RCCL refuses two ranks on one GPU, so the group
+    runs on gloo and the blocks cross through the host -- parallel.all_gather_predictions), each runs the product forward + the device-side
+    compact predictions on ITS contiguous shard of a 4-image global batch (parallel.shard_range == InferenceSampler._get_local_indices,
+    detectron2/data/samplers/distributed_sampler.py:245-278) and all-gathers; every rank must end up with the block one process computes
+    for the whole batch (class / query ids equal up to swaps of near-tied scores, boxes and scores within the batch-independence bound
+    of test_gpu_e2e)."""
+    import json
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, "-c", SHARD_CHILD % (ROOT, ROOT)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    res = []
+    try:
+        for p in procs:
+            out, err = p.communicate(timeout=400)
+            tag = [l for l in out.splitlines() if l.startswith("SHARD_OK ")]
+            assert p.returncode == 0 and tag, (out[-2000:], err[-3000:])
+            res.append(json.loads(tag[-1][len("SHARD_OK "):]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    res.sort(key=lambda r: r["rank"])
+    for r in res:
+        assert r["shape"] == [4, 20, 7] and r["device"].startswith("cuda") and r["n_inst"] > 0
+        assert r["same_ids"] >= 0.95 and r["boxes_err"] < 1e-3, r
+        assert r["t"] == 2.0 and r["dp"]["rccl_ranks"] == 2 and r["dp"]["backend"] == "gloo" and r["dp"]["global_images"] == 4
+    assert res[0]["dp"]["shard_of_this_rank"] == [0, 2] and res[1]["dp"]["shard_of_this_rank"] == [2, 4]
