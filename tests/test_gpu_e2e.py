@@ -8,7 +8,7 @@ Tolerances (max|a-b| / max|b|, BASELINE.json: "within 1e-3 rel fp16 tolerance"):
   Precision.parity() (fp32 library GEMMs, fp16 attention operands)     a SIDE policy, 2e-3 on the end-to-end fixtures: its IoU-head error sits at
                      0.8 - 1.0e-3 and moves with the library's GEMM algorithm from box to box (measured 9.8e-4 on e2e_tiny, 8.4e-4 / 9.5e-4 /
                      1.0e-3 on e2e_r50_512 on three boxes; tools/policy_margins.py prints every measured error beside its bound); 1e-3 on the
-                     R50 tiny fixture and the backbone stage (35 % of the bound); fails at depth: DESIGN.md section 6;
+                     R50 tiny fixture (measured 3.5e-4) and on the backbone stage; fails at depth: DESIGN.md section 6;
   Precision.fast()   (opt-in: single fp16 operands, fp32 accumulate)   8e-3 on the tiny fixtures (measured 1e-3 .. 6e-3; out of
                      tolerance at the shipped depths -- bench.py prints its numbers as `fast_policy`, never as `value`);
   Precision.bf16()   (bf16 everywhere)                                  8e-2 -- bf16 has 8 mantissa bits, the reference is fp32
