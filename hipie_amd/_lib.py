@@ -59,6 +59,8 @@ SIGNATURES = {
     "hipie_msda_backward_ws": [c_p] * 9 + [c_i] * 8 + [c_p, c_l, c_p],
     "hipie_msda_backward_workspace": [c_i] * 6,
     "hipie_gemm_batched": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l] + [c_i] * 6 + [c_f, c_p],
+    "hipie_gemm_batched_softmax_bias": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l] + [c_i] * 5 + [c_p, c_i, c_p, c_f, c_f, c_p],
+    "hipie_gemm_batched_resid": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l] + [c_i] * 5 + [c_f, c_p],
     "hipie_gemm_batched_softmax": [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l] + [c_i] * 5 + [c_p, c_i, c_f, c_f, c_p],
     "hipie_softmax_hl8": [c_p, c_l, c_p, c_l, c_l, c_i, c_i, c_p, c_l, c_f, c_p],
     "hipie_attn_f32": [c_p] * 5 + [c_i] * 5 + [c_l] * 6 + [c_f, c_p],

@@ -63,6 +63,8 @@ struct GemmParams {
   const unsigned char* sm_mask;
   // residual add + LayerNorm in the epilogue (hipie_gemm_ln: N = 256 = ONE column tile, so a workgroup holds whole rows):
   // y = LN(alpha * acc + bias + resid) * ln_g + ln_b; out = y as fp32, out2 (optional) = y as HL8 rows (row stride ldo2 fp16 elements)
+  const float* sm_bias = nullptr;            // softmax epilogue (VAR 8): per-column logit bias, (n_outer * n_inner, N) fp32, added before the clamp
+  long r_bo = 0, r_bi = 0;                   // batched form: offsets of `resid` per outer / inner index in fp32 ELEMENTS (bias is shared)
   const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 0.f;
   char* out2 = nullptr; long ldo2 = 0;
   int variant;                // timing experiments (HIPIE_GEMM_VARIANTS builds only)
@@ -253,6 +255,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams pin) {
     p.W += bo * p.w_bo + bi * p.w_bi;
     p.out += bo * p.o_bo + bi * p.o_bi;
     if (p.sm_mask != nullptr) p.sm_mask += (long)bo * p.sm_L;
+    if (p.sm_bias != nullptr) p.sm_bias += (long)blockIdx.y * p.N;
+    if (p.resid != nullptr) p.resid += bo * p.r_bo + bi * p.r_bi;
   }
   constexpr int BM = 256;
   constexpr int ROWS = BM + BN;                // rows of one LDS stage: the A tile then the W tile
@@ -523,13 +527,15 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams pin) {
     p.alpha = 1.f; p.act = 0; p.oscale = 1.f; p.out_fmt = HIPIE_F32;   // compile-time facts of this instance from here on
     has_res = false;
   }
-  if (SPLIT && VAR == 0 && BN == 256 && p.softmax) {
+  if (SPLIT && (VAR == 0 || VAR == 8) && BN == 256 && p.softmax) {
     // ---- row softmax over the tile's columns (the whole row: one column tile).  A lane owns 64 of its token's 256 columns per token
     //      tile (its lane half's 4 of every 8, this wave's 128-column half): lane-local reduction, one exchange with the other lane half
     //      (xor 32), one with the partner wave (wn ^ 1) through LDS.  Column validity enters as a 0 / -inf table. ----
     float* kb = sbias + 256;                    // [256] 0 | -inf per column
     float* red = kb + 256;                      // [2 wn][256 tokens] partial max, then partial sums
+    float* cb = red + 512;                      // [256] VAR 8: the logit bias of the column (q-side bias folded into the keys: bq . k_j)
     if (tid < 256) kb[tid] = (tid < p.sm_L && (p.sm_mask == nullptr || p.sm_mask[tid] != 0)) ? 0.f : -INFINITY;
+    if (VAR == 8 && tid < 256) cb[tid] = (p.sm_bias != nullptr && tid < p.N) ? p.sm_bias[tid] : 0.f;
     __syncthreads();
     const float cl = p.sm_clamp;
     float mx[2] = {-INFINITY, -INFINITY};
@@ -540,9 +546,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams pin) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 k4 = *reinterpret_cast<const f32x4*>(kb + wn * (BN / 2) + j * 32 + 8 * g + 4 * hi);
+          f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
+          if (VAR == 8) c4 = *reinterpret_cast<const f32x4*>(cb + wn * (BN / 2) + j * 32 + 8 * g + 4 * hi);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float x = acc[j][t][4 * g + e] * p.alpha;
+            if (VAR == 8) x += c4[e];
             if (cl > 0.f) x = __builtin_amdgcn_fmed3f(x, -cl, cl);
             x += k4[e];
             acc[j][t][4 * g + e] = x;
@@ -997,6 +1006,34 @@ extern "C" int hipie_gemm_batched(const void* A, int64_t lda, int64_t a_outer, i
   if (gemm2_mode() == 1) return (N % 160 == 0) ? launch_gemm2<5, 0>(p, st, batches) : launch_gemm2<4, 0>(p, st, batches);
 #endif
   return (N % 320 == 0) ? launch_gemm<320, true>(p, st, batches) : launch_gemm<256, true>(p, st, batches);
+}
+
+extern "C" int hipie_gemm_batched_resid(const void* A, int64_t lda, int64_t a_outer, int64_t a_inner, const void* W, int64_t ldw, int64_t w_outer,
+                                        int64_t w_inner, const float* bias, const float* resid, int64_t ldr, int64_t r_outer, int64_t r_inner,
+                                        float* out, int64_t ldo, int64_t o_outer, int64_t o_inner, int n_outer, int n_inner, int M, int N, int K,
+                                        float alpha, void* stream) {
+  HIPIE_REQUIRE(A && W && out, "gemm_batched_resid: null pointer");
+  HIPIE_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 32 == 0, "gemm_batched_resid: M=%d N=%d K=%d (N %% 8, K %% 32)", M, N, K);
+  HIPIE_REQUIRE(n_outer > 0 && n_inner > 0 && (long)n_outer * n_inner <= 65535, "gemm_batched_resid: %d x %d problems", n_outer, n_inner);
+  HIPIE_REQUIRE(lda >= 2 * K && ldw >= 2 * K && lda % 8 == 0 && ldw % 8 == 0, "gemm_batched_resid: operand row strides %ld / %ld", (long)lda, (long)ldw);
+  HIPIE_REQUIRE((long)256 * lda * 2 < (1L << 31) && (long)320 * ldw * 2 < (1L << 31), "gemm_batched_resid: row stride too large");
+  HIPIE_REQUIRE(ldo >= N && ldo % 4 == 0, "gemm_batched_resid: output row stride %ld (>= %d)", (long)ldo, N);
+  HIPIE_REQUIRE(resid == nullptr || (ldr >= N && ldr % 4 == 0 && ((r_outer | r_inner) % 4) == 0), "gemm_batched_resid: residual strides %ld / %ld / %ld",
+                (long)ldr, (long)r_outer, (long)r_inner);
+  HIPIE_REQUIRE(((a_outer | a_inner | w_outer | w_inner) % 8) == 0 && ((o_outer | o_inner) % 4) == 0, "gemm_batched_resid: batch offsets must keep 16-byte alignment");
+  HIPIE_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)bias % 16) == 0 &&
+                ((uintptr_t)resid % 16) == 0, "gemm_batched_resid: pointers must be 16-byte aligned");
+  GemmParams p;
+  p.A = (const char*)A; p.W = (const char*)W; p.bias = bias; p.resid = resid; p.out = (char*)out; p.out_row = nullptr; p.a_row = nullptr;
+  p.lda_b = lda * 2; p.ldw_b = ldw * 2; p.ldr = ldr; p.ldo = ldo;
+  p.M = M; p.N = N; p.K = K; p.nkt = K / 32;
+  p.out_fmt = HIPIE_F32; p.act = 0; p.alpha = alpha; p.oscale = 1.f;
+  p.conv_kpt = 0; p.conv_wp = 0; p.softmax = 0; p.sm_L = 0; p.sm_clamp = 0.f; p.sm_mask = nullptr;
+  p.nbi = n_inner;
+  p.a_bo = a_outer * 2; p.a_bi = a_inner * 2; p.w_bo = w_outer * 2; p.w_bi = w_inner * 2; p.o_bo = o_outer * 4; p.o_bi = o_inner * 4;
+  p.r_bo = r_outer; p.r_bi = r_inner;
+  p.prio_mode = 0; p.variant = 0;
+  return (N % 320 == 0) ? launch_gemm<320, true>(p, (hipStream_t)stream, n_outer * n_inner) : launch_gemm<256, true>(p, (hipStream_t)stream, n_outer * n_inner);
 }
 
 extern "C" int hipie_gemm_batched_softmax(const void* A, int64_t lda, int64_t a_outer, int64_t a_inner, const void* W, int64_t ldw, int64_t w_outer,

@@ -36,3 +36,35 @@ extern "C" int hipie_gemm_ln(const void* A, int64_t lda, const void* W, int64_t 
   hipStream_t st = (hipStream_t)stream;
   return a_f32 ? launch_gemm<256, true, 6>(p, st) : launch_gemm<256, true, 4>(p, st);
 }
+
+// The image -> text direction of the vision-language fusion with the visual projections folded into the text side:
+//   logits[b, h][i, j] = x_i . M_{b,h,j} + c_{b,h,j},   M = k_h W_q,h (L x 256),  c = k_h . b_q,h
+// -- hipie_gemm_batched_softmax with a per-column logit bias added before the clamp (instance VAR 8 of gemm_kernel, built here) --
+//   out[b] = P[b] (Nv x heads * Lp) . U[b]^T + bias + resid,   U = W_o,h V_h^T  (hipie_gemm_batched_resid: the batched GEMM with the plain
+// GEMM's bias / residual epilogue; `resid` moves with the outer / inner index like `out`).
+extern "C" int hipie_gemm_batched_softmax_bias(const void* A, int64_t lda, int64_t a_outer, int64_t a_inner, const void* W, int64_t ldw,
+                                               int64_t w_outer, int64_t w_inner, void* out, int64_t ldo, int64_t o_outer, int64_t o_inner,
+                                               int n_outer, int n_inner, int M, int N, int K, const unsigned char* mask, int L,
+                                               const float* col_bias, float clamp, float alpha, void* stream) {
+  using namespace hipie;
+  HIPIE_REQUIRE(A && W && out, "gemm_batched_softmax_bias: null pointer");
+  HIPIE_REQUIRE(M > 0 && N > 0 && N <= 256 && N % 8 == 0 && K > 0 && K % 32 == 0 && L > 0 && L <= N,
+                "gemm_batched_softmax_bias: M=%d N=%d K=%d L=%d (N <= 256: the row must fit one column tile)", M, N, K, L);
+  HIPIE_REQUIRE(n_outer > 0 && n_inner > 0 && (long)n_outer * n_inner <= 65535, "gemm_batched_softmax_bias: %d x %d problems", n_outer, n_inner);
+  HIPIE_REQUIRE(lda >= 2 * K && ldw >= 2 * K && lda % 8 == 0 && ldw % 8 == 0, "gemm_batched_softmax_bias: operand row strides %ld / %ld", (long)lda, (long)ldw);
+  HIPIE_REQUIRE((long)256 * lda * 2 < (1L << 31) && (long)256 * ldw * 2 < (1L << 31), "gemm_batched_softmax_bias: row stride too large");
+  HIPIE_REQUIRE(ldo >= 2 * N && ldo % 4 == 0, "gemm_batched_softmax_bias: output row stride %ld (HL8: >= %d)", (long)ldo, 2 * N);
+  HIPIE_REQUIRE(((a_outer | a_inner | w_outer | w_inner) % 8) == 0 && ((o_outer | o_inner) % 4) == 0, "gemm_batched_softmax_bias: batch offsets must keep 16-byte alignment");
+  HIPIE_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)col_bias % 16) == 0,
+                "gemm_batched_softmax_bias: pointers must be 16-byte aligned");
+  GemmParams p;
+  p.A = (const char*)A; p.W = (const char*)W; p.bias = nullptr; p.resid = nullptr; p.out = (char*)out; p.out_row = nullptr; p.a_row = nullptr;
+  p.lda_b = lda * 2; p.ldw_b = ldw * 2; p.ldr = 0; p.ldo = ldo;
+  p.M = M; p.N = N; p.K = K; p.nkt = K / 32;
+  p.out_fmt = HIPIE_HL8; p.act = 0; p.alpha = alpha; p.oscale = 1.f;
+  p.nbi = n_inner;
+  p.a_bo = a_outer * 2; p.a_bi = a_inner * 2; p.w_bo = w_outer * 2; p.w_bi = w_inner * 2; p.o_bo = o_outer * 2; p.o_bi = o_inner * 2;
+  p.conv_kpt = 0; p.conv_wp = 0; p.prio_mode = 0; p.variant = 0;
+  p.softmax = 1; p.sm_L = L; p.sm_clamp = clamp; p.sm_mask = mask; p.sm_bias = col_bias;
+  return launch_gemm<256, true, 8>(p, (hipStream_t)stream, n_outer * n_inner);
+}

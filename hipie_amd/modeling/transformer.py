@@ -406,6 +406,8 @@ class BiMultiHeadAttention(nn.Module):
         if attention_mask_l is None:
             attention_mask_l = torch.ones(B, L, dtype=torch.uint8, device=v.device)
         keep = attention_mask_l != 0
+        if ops.bi_i2t_folded_ok(v, L, n_keys):
+            return self._forward_folded(v, l, keep, gamma_v, wq, bq, n_keys, resid_v)
         vh = ops.to_hl8(v.float().contiguous())                                 # the visual stream once, for its three projections
         q_hl8 = _lin(self, "q_scaled", vh, wq, bq, out_fmt=ops.HL8, x_hl8=True)
         # the text -> image direction reads the same scaled projection as single fp16: that is the `hi` half of every HL8 group (hi = fp16(x)
@@ -424,6 +426,44 @@ class BiMultiHeadAttention(nn.Module):
             self.resid_fused = True
             return ops.split_linear(ov, self, "out_scaled", wo, bo, resid=resid_v), self.out_l_proj(ol)
         return _lin(self, "out_scaled", ov, wo, bo).to(self.out_v_proj.out_dtype), self.out_l_proj(ol)
+
+    def _forward_folded(self, v, l, keep, gamma_v, wq, bq, n_keys, resid_v):
+        """Precision.split3, texts with at most 256 attended tokens (every shipped prompt but the open-vocabulary captions of configs[3] / [4]):
+        both directions WITHOUT the two visual-side projections of width embed_dim (174080 x 2048 x 256 each at the headline size).  With
+        M[b,h,j] = k_{b,j,h} W_q,h (a 256-vector per text token and head) the logits are x_i . M[b,h,j] + b_q,h . k_{b,j,h} -- the visual
+        stream itself is the operand:
+          image -> text  ops.bi_i2t_folded: softmax_j in the epilogue of ONE batched split GEMM over x (P as HL8), then out = P . (V_text W_o^T)
+                         with bias, gamma and the block's residual in the epilogue of the second (fuse_helper.py:77-121, 131-137);
+          text -> image  queries M (fp16), keys AND values the fp16 visual stream shared by all heads (hipie_flash_attn, head stride 0);
+                         the value projection moves behind the attention, onto the L text rows: sum_i P'[j,i] (W_v x_i + b_v) =
+                         W_v (sum_i P'[j,i] x_i) + b_v (fuse_helper.py:85-95, 122-130).  The per-text-token logit bias is constant along the
+                         visual tokens and drops out of that softmax."""
+        B, Nv, C = v.shape
+        L = l.shape[1]
+        H, hd = self.num_heads, self.head_dim
+        v = v.contiguous()
+        vh = ops.to_hl8(v)
+        k32 = self.l_proj(l)                                                    # (B, L, E)
+        vl32 = self.values_l_proj(l)
+        kh = k32.view(B, L, H, hd).permute(0, 2, 1, 3)                          # (B, H, L, hd)
+        M = torch.matmul(kh, wq.float().view(1, H, hd, C))                      # (B, H, L, C): k_h W_q,h, fp32
+        cb = (kh * bq.float().view(1, H, 1, hd)).sum(-1)                        # (B, H, L)
+        Lk = L if not n_keys or n_keys >= L else int(n_keys)
+        if gamma_v is None:
+            wo, bo = self.out_v_proj.weight, self.out_v_proj.bias
+        else:
+            wo, bo = self._scaled_out(gamma_v)
+        fuse_resid = resid_v is not None and resid_v.dtype == torch.float32 and resid_v.is_contiguous() and gamma_v is not None
+        ov = ops.bi_i2t_folded(vh, M[:, :, :Lk].contiguous(), cb[:, :, :Lk].contiguous(), vl32[:, :Lk].contiguous(), keep[:, :Lk], H, wo, bo,
+                               resid=resid_v if fuse_resid else None, clamp=50000.0)
+        self.resid_fused = fuse_resid
+        x16 = v.half()
+        kx = x16.view(B, Nv, 1, C).expand(B, Nv, H, C)                          # every head reads the same keys / values
+        q16 = M.half().permute(0, 2, 1, 3)                                      # (B, L, H, C) view
+        olx = ops.flash_attn(q16, kx, kx, 1.0, clamp=50000.0, out_f32=True)     # (B, L, H * C): sum_i P'[j,i] x_i per head
+        wv = self.values_v_proj
+        ol = torch.einsum("blhc,hec->blhe", olx.view(B, L, H, C), wv.weight.float().view(H, hd, C)).reshape(B, L, H * hd) + wv.bias.float()
+        return ov.to(self.out_v_proj.out_dtype), self.out_l_proj(ol)
 
     def _scaled_out(self, gamma):
         p = self.out_v_proj

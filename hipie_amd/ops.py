@@ -282,6 +282,64 @@ def bi_i2t_split(q_hl8, k, vl, text_mask, heads, clamp=50000.0, n_keys=None):
     return out
 
 
+def bi_i2t_folded_ok(v, L_text, n_keys=None):
+    """the folded vision-language attention applies: at most 256 attended text columns (one column tile of the softmax epilogue), a visual
+    width the split GEMM takes (and the fp16 attention kernel as a head dim: 256), inference"""
+    L = L_text if not n_keys else min(int(n_keys), L_text)
+    return v.is_cuda and v.dtype == torch.float32 and v.shape[-1] == 256 and 0 < L <= 256 and not torch.is_grad_enabled()
+
+
+@_timed("bi_i2t_folded")
+def bi_i2t_folded(v_hl8, M, cb, vl, text_mask, heads, wo, bo, resid=None, clamp=50000.0):
+    """image -> text direction of the vision-language fusion (fuse_helper.py:62-139) at fp32-class accuracy WITHOUT the two visual-side
+    projections of width E = heads * hd:
+        logits[b,h][i,j] = (wq_h x_i + bq_h) . k[b,j,h] = x_i . M[b,h,j] + cb[b,h,j]       M = k_h wq_h (L x C), cb = k_h . bq_h
+        out[b,i]         = wo concat_h(P_h[i] vl_h) + bo (+ resid) = sum_h P_h[i] . U[b,h] + bo      U = vl_h wo_h^T (L x C_out)
+    v_hl8 (B, Nv, 2C) HL8 of the (layer-normed) visual stream x; M (B, H, L, C), cb (B, H, L) fp32 (the caller's small text-side products,
+    already cut to the attended columns); vl (B, L, E) fp32 text values; wo (C_out, E), bo (C_out) the output projection; resid (B, Nv, C_out)
+    fp32 or None -> (B, Nv, C_out) fp32.  TWO launches over the visual tokens (hipie_gemm_batched_softmax_bias: P as HL8, the logits never
+    exist; hipie_gemm_batched_resid: K = heads * Lp).  L <= 256.  The reassociation moves the rounding of the logits at the 1e-7 level."""
+    lib = _lib.load()
+    B, Nv, C2 = v_hl8.shape
+    C = C2 // 2
+    L = M.shape[2]
+    E = vl.shape[-1]
+    hd = E // heads
+    Lp = (L + 31) // 32 * 32
+    Co = wo.shape[0]
+    if v_hl8.dtype != torch.float16 or not v_hl8.is_contiguous() or M.dtype != torch.float32 or vl.dtype != torch.float32 or Lp > 256 or Co % 8 \
+            or tuple(M.shape) != (B, heads, L, C) or tuple(cb.shape) != (B, heads, L) or vl.shape[1] != L:
+        raise RuntimeError("bi_i2t_folded: x HL8 (fp16) contiguous, M (B, H, L, C) / cb (B, H, L) / vl (B, L, E) fp32, at most 256 text columns")
+    dev = v_hl8.device
+    Mp = torch.zeros(B, heads, Lp, C, dtype=torch.float32, device=dev)
+    Mp[:, :, :L] = M
+    cbp = torch.zeros(B, heads, Lp, dtype=torch.float32, device=dev)
+    cbp[:, :, :L] = cb
+    m_hl8 = to_hl8(Mp)                                                                 # (B, H, Lp, 2C)
+    U = torch.zeros(B, Co, heads, Lp, dtype=torch.float32, device=dev)
+    U[..., :L] = torch.einsum("nhd,blhd->bnhl", wo.float().view(Co, heads, hd), vl.reshape(B, L, heads, hd))
+    u_hl8 = to_hl8(U.view(B, Co, heads * Lp))                                          # (B, C_out, 2 H Lp): K = (head, text token)
+    P = torch.empty(B, Nv, heads * 2 * Lp, dtype=torch.float16, device=dev)
+    mk = text_mask.to(torch.uint8).contiguous()
+    rc = lib.hipie_gemm_batched_softmax_bias(v_hl8.data_ptr(), 2 * C, Nv * 2 * C, 0, m_hl8.data_ptr(), 2 * C, heads * Lp * 2 * C, Lp * 2 * C,
+                                             P.data_ptr(), heads * 2 * Lp, Nv * heads * 2 * Lp, 2 * Lp, B, heads, Nv, Lp, C, mk.data_ptr(), L,
+                                             cbp.data_ptr(), float(clamp), 1.0, _stream())
+    _lib.check(rc, "hipie_gemm_batched_softmax_bias")
+    out = torch.empty(B, Nv, Co, dtype=torch.float32, device=dev)
+    r = None
+    if resid is not None:
+        r = resid.reshape(B, Nv, Co)
+        if r.dtype != torch.float32 or not r.is_contiguous():
+            raise RuntimeError("bi_i2t_folded: resid must be contiguous fp32 (B, Nv, C_out)")
+    bo32 = None if bo is None else bo.float().contiguous()
+    KK = heads * Lp
+    rc = lib.hipie_gemm_batched_resid(P.data_ptr(), 2 * KK, Nv * 2 * KK, 0, u_hl8.data_ptr(), 2 * KK, Co * 2 * KK, 0,
+                                      None if bo32 is None else bo32.data_ptr(), None if r is None else r.data_ptr(),
+                                      Co, Nv * Co, 0, out.data_ptr(), Co, Nv * Co, 0, B, 1, Nv, Co, KK, 1.0, _stream())
+    _lib.check(rc, "hipie_gemm_batched_resid")
+    return out
+
+
 def _small_attn(fn_name, q, k, v, scale, key_mask):
     lib = _lib.load()
     B, Nq, H, hd = q.shape

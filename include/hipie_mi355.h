@@ -539,6 +539,25 @@ int hipie_gemm_batched_softmax(const void* A, int64_t lda, int64_t a_outer, int6
                                int N, int K, const unsigned char* mask, int L, float clamp, float alpha, void* stream);
 
 /*
+ * The image -> text direction of BiMultiHeadAttention (models/deformable_detr/fuse_helper.py:62-139) with the two visual-side projections
+ * FOLDED into the text side, so that nothing of width embed_dim (2048) is ever computed per visual token:
+ *     logits[b,h][i,j] = (W_q,h x_i + b_q,h) . k_{b,j,h} = x_i . M_{b,h,j} + c_{b,h,j},      M = k_h W_q,h  (L x 256),  c = k_h . b_q,h
+ *     out_v[b][i]      = W_o concat_h( P_h[i,:] V_h ) + b_o = sum_h P_h[i,:] . U_{b,h} + b_o,   U = V_h W_o,h^T  (L x 256)
+ * hipie_gemm_batched_softmax_bias: hipie_gemm_batched_softmax with col_bias (n_outer * n_inner, N) fp32 added to the scaled accumulator BEFORE
+ * the clamp (the reference clamps q . k including the bias); A may be shared by the inner index (a_inner = 0: every head reads x).
+ * hipie_gemm_batched_resid: hipie_gemm_batched (fp32 out) with hipie_gemm's bias (shared) and residual epilogue; resid moves with the
+ * problem index like out (r_outer / r_inner in fp32 elements).  One launch each per fusion layer.
+ */
+int hipie_gemm_batched_softmax_bias(const void* A, int64_t lda, int64_t a_outer, int64_t a_inner, const void* W, int64_t ldw, int64_t w_outer,
+                                    int64_t w_inner, void* out, int64_t ldo, int64_t o_outer, int64_t o_inner, int n_outer, int n_inner,
+                                    int M, int N, int K, const unsigned char* mask, int L, const float* col_bias, float clamp, float alpha,
+                                    void* stream);
+int hipie_gemm_batched_resid(const void* A, int64_t lda, int64_t a_outer, int64_t a_inner, const void* W, int64_t ldw, int64_t w_outer,
+                             int64_t w_inner, const float* bias, const float* resid, int64_t ldr, int64_t r_outer, int64_t r_inner, float* out,
+                             int64_t ldo, int64_t o_outer, int64_t o_inner, int n_outer, int n_inner, int M, int N, int K, float alpha,
+                             void* stream);
+
+/*
  * Row softmax of fp32 logits written as an HL8 operand:  P[r, :Lp] = softmax over the L valid columns of clamp(S[r, :L], +-clamp) with
  * columns masked by mask[r / rows_per_batch, :] (uint8, 1 = keep; NULL = all) or beyond L set to 0.  S rows lds floats apart, P rows
  * ldp fp16 elements apart (>= 2 * Lp);  Lp a multiple of 8, <= 4096.  A row with no valid column gives zeros (DEVIATION, never reached

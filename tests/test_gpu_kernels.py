@@ -1459,3 +1459,75 @@ def test_bi_i2t_split(B, Nv, L, heads, hd):
     e = rel_err(got.cpu(), want.float())
     print("bi_i2t_split Nv=%d L=%d: %.2e" % (Nv, L, e))
     assert got.shape == (B, Nv, E) and e < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Nv,L,heads,hd,C", [(2, 1000, 30, 8, 256, 256), (1, 21760, 194, 8, 256, 256), (2, 300, 256, 2, 64, 256)])
+def test_bi_i2t_folded(B, Nv, L, heads, hd, C):
+    """ops.bi_i2t_folded -- the image -> text direction with the visual-side projections folded into the text side (one batched split GEMM with
+    the masked softmax and the per-column logit bias in its epilogue, one batched GEMM with bias + residual) -- against the reference order of
+    operations in double (fuse_helper.py:62-139: v_proj * scale, q . k, clamp, -9e15 mask, softmax over the text tokens, bmm with the text
+    values, out_v_proj); logits of magnitude ~20, a partly masked text, the residual in the epilogue."""
+    from hipie_amd import ops
+    g = torch.Generator().manual_seed(L + Nv)
+    E = heads * hd
+    x = torch.randn(B, Nv, C, generator=g)
+    wq = torch.randn(E, C, generator=g) * (0.9 / C ** 0.5)
+    bq = torch.randn(E, generator=g) * 0.3
+    k = torch.randn(B, L, E, generator=g) * 0.9
+    vl = torch.randn(B, L, E, generator=g)
+    wo = torch.randn(C, E, generator=g) * E ** -0.5
+    bo = torch.randn(C, generator=g)
+    resid = torch.randn(B, Nv, C, generator=g)
+    mask = torch.ones(B, L, dtype=torch.bool)
+    mask[0, L - L // 4:] = False
+    xd, kd, vd = x.double(), k.double().view(B, L, heads, hd), vl.double().view(B, L, heads, hd)
+    qd = (xd @ wq.double().t() + bq.double()).view(B, Nv, heads, hd)
+    w = torch.einsum("bnhd,blhd->bhnl", qd, kd).clamp(-50000, 50000)
+    am = mask.long()[:, None, None, :].expand(B, 1, Nv, L).clone()
+    am = am.masked_fill(am == 0, int(-9e15))
+    attn = torch.einsum("bhnl,blhd->bnhd", (w + am).softmax(-1), vd).reshape(B, Nv, E)
+    want = attn @ wo.double().t() + bo.double() + resid.double()
+    kh = k.to(DEV).view(B, L, heads, hd).permute(0, 2, 1, 3)
+    M = torch.matmul(kh, wq.to(DEV).view(1, heads, hd, C))
+    cb = (kh * bq.to(DEV).view(1, heads, 1, hd)).sum(-1)
+    got = ops.bi_i2t_folded(ops.to_hl8(x.to(DEV)), M.contiguous(), cb.contiguous(), vl.to(DEV), mask.to(DEV), heads, wo.to(DEV), bo.to(DEV),
+                            resid=resid.to(DEV))
+    e = rel_err(got.cpu(), want.float())
+    print("bi_i2t_folded Nv=%d L=%d: %.2e" % (Nv, L, e))
+    assert got.shape == (B, Nv, C) and e < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,n_keys", [(40, None), (194, None), (300, 150)])
+def test_bi_attention_folded_matches_the_projected_form(L, n_keys):
+    """BiMultiHeadAttention in the split policy: the folded form (no visual projection of width embed_dim: transformer._forward_folded) against
+    the projected form (q / values projections of every visual token, ops.bi_i2t_split + the flash kernel) on the same module: the visual update
+    at fp32 class (2e-5), the text update at the fp16-operand class of that direction (2e-3); a text with trailing masked tokens and n_keys."""
+    import hipie_amd.modeling.transformer as T
+    from hipie_amd import ops
+    torch.manual_seed(L)
+    m = T.BiMultiHeadAttention(256, 768, 2048, 8, torch.float16).cuda()
+    for p in m.parameters():
+        torch.nn.init.normal_(p, std=0.03)
+    T.set_split(m)
+    B, Nv = 2, 3000
+    v = torch.randn(B, Nv, 256, device="cuda")
+    l = torch.randn(B, L, 768, device="cuda")
+    mask = torch.ones(B, L, dtype=torch.uint8, device="cuda")
+    if n_keys:
+        mask[:, n_keys:] = 0
+    mask[1, (n_keys or L) - 7:] = 0
+    gamma = torch.rand(256, device="cuda") + 0.5
+    assert ops.bi_i2t_folded_ok(v, L, n_keys)
+    fv, fl = m(v, l, attention_mask_l=mask, gamma_v=gamma, n_keys=n_keys, resid_v=v)
+    assert m.resid_fused
+    keep = ops.bi_i2t_folded_ok
+    ops.bi_i2t_folded_ok = lambda *a: False
+    try:
+        pv, pl = m(v, l, attention_mask_l=mask, gamma_v=gamma, n_keys=n_keys, resid_v=v)
+    finally:
+        ops.bi_i2t_folded_ok = keep
+    ev, el = rel_err((fv - v).cpu(), (pv - v).cpu()), rel_err(fl.cpu(), pl.cpu())
+    print("folded vs projected, L=%d: visual update %.2e, text update %.2e" % (L, ev, el))
+    assert ev < 2e-5 and el < 2e-3
