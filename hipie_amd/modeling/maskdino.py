@@ -17,7 +17,7 @@ from .. import ops
 from .transformer import (MLP, _select_topk, DeformableTransformerDecoderLayer, DeformableTransformerEncoderLayer, FeatureResizer, geo_cached,
                           PConv2d, PGroupNorm, PLayerNorm, PLinear, PositionEmbeddingSine, _get_clones, encoder_reference_points,
                           gen_encoder_output_proposals, level_tensors,
-                          batched_decoder_values, decoder_box_refine, decoder_split_values, decoder_fast_path, decoder_query_pos)
+                          batched_decoder_values, decoder_box_refine, decoder_split_values, selected_proposal_boxes, decoder_fast_path, decoder_query_pos)
 
 
 class NormConv2d(PConv2d):
@@ -241,13 +241,13 @@ class MaskDINODecoder(nn.Module):
         om, prop = gen_encoder_output_proposals(src, mask, shapes_list, gk)
         om = self.enc_output_norm(self.enc_output(om))
         cls_un = self.class_embed(om)
-        coord_un = self._bbox_embed(om) + prop
         if self.pinned_topk is not None:
             topk = self.pinned_topk.to(src.device)
         else:
             topk = _select_topk(cls_un.max(-1)[0], self.num_queries)
         self.last_topk = topk
-        ref_un = torch.gather(coord_un, 1, topk.unsqueeze(-1).repeat(1, 1, 4))
+        # the box head on the selected proposals only (maskdino_decoder.py:396-405 heads every token, then gathers: the same rows)
+        ref_un = selected_proposal_boxes(self._bbox_embed, om, prop, topk)
         tgt = torch.gather(om, 1, topk.unsqueeze(-1).repeat(1, 1, self.hidden_dim))
         # einsum #1 (:428): interm_outputs
         interm_cls, interm_mask = self.forward_prediction_heads(tgt, mask_features, pred_mask=self.initial_pred_masks)

@@ -924,13 +924,20 @@ class DeformableTransformerVLDINO(nn.Module):
         om = self.enc_output_norm(self.enc_output(om))
         nd = self.decoder.num_layers
         enc_cls = self.decoder.class_embed[nd](om, None)
-        enc_coord = self.decoder.bbox_embed[nd](om) + prop
+        # inference: the box head runs on the SELECTED proposals only (row-wise the same arithmetic as heading every token and gathering
+        # afterwards -- deformable_transformer_dino.py:216-231 -- minus a 3-layer MLP over all 21760 tokens per image); the per-token
+        # boxes are an output of the training step alone (encoder loss), which keeps the full form
+        lazy_boxes = not torch.is_grad_enabled()
+        enc_coord = None if lazy_boxes else self.decoder.bbox_embed[nd](om) + prop
         if self.pinned_topk is not None:
             topk = self.pinned_topk.to(src.device)
         else:
             topk = _select_topk(enc_cls[..., 0], self.two_stage_num_proposals)
         self.last_topk = topk
-        ref = torch.gather(enc_coord, 1, topk.unsqueeze(-1).repeat(1, 1, 4)).sigmoid()
+        if lazy_boxes:
+            ref = selected_proposal_boxes(self.decoder.bbox_embed[nd], om, prop, topk).sigmoid()
+        else:
+            ref = torch.gather(enc_coord, 1, topk.unsqueeze(-1).repeat(1, 1, 4)).sigmoid()
         tgt = self.tgt_embed.weight[None].repeat(bs, 1, 1)
         if self.background_proposals > 0:
             tgt = torch.cat([self.tgt_embed_bg.weight[None].repeat(bs, 1, 1), tgt], dim=1)
@@ -938,6 +945,13 @@ class DeformableTransformerVLDINO(nn.Module):
         init_ref = ref
         hs, inter_refs = self.decoder(tgt.float(), ref.float(), memory, spatial_shapes, level_start_index, valid_ratios, layer_mask)
         return hs, memory, init_ref, inter_refs, enc_cls, enc_coord, language_dict_features, shapes_list
+
+
+def selected_proposal_boxes(bbox_embed, om, prop, topk):
+    """bbox_embed(om)[topk] + prop[topk] computed on the gathered rows: (B, k, 4) un-activated boxes of the selected proposals."""
+    om_k = torch.gather(om, 1, topk.unsqueeze(-1).expand(-1, -1, om.shape[-1]))
+    prop_k = torch.gather(prop.expand(om.shape[0], -1, -1), 1, topk.unsqueeze(-1).expand(-1, -1, prop.shape[-1]))
+    return bbox_embed(om_k) + prop_k
 
 
 def _select_topk(scores, k):
