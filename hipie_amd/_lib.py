@@ -53,7 +53,6 @@ SIGNATURES = {
     "hipie_group_norm": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_i, c_p],
     "hipie_gemm": [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p] + [c_i] * 6 + [c_f, c_f, c_p],
     "hipie_gemm_ln": [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_p, c_f, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_p],
-    "hipie_gemm_rowtable": [c_p, c_l, c_p, c_l, c_p, c_p, c_l, c_i, c_p, c_l, c_i, c_i, c_i, c_i, c_p],
     "hipie_gemm_gather": [c_p, c_l, c_l, c_p, c_p, c_l, c_p, c_p, c_l, c_p, c_l, c_p] + [c_i] * 6 + [c_f, c_f, c_p],
     "hipie_vit_attn_split": [c_p, c_p, c_p, c_p] + [c_i] * 5 + [c_p],
     "hipie_msda_backward": [c_p] * 9 + [c_i] * 8 + [c_p],

@@ -63,7 +63,6 @@ struct GemmParams {
   const unsigned char* sm_mask;
   // residual add + LayerNorm in the epilogue (hipie_gemm_ln: N = 256 = ONE column tile, so a workgroup holds whole rows):
   // y = LN(alpha * acc + bias + resid) * ln_g + ln_b; out = y as fp32, out2 (optional) = y as HL8 rows (row stride ldo2 fp16 elements)
-  int res_mod = 0;                           // VAR 10: the residual of output row m is resid row m % res_mod (a per-position table shared by the images of a batch)
   const float* sm_bias = nullptr;            // softmax epilogue (VAR 8): per-column logit bias, (n_outer * n_inner, N) fp32, added before the clamp
   long r_bo = 0, r_bi = 0;                   // batched form: offsets of `resid` per outer / inner index in fp32 ELEMENTS (bias is shared)
   const float* ln_g = nullptr; const float* ln_b = nullptr; float ln_eps = 0.f;
@@ -607,13 +606,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams pin) {
     const int m = m0 + wm * 64 + t * 32 + li;
     orow[t] = (m < p.M) ? (p.out_row != nullptr ? (long)p.out_row[m] : (long)m) : -1;
   }
-  long rrow[2] = {orow[0], orow[1]};          // residual row (VAR 10: modulo a table height)
-  if (VAR == 10 && p.res_mod > 0) { rrow[0] = orow[0] < 0 ? 0 : orow[0] % p.res_mod; rrow[1] = orow[1] < 0 ? 0 : orow[1] % p.res_mod; }
   auto load_res = [&](const int t, const int j, float4 (&dst)[4]) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int n = n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * hi;
-      dst[g] = (has_res && orow[t] >= 0 && n < p.N) ? *reinterpret_cast<const float4*>(p.resid + rrow[t] * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dst[g] = (has_res && orow[t] >= 0 && n < p.N) ? *reinterpret_cast<const float4*>(p.resid + orow[t] * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   // LayerNorm epilogue: the normalised rows leave twice -- fp32 (the stream), then HL8 (the operand of the GEMM that follows)

@@ -68,30 +68,3 @@ extern "C" int hipie_gemm_batched_softmax_bias(const void* A, int64_t lda, int64
   p.softmax = 1; p.sm_L = L; p.sm_clamp = clamp; p.sm_mask = mask; p.sm_bias = col_bias;
   return launch_gemm<256, true, 8>(p, (hipStream_t)stream, n_outer * n_inner);
 }
-
-// hipie_gemm (split operands, fp32 out) whose "residual" is a per-POSITION table shared by the images of a batch: out[m] = A[m] . W^T + bias +
-// table[m % table_rows].  One launch computes value_proj(src), sampling_offsets(src + pos) and attention_weights(src + pos) of a deformable
-// encoder layer from ONE operand: W (src + pos) = W src + (W pos), and W pos + b is a constant of the geometry (ms_deform_attn.py:93-99).
-extern "C" int hipie_gemm_rowtable(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* table, int64_t ldt,
-                                   int table_rows, float* out, int64_t ldo, int M, int N, int K, int in_fmt, void* stream) {
-  using namespace hipie;
-  HIPIE_REQUIRE(A && W && out && table, "gemm_rowtable: null pointer");
-  HIPIE_REQUIRE(in_fmt == HIPIE_HL8, "gemm_rowtable: operand format %d (HIPIE_HL8)", in_fmt);
-  HIPIE_REQUIRE(M > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 32 == 0 && table_rows > 0, "gemm_rowtable: M=%d N=%d K=%d rows=%d", M, N, K, table_rows);
-  HIPIE_REQUIRE(lda >= 2 * K && ldw >= 2 * K && lda % 8 == 0 && ldw % 8 == 0, "gemm_rowtable: operand row strides %ld / %ld", (long)lda, (long)ldw);
-  HIPIE_REQUIRE((long)256 * lda * 2 < (1L << 31) && (long)320 * ldw * 2 < (1L << 31), "gemm_rowtable: row stride too large");
-  HIPIE_REQUIRE(ldo >= N && ldo % 4 == 0 && ldt >= N && ldt % 4 == 0, "gemm_rowtable: row strides %ld / %ld (>= %d)", (long)ldo, (long)ldt, N);
-  HIPIE_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)bias % 16) == 0 &&
-                ((uintptr_t)table % 16) == 0, "gemm_rowtable: pointers must be 16-byte aligned");
-  GemmParams p;
-  p.A = (const char*)A; p.W = (const char*)W; p.bias = bias; p.resid = table; p.out = (char*)out; p.out_row = nullptr; p.a_row = nullptr;
-  p.lda_b = lda * 2; p.ldw_b = ldw * 2; p.ldr = ldt; p.ldo = ldo;
-  p.M = M; p.N = N; p.K = K; p.nkt = K / 32;
-  p.out_fmt = HIPIE_F32; p.act = 0; p.alpha = 1.f; p.oscale = 1.f;
-  p.nbi = 1; p.a_bo = p.a_bi = p.w_bo = p.w_bi = p.o_bo = p.o_bi = 0;
-  p.conv_kpt = 0; p.conv_wp = 0; p.softmax = 0; p.sm_L = 0; p.sm_clamp = 0.f; p.sm_mask = nullptr;
-  p.res_mod = table_rows;
-  p.prio_mode = 0; p.variant = 0;
-  hipStream_t st = (hipStream_t)stream;
-  return (N % 320 == 0) ? launch_gemm<320, true, 10>(p, st) : launch_gemm<256, true, 10>(p, st);
-}

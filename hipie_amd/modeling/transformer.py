@@ -346,40 +346,6 @@ class MSDeformAttn(nn.Module):
         out = ops.msda_fused(value, input_spatial_shapes, input_level_start_index, reference_points.float().contiguous(), off, logits)
         return self.output_proj(out) if project else out
 
-    def _pos_table(self, pos):
-        """(S, d_model + offsets + weights) fp32: zero over the value columns, W_ol pos + b_ol over the offset / weight columns; None when the
-        images of the batch do not share one position embedding.  Cached per (pos, parameter versions)."""
-        so, aw = self.sampling_offsets, self.attention_weights
-        key = (pos.data_ptr(), pos._version, tuple(pos.shape)) + tuple((p.data_ptr(), p._version) for p in (so.weight, aw.weight, so.bias, aw.bias))
-        if getattr(self, "_pt_key", None) != key:
-            p0 = pos[0]
-            same = pos.shape[0] == 1 or bool((pos == p0[None]).all())            # one host wait per geometry
-            tab = None
-            if same:
-                w, b = self._fused_proj()
-                tab = torch.zeros(p0.shape[0], self.d_model + w.shape[0], dtype=torch.float32, device=pos.device)
-                tab[:, self.d_model:] = _lin(self, "offlog", p0.float().contiguous(), w, b)
-            self._pt, self._pt_key = tab, key
-        return self._pt
-
-    def forward_merged(self, src_h, pos, reference_points, input_spatial_shapes, input_level_start_index):
-        """the sampled values (before output_proj) of an encoder layer whose queries are `src + pos`: ONE split GEMM over the HL8 rows of src with
-        the concatenated [value_proj; sampling_offsets; attention_weights] weights and the per-position table of _pos_table as its addend; the
-        deformable-attention kernel reads the value block and the offset / logit blocks of that single output in place (row strides)."""
-        vp = self.value_proj
-        w_ol, b_ol = self._fused_proj()
-        tab = self._pos_table(pos)
-        params = [vp.weight, vp.bias, w_ol]
-        proj = ops.split_linear_rowtable(src_h, self, "vol", None, None, tab, params=params,
-                                         weight_fn=lambda: torch.cat([vp.weight, w_ol], 0),
-                                         bias_fn=lambda: torch.cat([vp.bias, torch.zeros_like(b_ol)], 0))
-        d, no = self.d_model, self.n_heads * self.n_levels * self.n_points * 2
-        N, S = proj.shape[0], proj.shape[1]
-        value = proj[..., :d].unflatten(-1, (self.n_heads, d // self.n_heads))
-        off = proj[..., d:d + no].unflatten(-1, (self.n_heads, self.n_levels, self.n_points, 2))
-        logits = proj[..., d + no:].unflatten(-1, (self.n_heads, self.n_levels * self.n_points))
-        return ops.msda_fused(value, input_spatial_shapes, input_level_start_index, reference_points.float().contiguous(), off, logits)
-
     def _fused_proj(self):
         so, aw = self.sampling_offsets, self.attention_weights
         key = tuple((p.data_ptr(), p._version, p.dtype) for p in (so.weight, aw.weight, so.bias, aw.bias))
@@ -584,32 +550,19 @@ def _enc_layer_forward_split(self, src, pos, reference_points, spatial_shapes, l
     the deformable-attention output is converted by hipie_to_hl8.  ``carry``: {"src_h", "q_h"} from the previous layer, or None."""
     attn = self.self_attn
     src = src.contiguous()
-    merged = merged_projections_ok(attn, src, pos, padding_mask)
     if isinstance(carry, dict):
-        src_h, q_h = carry["src_h"], carry.get("q_h")
-    elif merged:
-        src_h, q_h = ops.to_hl8(src), None
+        src_h, q_h = carry["src_h"], carry["q_h"]
     elif carry is None:                     # first layer: the query src + pos as ONE pass over the cached HL8 position embedding
         src_h, q_h = ops.to_hl8(src), ops.add_to_hl8(src, _pos_hl8(self, pos))
     else:
         src_h, q_h = ops.to_hl8(src), ops.to_hl8(carry)
+    value = attn.project_value(src_h, padding_mask, x_hl8=True)
     n, op = self.norm1, attn.output_proj
-    if merged:
-        # value_proj(src), sampling_offsets(src + pos), attention_weights(src + pos) from the ONE operand src in one launch:
-        # W (src + pos) = W src + (W pos + b), the second term a per-position constant of the geometry (hipie_gemm_rowtable)
-        sampled = attn.forward_merged(src_h, pos, reference_points, spatial_shapes, level_start_index)
-        src, s_h = ops.split_linear_ln(sampled, op, "w", op.weight, op.bias, src, n.weight, n.bias, n.eps)
-    elif ops.split_linear_ln_ok(src, op.weight, n.weight):
-        if q_h is None:
-            q_h = ops.add_to_hl8(src, _pos_hl8(self, pos))
-        value = attn.project_value(src_h, padding_mask, x_hl8=True)
+    if ops.split_linear_ln_ok(src, op.weight, n.weight):
         # output_proj + residual + norm1 as ONE launch (hipie_gemm_ln: 256 features = one column tile, the rows are whole in the epilogue)
         sampled = attn.forward_projected(q_h, reference_points, value.contiguous(), spatial_shapes, level_start_index, x_hl8=True, project=False)
         src, s_h = ops.split_linear_ln(sampled, op, "w", op.weight, op.bias, src, n.weight, n.bias, n.eps)
     else:
-        if q_h is None:
-            q_h = ops.add_to_hl8(src, _pos_hl8(self, pos))
-        value = attn.project_value(src_h, padding_mask, x_hl8=True)
         src2 = attn.forward_projected(q_h, reference_points, value.contiguous(), spatial_shapes, level_start_index, x_hl8=True)
         src, s_h, _ = ops.add_layernorm_dec(src, src2.contiguous(), n.weight, n.bias, n.eps, "hl8", want16=True)
     if ops.ffn_fused_ok(s_h, self.linear1, self.linear2):
@@ -619,20 +572,8 @@ def _enc_layer_forward_split(self, src, pos, reference_points, spatial_shapes, l
     n = self.norm2
     if not want_query:
         return ops.add_layernorm_dec(src, src2, n.weight, n.bias, n.eps, "hl8")[0]
-    if merged:                              # the next layer takes its query from src alone as well: no `src + pos` operand to emit
-        out, o_h, _ = ops.add_layernorm_dec(src, src2, n.weight, n.bias, n.eps, "hl8", want16=True)
-        return out, {"src_h": o_h}
     out, o_h, q_h = ops.add_layernorm_dec(src, src2, n.weight, n.bias, n.eps, "hl8", want16=True, addend=_pos_hl8(self, pos))
     return out, {"src_h": o_h, "q_h": q_h}
-
-
-def merged_projections_ok(attn, src, pos, padding_mask):
-    """the three projections at the head of an encoder layer's MSDeformAttn run as one GEMM over src (MSDeformAttn.forward_merged): inference, split
-    policy, no padded tokens (value_proj's masked_fill would need its own pass), and a position embedding that is the same for every image of the
-    batch (equal-size images: the rows of `pos` repeat per image -- checked once per geometry and cached with the table)."""
-    return (bool(getattr(attn, "split", False)) and padding_mask is None and src.is_cuda and src.dtype == torch.float32 and not torch.is_grad_enabled()
-            and attn.value_proj.weight.dtype == torch.float32 and attn.value_dtype == torch.float32 and attn.d_model % 32 == 0
-            and attn._pos_table(pos) is not None)
 
 
 def _pos_hl8(layer, pos):

@@ -1433,24 +1433,6 @@ def split_linear_ln(x, owner, key, weight, bias, resid, norm_weight, norm_bias, 
     return out, o16
 
 
-@_timed("gemm_rowtable")
-def split_linear_rowtable(x_hl8, owner, key, weight, bias, table, params=None, weight_fn=None, bias_fn=None):
-    """x W^T + bias + table[row % table_rows] on the split GEMM (hipie_gemm_rowtable): x_hl8 (B, S, 2K) HL8, table (S, N) fp32 -> (B, S, N) fp32."""
-    lib = _lib.load()
-    w, b, N = split_weight(owner, key, params if params is not None else [weight] + ([bias] if bias is not None else []),
-                           weight_fn or (lambda: weight), bias_fn or ((lambda: bias) if bias is not None else None))
-    x2 = x_hl8.reshape(-1, x_hl8.shape[-1])
-    K = w.shape[1] // 2
-    if x2.dtype != torch.float16 or x2.shape[-1] != 2 * K or x2.stride(-1) != 1 or N != w.shape[0] or tuple(table.shape) != (table.shape[0], N) \
-            or table.dtype != torch.float32 or not table.is_contiguous() or x2.shape[0] % table.shape[0]:
-        raise RuntimeError("split_linear_rowtable: x HL8 (rows, 2K), table (S, N) fp32 with rows %% S == 0")
-    out = torch.empty(*x_hl8.shape[:-1], N, dtype=torch.float32, device=x_hl8.device)
-    rc = lib.hipie_gemm_rowtable(x2.data_ptr(), x2.stride(0), _chk(w, "w"), w.shape[1], None if b is None else b.data_ptr(), table.data_ptr(), N,
-                                 table.shape[0], out.data_ptr(), N, x2.shape[0], N, K, HL8, _stream())
-    _lib.check(rc, "hipie_gemm_rowtable")
-    return out
-
-
 _SHUFFLE_MAPS = {}
 
 

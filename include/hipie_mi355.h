@@ -461,15 +461,6 @@ int hipie_gemm_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const 
                   int in_fmt, float alpha, void* stream);
 
 /*
- * hipie_gemm (HL8 operands, fp32 out) with a per-POSITION addend shared by the images of a batch:  out[m] = A[m] . W^T + bias + table[m % table_rows]
- * (table (table_rows, N) fp32, row stride ldt).  One launch for the three projections at the head of MSDeformAttn.forward in an encoder layer --
- * value_proj(src), sampling_offsets(src + pos), attention_weights(src + pos), ops/modules/ms_deform_attn.py:93-99 -- from the ONE operand src:
- * W (src + pos) = W src + (W pos + b), and the second term is a constant of the geometry (zero over the value_proj columns).
- */
-int hipie_gemm_rowtable(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* table, int64_t ldt, int table_rows,
-                        float* out, int64_t ldo, int M, int N, int K, int in_fmt, void* stream);
-
-/*
  * hipie_gemm whose product row m READS operand row a_row[m] (0 <= a_row[m] < a_rows; A is a_rows x K; split formats only; the whole operand
  * below 4 GiB): the linears of the windowed ViT blocks run over the REAL tokens only and pick them out of / scatter them into (out_row) the
  * zero-padded window layout (window_partition pads 64 x 64 tokens to 70 x 70: 19.6 % more rows, whose qkv is the bias and whose projection

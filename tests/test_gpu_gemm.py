@@ -467,59 +467,3 @@ def test_decoder_values_batched_in_the_split_policy():
     finally:
         T.decoder_split_values = keep
     assert rel_err(got.cpu(), want.cpu()) < 2e-6 and rel_err(got_refs.cpu(), want_refs.cpu()) < 2e-6
-
-
-@gpu
-@pytest.mark.parametrize("B,S,N", [(3, 700, 640), (2, 21760, 640), (1, 300, 256)])
-def test_gemm_rowtable(B, S, N):
-    """hipie_gemm_rowtable: out[b, s] = x[b, s] . W^T + bias + table[s] (a per-position addend shared by the images) against fp64, on the wide
-    (320-column) and the 256-column tiles, M not a multiple of the tile."""
-    from hipie_amd import ops
-    g = torch.Generator(device="cuda").manual_seed(B * S + N)
-    K = 256
-    x = torch.randn(B, S, K, device="cuda", generator=g) * 2.0
-    w = torch.randn(N, K, device="cuda", generator=g) * (K ** -0.5)
-    b = torch.randn(N, device="cuda", generator=g)
-    tab = torch.randn(S, N, device="cuda", generator=g) * 3.0
-    got = ops.split_linear_rowtable(ops.to_hl8(x), _Owner(), "w", w, b, tab)
-    want = x.double() @ w.double().t() + b.double() + tab.double()[None]
-    assert got.shape == (B, S, N) and rel_err(got.cpu(), want.float().cpu()) < 3e-6
-
-
-@gpu
-def test_encoder_layer_merged_projections_match_the_separate_ones():
-    """deformable encoder layer, split policy: value_proj(src) / sampling_offsets(src + pos) / attention_weights(src + pos) as ONE GEMM over src with
-    the per-position table W pos + b (MSDeformAttn.forward_merged, ms_deform_attn.py:93-99) against the three projections of the same layer;
-    two chained layers (the second takes its operand from the first's LayerNorm pass), and a batch whose position embedding differs per
-    image keeps the separate form."""
-    import hipie_amd.modeling.transformer as T
-    torch.manual_seed(11)
-    layers = [T.DeformableTransformerEncoderLayer(256, 2048, 4, 8, 4, torch.float32).cuda() for _ in range(2)]
-    for l in layers:
-        for p in l.parameters():
-            torch.nn.init.normal_(p, std=0.04)
-        T.set_split(l)
-    shapes = [(32, 40), (16, 20), (8, 10), (4, 5)]
-    S = sum(h * w for h, w in shapes)
-    ss = torch.tensor(shapes, device="cuda")
-    ls = torch.cat([ss.new_zeros(1), (ss[:, 0] * ss[:, 1]).cumsum(0)[:-1]])
-    B = 5                                                    # 5 x 1700 tokens: ffn_fused and the 256-row tiles with a tail
-    src = torch.randn(B, S, 256, device="cuda")
-    pos = torch.randn(1, S, 256, device="cuda").expand(B, S, 256).contiguous()
-    refs = T.encoder_reference_points(shapes, torch.ones(B, 4, 2, device="cuda"), "cuda")
-
-    def run():
-        x, q = layers[0](src, pos, refs, ss, ls, None, query=None, want_query=True)
-        return layers[1](x, pos, refs, ss, ls, None, query=q)
-    assert T.merged_projections_ok(layers[0].self_attn, src, pos, None)
-    got = run()
-    keep = T.merged_projections_ok
-    T.merged_projections_ok = lambda *a: False
-    try:
-        want = run()
-    finally:
-        T.merged_projections_ok = keep
-    assert rel_err(got.cpu(), want.cpu()) < 1e-5
-    pos2 = pos.clone()
-    pos2[1] += 0.5                                           # image 1 has its own embedding: no shared table
-    assert not T.merged_projections_ok(layers[0].self_attn, src, pos2, None)

@@ -4,7 +4,6 @@ switch off / on (A B A B ...) and prints the mean ms of each.  Switches (functio
   ln     ops.split_linear_ln_ok          output_proj + residual + norm1 of the encoder layers as ONE launch (hipie_gemm_ln)
   dv     transformer.decoder_split_values  the decoder value projections as one batched thin-K GEMM
   bi     ops.bi_i2t_folded_ok            the vision-language fusion attention without the visual projections of width embed_dim
-  mp     transformer.merged_projections_ok  value / offset / weight projections of an encoder layer as one GEMM over src (+ W pos table)
   gn     ops.group_norm(out_nchw=...)    the mask_features GroupNorm writes NCHW itself (no transposing copy behind it)
 python tools/ab_step.py [ln,dv] [rounds]"""
 import os
@@ -34,7 +33,7 @@ def main():
     bench.randomize_degenerate_inits(model)
     model.finalize()
     batch = bench.synth_batch(cfg, 8, 1024, 80, 194, dev, seed=0)
-    keep = {"mp": T.merged_projections_ok, "bi": ops.bi_i2t_folded_ok, "ln": ops.split_linear_ln_ok, "dv": T.decoder_split_values, "gn": ops.group_norm}
+    keep = {"bi": ops.bi_i2t_folded_ok, "ln": ops.split_linear_ln_ok, "dv": T.decoder_split_values, "gn": ops.group_norm}
 
     def gn_plain(*a, **kw):
         kw.pop("out_nchw", None)
@@ -43,8 +42,6 @@ def main():
     def switch(on):
         if "ln" in which:
             ops.split_linear_ln_ok = keep["ln"] if on else (lambda *a: False)
-        if "mp" in which:
-            T.merged_projections_ok = keep["mp"] if on else (lambda *a: False)
         if "bi" in which:
             ops.bi_i2t_folded_ok = keep["bi"] if on else (lambda *a: False)
         if "gn" in which:
