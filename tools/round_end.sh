@@ -15,7 +15,7 @@ timeout 200 python bench.py --config 0 --steps 10 --warmup 3 --no-cpu-baseline -
 timeout 600 python bench.py --graph --timed-only --steps 20 --warmup 3 2>/dev/null | tail -1 > $O/r${R}_bench_line_hipgraph.json
 for f in $O/r${R}_bench_config*.json; do tail -1 $f | cut -c1-200; done
 cd /tmp && export TMPDIR=/tmp
-(cd $GRAFT_REPO_ROOT && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o b -- python bench.py --no-cpu-baseline --no-parity-leg > $O/r${R}_bench_line_under_rocprof.json 2> $O/prof.err)
+(cd $GRAFT_REPO_ROOT && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o b -- python bench.py --no-cpu-baseline --no-parity-leg --no-train-leg > $O/r${R}_bench_line_under_rocprof.json 2> $O/prof.err)
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/r${R}_bench_vith_bs8_kernel_stats.csv
 (timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt2 -o b -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-parity-leg --timed-only > $O/prof_timed.json 2> $O/prof2.err)
 cd $GRAFT_REPO_ROOT
