@@ -249,7 +249,23 @@ __device__ __forceinline__ void gm_epi_quads(const f32x16& a, const float4* rq, 
 template <int BN, bool SPLIT, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams pin) {
   GemmParams p = pin;
-  if (gridDim.y > 1) {                          // batched: one (outer, inner) problem per blockIdx.y
+  int vtile = -1;
+  if (VAR == 8) {
+    // batched with the INNER index fastest (grid: tiles * n_inner x n_outer): the n_inner problems of one row tile share their A operand (the
+    // heads of the folded fusion attention all read the visual stream), so they run back to back inside ONE XCD's contiguous range of ids
+    // and the 256 KB A tile is fetched once into that XCD's L2 instead of once per head (PMC: 1.57 GB fetched per launch for 0.18 GB of A)
+    const int nblk = p.tiles_m * p.tiles_n * p.nbi;
+    const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    const int bo = blockIdx.y, bi = v % p.nbi;
+    vtile = v / p.nbi;
+    p.A += bo * p.a_bo + bi * p.a_bi;
+    p.W += bo * p.w_bo + bi * p.w_bi;
+    p.out += bo * p.o_bo + bi * p.o_bi;
+    if (p.sm_mask != nullptr) p.sm_mask += (long)bo * p.sm_L;
+    if (p.sm_bias != nullptr) p.sm_bias += ((long)bo * p.nbi + bi) * p.N;
+  } else if (gridDim.y > 1) {                   // batched: one (outer, inner) problem per blockIdx.y
     const int bo = blockIdx.y / p.nbi, bi = blockIdx.y - bo * p.nbi;
     p.A += bo * p.a_bo + bi * p.a_bi;
     p.W += bo * p.w_bo + bi * p.w_bi;
@@ -282,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel(const GemmParams pin) {
     const int nblk = p.tiles_m * p.tiles_n;
     const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
     const int q = nblk >> 3, r = nblk & 7;
-    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    const int v = (VAR == 8) ? vtile : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     if (p.group_m > 1) {
       const int gsz = p.group_m * p.tiles_n;
       const int g = v / gsz, w = v - g * gsz;
@@ -798,7 +814,10 @@ static int launch_gemm(GemmParams& p, hipStream_t st, int batches = 1) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (dev >= 0 && dev < 64) lds_set[dev] = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n), (unsigned)batches), dim3(512), lds, st, p);
+  if (VAR == 8)       // inner index fastest inside blockIdx.x (see the kernel): grid = tiles * n_inner x n_outer
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n * p.nbi), (unsigned)(batches / p.nbi)), dim3(512), lds, st, p);
+  else
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n), (unsigned)batches), dim3(512), lds, st, p);
   return check_launch("gemm");
 }
 
